@@ -1,0 +1,234 @@
+"""Shared helpers for the test-suite (test infrastructure only).
+
+* ctypes binding of the CPU oracle (oracle/libw2b_oracle.so) -- the checker.
+* deterministic synthetic corpora (no network: text8 is not available offline).
+* a runner for the unmodified reference binaries under oracle/_ref/ (compiled by
+  oracle/Makefile from /root/reference when that mount exists).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int)
+c_i64p = C.POINTER(C.c_longlong)
+
+
+def fptr(a):
+    return a.ctypes.data_as(c_f32p)
+
+
+def iptr(a):
+    return a.ctypes.data_as(c_i32p)
+
+
+def lptr(a):
+    return a.ctypes.data_as(c_i64p)
+
+
+class OracleModel(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_longlong), ("dim", C.c_longlong), ("train_words", C.c_longlong),
+        ("iter", C.c_longlong),
+        ("window", C.c_int), ("negative", C.c_int), ("bitlevel", C.c_int), ("num_threads", C.c_int),
+        ("starting_alpha", C.c_float), ("sample", C.c_float), ("reg", C.c_float),
+        ("cn", c_i64p), ("u", c_f32p), ("v", c_f32p), ("exp_table", c_f32p),
+        ("table", c_i32p), ("table_size", C.c_longlong),
+        ("alpha", C.c_float), ("word_count_actual", C.c_longlong), ("compute_loss", C.c_int),
+    ]
+
+
+_oracle = None
+
+
+def build_oracle():
+    so = os.path.join(ORACLE_DIR, "libw2b_oracle.so")
+    src = os.path.join(ORACLE_DIR, "w2b_oracle.c")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libw2b_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def oracle():
+    """ctypes handle of the CPU oracle (built on demand with gcc)."""
+    global _oracle
+    if _oracle is not None:
+        return _oracle
+    L = C.CDLL(build_oracle())
+    L.w2bo_quantize.restype = C.c_float
+    L.w2bo_quantize.argtypes = [C.c_float, C.c_int]
+    L.w2bo_quantize_array.argtypes = [c_f32p, c_f32p, C.c_longlong, C.c_int]
+    L.w2bo_sigmoid.restype = C.c_float
+    L.w2bo_sigmoid.argtypes = [C.c_float]
+    L.w2bo_build_exp_table.argtypes = [c_f32p]
+    L.w2bo_lcg_next.restype = C.c_uint64
+    L.w2bo_lcg_next.argtypes = [C.c_uint64]
+    L.w2bo_exp_index.restype = C.c_int
+    L.w2bo_exp_index.argtypes = [C.c_float]
+    L.w2bo_init_net.argtypes = [C.c_longlong, C.c_longlong, c_f32p, c_f32p]
+    L.w2bo_build_unigram_table.argtypes = [c_i64p, C.c_longlong, c_i32p, C.c_longlong]
+    L.w2bo_keep_prob.restype = C.c_float
+    L.w2bo_keep_prob.argtypes = [C.c_longlong, C.c_float, C.c_longlong]
+    L.w2bo_center_update.restype = C.c_double
+    L.w2bo_center_update.argtypes = [C.POINTER(OracleModel), c_i32p, C.c_int, c_i32p, c_i32p, C.c_int,
+                                     C.c_float, c_f32p]
+    L.w2bo_train_tuples.restype = C.c_double
+    L.w2bo_train_tuples.argtypes = [C.POINTER(OracleModel), C.c_longlong, c_i32p, c_i32p, c_i32p, c_i32p,
+                                    C.c_float]
+    L.w2bo_train_worker_tokens.restype = C.c_double
+    L.w2bo_train_worker_tokens.argtypes = [C.POINTER(OracleModel), C.c_longlong, c_i32p, C.c_longlong,
+                                           C.c_longlong, C.c_int]
+    L.w2bo_train_epoch_tokens.restype = C.c_double
+    L.w2bo_train_epoch_tokens.argtypes = [C.POINTER(OracleModel), c_i32p, C.c_longlong, c_i64p, c_i32p,
+                                          C.c_int]
+    L.w2bo_vocab_learn.restype = C.c_void_p
+    L.w2bo_vocab_learn.argtypes = [C.c_char_p, C.c_int]
+    L.w2bo_vocab_free.argtypes = [C.c_void_p]
+    for f in ("w2bo_vocab_size", "w2bo_vocab_train_words", "w2bo_vocab_file_size"):
+        getattr(L, f).restype = C.c_longlong
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.w2bo_vocab_word.restype = C.c_char_p
+    L.w2bo_vocab_word.argtypes = [C.c_void_p, C.c_longlong]
+    L.w2bo_vocab_count.restype = C.c_longlong
+    L.w2bo_vocab_count.argtypes = [C.c_void_p, C.c_longlong]
+    L.w2bo_vocab_search.restype = C.c_int
+    L.w2bo_vocab_search.argtypes = [C.c_void_p, C.c_char_p]
+    L.w2bo_tokenize_file.restype = C.c_longlong
+    L.w2bo_tokenize_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(c_i32p), C.POINTER(c_i64p)]
+    L.w2bo_shard_start.restype = C.c_longlong
+    L.w2bo_shard_start.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong, c_i64p, C.c_longlong, c_i32p]
+    L.w2bo_run.restype = C.c_int
+    L.w2bo_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                           C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_double)]
+    _oracle = L
+    return L
+
+
+class OracleState:
+    """Convenience owner of an oracle model (numpy-backed buffers)."""
+
+    def __init__(self, cn, dim, window=5, negative=5, bitlevel=1, num_threads=1, iters=1, alpha=0.05,
+                 sample=1e-3, reg=0.0, table_size=100000, compute_loss=1, init=True):
+        L = oracle()
+        self.L = L
+        self.cn = np.ascontiguousarray(cn, dtype=np.int64)
+        V = len(self.cn)
+        self.V, self.D = V, dim
+        self.u = np.zeros((V, dim), np.float32)
+        self.v = np.zeros((V, dim), np.float32)
+        if init:
+            L.w2bo_init_net(V, dim, fptr(self.u), fptr(self.v))
+        self.exp_table = np.zeros(1001, np.float32)
+        L.w2bo_build_exp_table(fptr(self.exp_table))
+        self.table = np.zeros(table_size, np.int32)
+        if negative > 0:
+            L.w2bo_build_unigram_table(lptr(self.cn), V, iptr(self.table), table_size)
+        m = OracleModel()
+        m.vocab_size, m.dim, m.train_words, m.iter = V, dim, int(self.cn.sum()), iters
+        m.window, m.negative, m.bitlevel, m.num_threads = window, negative, bitlevel, num_threads
+        m.starting_alpha, m.sample, m.reg = alpha, sample, reg
+        m.cn, m.u, m.v = lptr(self.cn), fptr(self.u), fptr(self.v)
+        m.exp_table, m.table, m.table_size = fptr(self.exp_table), iptr(self.table), table_size
+        m.alpha, m.word_count_actual, m.compute_loss = alpha, 0, compute_loss
+        self.m = m
+
+    def train_tuples(self, center, ctx_off, ctx, neg, alpha):
+        center = np.ascontiguousarray(center, np.int32)
+        ctx_off = np.ascontiguousarray(ctx_off, np.int32)
+        ctx = np.ascontiguousarray(ctx, np.int32)
+        neg = np.ascontiguousarray(neg, np.int32)
+        return self.L.w2bo_train_tuples(C.byref(self.m), len(center), iptr(center), iptr(ctx_off),
+                                        iptr(ctx), iptr(neg), alpha)
+
+    def train_epoch_tokens(self, ids, starts, overrides=None):
+        ids = np.ascontiguousarray(ids, np.int32)
+        starts = np.ascontiguousarray(starts, np.int64)
+        ov = None if overrides is None else np.ascontiguousarray(overrides, np.int32)
+        return self.L.w2bo_train_epoch_tokens(C.byref(self.m), iptr(ids), len(ids), lptr(starts),
+                                              None if ov is None else iptr(ov), len(starts))
+
+
+# ----------------------------------------------------------------------------- corpora
+
+def zipf_ids(rng, vocab, n, s=1.0):
+    """ids in [1, vocab) with P(k) ~ 1/k^s (rank 1 most frequent)."""
+    w = 1.0 / np.arange(1, vocab, dtype=np.float64) ** s
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    return (np.searchsorted(cdf, rng.random(n)) + 1).astype(np.int64)
+
+
+def write_corpus(path, seed=0, vocab=300, n_tokens=5000, line_len=40, quirks=True):
+    """A small whitespace-separated corpus of tokens 'w<id>' with the tokenizer's corner cases:
+    tabs, CRs, empty lines, a very long line (> MAX_SENTENCE_LENGTH tokens), no trailing newline."""
+    rng = np.random.default_rng(seed)
+    ids = zipf_ids(rng, vocab, n_tokens)
+    out = []
+    i = 0
+    line = 0
+    while i < n_tokens:
+        if quirks and line == 3:
+            ln = 1300                      # > 1000-token sentence chunking (ref :410)
+        elif quirks and line == 5:
+            ln = 0                         # empty line -> bare </s> (ref :145-147)
+        else:
+            ln = int(rng.integers(1, 2 * line_len))
+        toks = ["w%d" % t for t in ids[i:i + ln]]
+        i += ln
+        sep = "\t" if (quirks and line % 7 == 2) else " "
+        s = sep.join(toks)
+        if quirks and line % 5 == 1:
+            s = "  " + s + " \r"
+        out.append(s)
+        line += 1
+    text = "\n".join(out)                  # no trailing newline: last token dropped (ref :135-138)
+    with open(path, "w") as f:
+        f.write(text)
+    return path
+
+
+# ----------------------------------------------------------------------------- reference binaries
+
+def ref_binary(name):
+    p = os.path.join(REF_DIR, name)
+    return p if os.path.exists(p) else None
+
+
+def run_ref(name, train, output, **kw):
+    """Run oracle/_ref/<name> with word2bits flags; returns stdout."""
+    exe = ref_binary(name)
+    assert exe, "oracle/_ref/%s not built (make -C oracle ref needs /root/reference)" % name
+    args = [exe, "-train", train, "-output", output]
+    for k, v in kw.items():
+        args += ["-" + k.replace("_", "-"), str(v)]
+    return subprocess.run(args, check=True, capture_output=True, text=True).stdout
+
+
+def read_vectors(path, binary):
+    """Parse a word2bits output file (ref :560-576) -> (words, float32 matrix)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    nl = data.index(b"\n")
+    V, D = (int(x) for x in data[:nl].split())
+    pos = nl + 1
+    words, M = [], np.zeros((V, D), np.float32)
+    for a in range(V):
+        sp = data.index(b" ", pos)
+        words.append(data[pos:sp].decode("latin1"))
+        pos = sp + 1
+        if binary:
+            M[a] = np.frombuffer(data, dtype="<f4", count=D, offset=pos)
+            pos += 4 * D
+        else:
+            nl2 = data.index(b"\n", pos)
+            M[a] = np.array(data[pos:nl2].split(), dtype=np.float64).astype(np.float32)
+            pos = nl2
+        assert data[pos:pos + 1] == b"\n"
+        pos += 1
+    return words, M
