@@ -1,0 +1,356 @@
+#!/usr/bin/env python3
+"""bench.py -- training words/sec of the Word2Bits hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): synthetic 100M-token Zipf(1) stream, vocab=400K, bitlevel=1,
+size=800, window=8, negative=24, sample=0, on one MI355X.  A "step" is ONE launch of the fused
+CBOW/negative-sampling update kernel over one batch of centre words:
+
+  --form tuples  (default) : 2^20 explicit (centre, 9 context rows, 24 negatives) tuples per step,
+                             SURVEY.md 8d / north_star "synthetic (center, context, K-negatives) tuples"
+  --form worker            : every Hogwild worker (workgroup) advances --positions sentence positions
+                             of the resident token stream, drawing windows/negatives on device exactly
+                             like TrainModelThread (ref src/word2bits.cpp:363-516)
+
+All inputs are resident in HBM before the timed region.  N>1: one process per GPU
+(torch.distributed.run), each rank trains its own shard (weak scaling) on its own replica and
+the replicas are combined every --sync-every steps by an RCCL all-reduce of [u||v] (delta-sum),
+inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     -- algorithmic HBM bytes per launch / hipEvent-measured launch duration vs 8 TB/s
+  cpu_baseline -- the reference CPU program (oracle/_ref/word2bits_stock, built from the unmodified
+                  reference sources) timed on this host on a bounded sample of the same shape
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--form", choices=["tuples", "worker"], default="tuples")
+    ap.add_argument("--vocab", type=int, default=400_000)
+    ap.add_argument("--dim", type=int, default=800)
+    ap.add_argument("--window", type=int, default=8)
+    ap.add_argument("--negative", type=int, default=24)
+    ap.add_argument("--bitlevel", type=int, default=1)
+    ap.add_argument("--tokens", type=int, default=100_000_000)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="centre words per step (tuples form)")
+    ap.add_argument("--workers", type=int, default=0, help="Hogwild workers (worker form); 0 = 4 per CU")
+    ap.add_argument("--positions", type=int, default=1024, help="positions per worker per step")
+    ap.add_argument("--ids", choices=["zipf", "uniform"], default="zipf")
+    ap.add_argument("--sync-every", type=int, default=16)
+    ap.add_argument("--sync-mode", type=int, default=0)
+    ap.add_argument("--cpu-baseline", choices=["reference", "port", "none"], default="reference")
+    ap.add_argument("--cpu-tokens", type=int, default=2_000_000)
+    ap.add_argument("--grid", type=int, default=0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_word(D, cw, K):
+    # every touched row read once + written once, ids read once
+    return 8 * D * (cw + K + 1) + 4 * (1 + cw + K)
+
+
+def zipf_cdf(torch, V, device, uniform):
+    if uniform:
+        w = torch.ones(V - 1, dtype=torch.float64, device=device)
+    else:
+        w = 1.0 / torch.arange(1, V, dtype=torch.float64, device=device)
+    cdf = torch.cumsum(w, 0)
+    return cdf / cdf[-1]
+
+
+def draw_ids(torch, cdf, n, gen):
+    out = torch.empty(n, dtype=torch.int32, device=cdf.device)
+    chunk = 1 << 24
+    for o in range(0, n, chunk):
+        m = min(chunk, n - o)
+        r = torch.rand(m, dtype=torch.float64, device=cdf.device, generator=gen)
+        out[o:o + m] = (torch.searchsorted(cdf, r) + 1).clamp_(max=len(cdf)).to(torch.int32)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline_reference(args):
+    """Time the UNMODIFIED reference program (training phase only) on this host.
+    Corpus per BASELINE.md section 4 / SURVEY Appendix C.8: every vocabulary word 5x (so that
+    -min-count 5 keeps V rows), then a Zipf(1) stream; newline every 1000 tokens."""
+    import pty
+    import re
+    import select
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "word2bits_stock")
+    if not os.path.exists(exe):
+        return None
+    V, nz = args.vocab, args.cpu_tokens
+    rng = np.random.default_rng(1234)
+    base = np.repeat(np.arange(1, V, dtype=np.int64), 5)
+    rng.shuffle(base)
+    w = 1.0 / np.arange(1, V, dtype=np.float64)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    z = np.searchsorted(cdf, rng.random(nz)) + 1
+    ids = np.concatenate([base, z])
+    tmpdir = tempfile.mkdtemp(prefix="w2b_cpu_")
+    path = os.path.join(tmpdir, "corpus.txt")
+    toks = np.char.add("w", ids.astype(str))
+    with open(path, "w") as f:
+        for o in range(0, len(toks), 1000):
+            f.write(" ".join(toks[o:o + 1000]))
+            f.write("\n")
+    cores = os.cpu_count() or 1
+    cmd = [exe, "-train", path, "-output", "/dev/null", "-bitlevel", str(args.bitlevel), "-size", str(args.dim),
+           "-window", str(args.window), "-negative", str(args.negative), "-iter", "1", "-sample", "0",
+           "-binary", "1", "-min-count", "5", "-threads", str(cores)]
+    master, slave = pty.openpty()          # a tty keeps the program's stdout line-buffered
+    p = subprocess.Popen(cmd, stdout=slave, stderr=subprocess.DEVNULL, close_fds=True)
+    os.close(slave)
+    t_start = t_end = None
+    words = None
+    buf = b""
+    deadline = time.time() + 600
+    while time.time() < deadline:
+        r, _, _ = select.select([master], [], [], 1.0)
+        if r:
+            try:
+                chunk = os.read(master, 65536)
+            except OSError:
+                chunk = b""
+            if not chunk:
+                break
+            now = time.time()
+            buf += chunk
+            if t_start is None and b"Starting epoch: 0" in buf:
+                t_start = now
+            m = re.search(rb"Words in train file: (\d+)", buf)
+            if m:
+                words = int(m.group(1))
+            if t_end is None and b"Epoch Loss:" in buf:
+                t_end = now
+                break
+        elif p.poll() is not None:
+            break
+    p.kill()                                 # the save loop that follows is not part of the metric
+    p.wait()
+    os.close(master)
+    try:
+        os.remove(path)
+        os.rmdir(tmpdir)
+    except OSError:
+        pass
+    if t_start is None or t_end is None or not words:
+        return None
+    return {"value": words / (t_end - t_start), "unit": "words/s", "cores": cores, "kind": "reference",
+            "sample": "unmodified reference CPU program (oracle/_ref/word2bits_stock: -O3 -march=x86-64-v3, "
+                      "FMA contraction on), %d tokens = every one of %d words 5x + %d Zipf(1) tokens, V=%d "
+                      "D=%d w=%d K=%d bitlevel=%d -sample 0 -threads %d; training phase only "
+                      "('Starting epoch' -> 'Epoch Loss'), %.1f s"
+                      % (words, V - 1, nz, V, args.dim, args.window, args.negative, args.bitlevel, cores,
+                         t_end - t_start)}
+
+
+def cpu_baseline_port(args):
+    """Time the oracle restatement (oracle/libw2b_oracle.so), Hogwild over all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from w2b_testlib import OracleState
+    V, D = args.vocab, args.dim
+    rng = np.random.default_rng(7)
+    n = args.cpu_tokens
+    w = 1.0 / np.arange(1, V, dtype=np.float64)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    ids = (np.searchsorted(cdf, rng.random(n)) + 1).astype(np.int32)
+    ids[999::1000] = 0
+    cn = np.bincount(ids, minlength=V).astype(np.int64)
+    cn[cn == 0] = 1
+    cores = os.cpu_count() or 1
+    o = OracleState(cn, D, window=args.window, negative=args.negative, bitlevel=args.bitlevel,
+                    num_threads=cores, iters=1, sample=0.0, table_size=100_000_000, compute_loss=0)
+    starts = (np.arange(cores, dtype=np.int64) * (n // cores))
+    t0 = time.time()
+    o.train_epoch_tokens(ids, starts)
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "words/s", "cores": cores, "kind": "port",
+            "sample": "oracle/w2b_oracle.c (bit-exact restatement, -O2 no FMA), %d Zipf(1) tokens, V=%d D=%d "
+                      "w=%d K=%d bitlevel=%d, %d pthreads Hogwild, %.1f s" %
+                      (n, V, D, args.window, args.negative, args.bitlevel, cores, dt)}
+
+
+# ------------------------------------------------------------------------------------------ main
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import word2bits_amd as w2b
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    V, D, W, K = args.vocab, args.dim, args.window, args.negative
+    cw = W + 1                                   # mean context words at window W
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)                 # stream seed = rank (mirrors ref :368)
+
+    # ---- synthetic corpus resident in HBM (untimed)
+    per_rank_tokens = args.tokens                 # weak scaling: the same stream length per GPU
+    cdf = zipf_cdf(torch, V, dev, args.ids == "uniform")
+    stream = draw_ids(torch, cdf, per_rank_tokens, gen)
+    stream[999::1000] = 0                        # "</s>" every 1000 tokens
+    counts = torch.bincount(stream.long(), minlength=V).clamp_(min=1).cpu().numpy().astype(np.int64)
+    train_words = int(counts.sum())
+
+    props = torch.cuda.get_device_properties(dev)
+    ncu = props.multi_processor_count
+    workers = args.workers if args.workers > 0 else 4 * ncu
+    t = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=workers if args.form == "worker" else 1,
+                    iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words, compute_loss=False,
+                    device=local_rank)
+    t.init_net()                                  # InitNet values (LCG seed 1), ref :343-361
+    t.set_vocab_counts(counts, 100_000_000)       # 1e8-entry unigram table, ref :112-128
+    if world > 1:
+        uid = [w2b.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        t.comm_init(world, rank, uid[0])
+
+    nsteps = args.steps + args.warmup
+    if args.form == "tuples":
+        B = args.batch
+        need = nsteps * B
+        reps = (need + per_rank_tokens - 1) // per_rank_tokens
+        table_dev = None
+        batches = []
+        # unigram table on device for drawing negatives with the reference's table semantics
+        import ctypes as C
+        from word2bits_amd import _lib
+        tab = np.empty(100_000_000, np.int32)
+        _lib.check(_lib.lib().w2b_build_unigram_table(counts.ctypes.data_as(_lib.i64p), V,
+                                                      tab.ctypes.data_as(_lib.i32p), len(tab)))
+        table_dev = torch.from_numpy(tab).to(dev)
+        del tab
+        for s in range(nsteps):
+            o = (s * B) % max(1, per_rank_tokens - B)
+            center = stream[o:o + B].clone()
+            center[center == 0] = 1
+            ctx = draw_ids(torch, cdf, B * cw, gen)
+            r = torch.randint(0, 100_000_000, (B * K,), device=dev, generator=gen)
+            neg = table_dev[r]
+            neg[neg == 0] = 1                                   # ref :457 remaps 0 to a random word
+            cexp = center.repeat_interleave(K)
+            neg = torch.where(neg == cexp, (neg % (V - 2)) + 1, neg)        # never the centre (ref :458)
+            off = (torch.arange(B + 1, device=dev, dtype=torch.int32) * cw).contiguous()
+            batches.append((center.contiguous(), off, ctx.contiguous(), neg.contiguous()))
+        del table_dev
+        words_per_step = B
+
+        def step(i):
+            c, off, ctx, neg = batches[i]
+            t.train_tuples_device(B, c.data_ptr(), off.data_ptr(), ctx.data_ptr(), neg.data_ptr(), 0.05,
+                                  args.grid)
+    else:
+        t.set_corpus_device(stream.data_ptr(), per_rank_tokens)
+        starts = (np.arange(workers, dtype=np.int64) * (per_rank_tokens // workers))
+        t.set_shards(starts)
+        t.epoch_begin()
+        words_per_step = workers * args.positions
+
+        def step(i):
+            t.train_step(args.positions)
+
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def run(n0, n1, timed):
+        for i in range(n0, n1):
+            step(i)
+            if world > 1 and (i + 1 - args.warmup) % args.sync_every == 0 and i >= args.warmup:
+                t.sync_replicas(args.sync_mode)
+
+    run(0, args.warmup, False)
+    t.synchronize()
+    t.timing_enable(True)
+    t.timing_read()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, nsteps, True)
+    t.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = t.timing_read()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if args.form == "worker":
+        fin, _, _, _ = t.epoch_status(want_loss=False)
+        assert not fin, "workers ran out of corpus inside the timed region: lower --steps/--positions"
+
+    total_words = words_per_step * args.steps * world
+    value = total_words / dt
+    bpw = algorithmic_bytes_per_word(D, cw, K)
+    avg_launch_s = (kernel_ms / 1e3) / max(1, launches)
+    achieved = words_per_step * bpw / avg_launch_s / 1e9        # GB/s, algorithmic
+    result = {
+        "metric": "training words/sec at dim=%d bitlevel=%d neg=%d" % (D, args.bitlevel, K),
+        "value": value, "unit": "words/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: synthetic %dM-token %s stream, vocab=%d, bitlevel=%d, "
+                               "size=%d, window=%d, negative=%d, sample=0; form=%s, %d centre words/step/GPU"
+                               % (args.tokens // 1_000_000, args.ids, V, args.bitlevel, D, W, K, args.form,
+                                  words_per_step),
+                   "form": args.form, "vocab": V, "dim": D, "window": W, "negative": K,
+                   "bitlevel": args.bitlevel, "words_per_step_per_gpu": words_per_step,
+                   "replica_sync": ("rccl all-reduce [u||v] every %d steps, mode %d" %
+                                    (args.sync_every, args.sync_mode)) if world > 1 else "none (1 GPU)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                     "kernel": "k_train_%s" % ("tuples" if args.form == "tuples" else "workers"),
+                     "algorithmic_bytes_per_word": bpw, "avg_launch_ms": avg_launch_s * 1e3,
+                     "launches": launches},
+    }
+    t.close()
+    if rank == 0:
+        cb = None
+        if world == 1 and args.cpu_baseline != "none":
+            try:
+                cb = cpu_baseline_reference(args) if args.cpu_baseline == "reference" else None
+                if cb is None:
+                    cb = cpu_baseline_port(args)
+            except Exception as e:            # the GPU number must still be reported
+                cb = {"value": None, "unit": "words/s", "cores": os.cpu_count(), "kind": "port",
+                      "sample": "failed: %r" % (e,)}
+        result["cpu_baseline"] = cb
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

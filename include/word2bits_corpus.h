@@ -1,0 +1,48 @@
+/*
+ * word2bits_corpus.h -- C ABI of the host-side corpus ingest that feeds the GPU hot path.
+ *
+ * Restates, for an in-memory token stream, what the reference does with stdio on every epoch:
+ * LearnVocabFromTrainFile / ReadWord / SearchVocab / SortVocab (ref src/word2bits.cpp:131-301),
+ * the per-thread fseek shard arithmetic (ref :377) and the output writer (ref :560-576).
+ * Pure host code: usable (and tested) without a GPU.
+ */
+#ifndef WORD2BITS_CORPUS_H
+#define WORD2BITS_CORPUS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct w2b_corpus w2b_corpus;
+
+/* Learn the vocabulary of `train_file` with -min-count `min_count` (ref :265-301, 215-242) and
+ * tokenise the file once into vocabulary ids (0 = "</s>", out-of-vocabulary words dropped as the
+ * reference's reader does at ref :398).  Returns 0, or W2B_EIO if the file cannot be read. */
+int w2b_corpus_load(const char *train_file, int32_t min_count, w2b_corpus **out);
+void w2b_corpus_free(w2b_corpus *c);
+
+int64_t w2b_corpus_vocab_size(const w2b_corpus *c);    /* vocab_size,  ref :49 */
+int64_t w2b_corpus_train_words(const w2b_corpus *c);   /* train_words, ref :233 */
+int64_t w2b_corpus_file_size(const w2b_corpus *c);     /* file_size,   ref :299 */
+const char *w2b_corpus_word(const w2b_corpus *c, int64_t i);
+const int64_t *w2b_corpus_counts(const w2b_corpus *c); /* vocab[].cn, [vocab_size] */
+int32_t w2b_corpus_search(const w2b_corpus *c, const char *word); /* SearchVocab, -1 if absent */
+int64_t w2b_corpus_num_tokens(const w2b_corpus *c);
+const int32_t *w2b_corpus_tokens(const w2b_corpus *c); /* [num_tokens] */
+
+/* Shard starts of `num_threads` workers: worker w would fseek to file_size/num_threads*w (ref :377).
+ * starts[w] = index (into the token stream) of the first whole token at or after that byte;
+ * first_override[w] = id of the truncated word when the seek lands inside a word (-1 = not in the
+ * vocabulary), -2 when it lands on a token boundary. */
+int w2b_corpus_shards(const w2b_corpus *c, int32_t num_threads, int64_t *starts, int32_t *first_override);
+
+/* Output writer of ref :560-576: "V D\n", then per row "word " + D values + "\n";
+ * binary != 0 -> raw little-endian float32, else "%lf ".  `values` is [vocab_size][dim],
+ * already quantize(u+v). */
+int w2b_save_vectors(const char *path, const w2b_corpus *c, const float *values, int64_t dim,
+                     int32_t binary);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

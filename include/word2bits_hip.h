@@ -1,0 +1,152 @@
+/*
+ * word2bits_hip.h -- C ABI of the MI355X (gfx950) training hot path of Word2Bits.
+ *
+ * The reference (agnusmaximus/Word2Bits) has no plugin/FFI layer: its hot path is the pthread
+ * start routine  void *TrainModelThread(void *id)  (src/word2bits.cpp:363-516) that communicates
+ * through process globals (src/word2bits.cpp:45-61).  This header is the seam a host program
+ * binds instead of that routine: the globals become an opaque trainer object, the per-epoch
+ * pthread_create/pthread_join pair (src/word2bits.cpp:535-536) becomes
+ * w2b_epoch_begin() + w2b_train_step()... until finished, and the save loop's
+ * quantize(u+v) (src/word2bits.cpp:549-550,568-569) becomes w2b_export_quantized().
+ *
+ * Conventions: plain C symbols, opaque handle, int return (0 = W2B_OK, <0 = error, text via
+ * w2b_last_error()), caller-owned host buffers, library-owned device buffers, no exceptions,
+ * no torch / C++ types.  All "ref" citations are paths inside the reference repository.
+ *
+ * There is NO CPU fallback: every compute entry point fails with W2B_ENOGPU when no
+ * gfx950 device is usable.
+ */
+#ifndef WORD2BITS_HIP_H
+#define WORD2BITS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2B_OK            0
+#define W2B_EINVAL       -1   /* bad argument */
+#define W2B_ENOGPU       -2   /* no usable HIP device */
+#define W2B_EHIP         -3   /* HIP runtime error (see w2b_last_error) */
+#define W2B_ENOMEM       -4
+#define W2B_EUNSUPPORTED -5   /* e.g. -size not a multiple of 4 and > 1024 */
+#define W2B_ERCCL        -6
+#define W2B_ESTATE       -7   /* call order (e.g. train before the corpus was set) */
+#define W2B_EIO          -8
+
+#define W2B_EXP_TABLE_SIZE 1000        /* ref src/word2bits.cpp:30 */
+#define W2B_MAX_EXP 6                  /* ref src/word2bits.cpp:31 */
+#define W2B_MAX_SENTENCE_LENGTH 1000   /* ref src/word2bits.cpp:32 */
+#define W2B_UNIGRAM_TABLE_SIZE 100000000LL /* ref src/word2bits.cpp:60 */
+
+typedef struct w2b_trainer w2b_trainer;
+
+/* The reference's training globals (src/word2bits.cpp:45-61) that the hot path reads. */
+typedef struct w2b_config {
+  int64_t vocab_size;    /* vocab_size                         ref :49 */
+  int64_t train_words;   /* train_words                        ref :51 */
+  int64_t iter;          /* -iter                              ref :51,608 */
+  int32_t layer1_size;   /* -size                              ref :50,598 */
+  int32_t window;        /* -window                            ref :48,605 */
+  int32_t negative;      /* -negative                          ref :59,607 */
+  int32_t bitlevel;      /* -bitlevel                          ref :48,597 */
+  int32_t num_threads;   /* -threads: number of Hogwild workers; one workgroup each (ref :48,608) */
+  float alpha;           /* starting alpha                     ref :53,603 */
+  float sample;          /* -sample                            ref :53,606 */
+  float reg;             /* -reg                               ref :54,599 */
+  int32_t compute_loss;  /* keep the "Cost"/"Epoch Loss" bookkeeping (ref :437-445,480-483) */
+  int32_t device;        /* HIP device ordinal */
+  /* multi-GPU (one replica per GPU): this trainer runs the workers with global ids
+   * [worker_offset, worker_offset + num_threads) out of total_threads (0 = num_threads).  Seeds
+   * (ref :368) and the per-worker quota train_words/num_threads (ref :414) use the GLOBAL numbers;
+   * the alpha schedule (ref :391) extrapolates local progress by total_threads/num_threads. */
+  int32_t worker_offset;
+  int32_t total_threads;
+  int32_t reserved[5];   /* must be zero */
+} w2b_config;
+
+/* ---- library ------------------------------------------------------------------------- */
+const char *w2b_version(void);
+const char *w2b_last_error(void);       /* thread-local text of the last failure */
+int w2b_device_count(void);             /* number of visible HIP devices (0 when none) */
+
+/* ---- host-side tables of the reference (pure host code, usable without a GPU) ---------- */
+/* expTable, ref src/word2bits.cpp:614-618; out[1000] */
+void w2b_build_exp_table(float *out);
+/* InitUnigramTable, ref src/word2bits.cpp:112-128 */
+int w2b_build_unigram_table(const int64_t *cn, int64_t vocab_size, int32_t *table, int64_t table_size);
+/* sub-sampling keep threshold per word, ref src/word2bits.cpp:403-404; out[vocab_size] */
+void w2b_build_keep_prob(const int64_t *cn, int64_t vocab_size, float sample, int64_t train_words,
+                         float *out);
+/* scalar quantizer (host twin of the device function), ref src/word2bits.cpp:73-108 */
+float w2b_quantize(float x, int32_t bitlevel);
+
+/* ---- trainer lifetime ------------------------------------------------------------------ */
+int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out);
+void w2b_trainer_destroy(w2b_trainer *t);
+
+/* ---- model: u ("syn0"), v ("syn1neg"), [vocab_size][layer1_size] fp32 row-major ---------- */
+int w2b_init_net(w2b_trainer *t);                                   /* InitNet, ref :343-361 */
+int w2b_set_model(w2b_trainer *t, const float *u, const float *v);  /* host -> device */
+int w2b_get_model(w2b_trainer *t, float *u, float *v);              /* device -> host */
+/* device addresses of the two tables (contiguous: v directly follows u) */
+int w2b_model_device_ptrs(w2b_trainer *t, void **u_dev, void **v_dev);
+/* quantize(u+v) of the save loop (ref :549-550,568-569) into a host buffer [V][D] */
+int w2b_export_quantized(w2b_trainer *t, float *out);
+
+/* ---- sampler state ------------------------------------------------------------------------ */
+/* word counts vocab[].cn: builds the keep-probability table and, when table_size > 0, the
+ * unigram table (InitUnigramTable) of that size (the reference uses 1e8). */
+int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t table_size);
+int w2b_set_unigram_table(w2b_trainer *t, const int32_t *table, int64_t table_size);
+int w2b_set_exp_table(w2b_trainer *t, const float *exp_table);      /* default: w2b_build_exp_table */
+
+/* ---- form (i): the worker, TrainModelThread(id), ref :363-516 --------------------------------
+ * The corpus is the in-vocabulary token-id stream of the training file (0 = "</s>"; words not in
+ * the vocabulary are already dropped, ref :398).  Worker w starts at ids[starts[w]]; when the
+ * reference's fseek (ref :377) lands inside a word, first_override[w] is the id that the truncated
+ * word maps to (-1: not in vocabulary, -2: seek landed on a token boundary). */
+int w2b_set_corpus(w2b_trainer *t, const int32_t *ids, int64_t n_tokens);
+int w2b_set_corpus_device(w2b_trainer *t, const void *ids_dev, int64_t n_tokens); /* not copied */
+int w2b_set_shards(w2b_trainer *t, const int64_t *starts, const int32_t *first_override /*or NULL*/);
+/* pthread_create of one epoch (ref :535): re-seed every worker (next_random = id, ref :368),
+ * rewind it to its shard start.  alpha / word_count_actual keep running across epochs. */
+int w2b_epoch_begin(w2b_trainer *t);
+/* Advance every unfinished worker by at most max_positions passes of the reference's main loop
+ * (one pass = one sentence position, ref :424-509).  Asynchronous on the trainer's stream. */
+int w2b_train_step(w2b_trainer *t, int64_t max_positions);
+/* blocks; *finished = 1 when all workers have ended their epoch (pthread_join, ref :536) */
+int w2b_epoch_status(w2b_trainer *t, int32_t *finished, int64_t *word_count_actual, float *alpha,
+                     double *loss_sum);
+
+/* ---- form (ii): explicit tuples (benchmark / single-step parity form) ------------------------
+ * n centre words; ctx_off[n+1] CSR into ctx[] (context rows of u, ref :431-447);
+ * neg[n*negative] rows of v drawn for d = 1..negative, -1 = skipped draw (ref :458).
+ * The centre word itself is target d = 0 with label 1 (ref :451-453).
+ * serial != 0: one workgroup applies the tuples strictly in order (the reference's -threads 1
+ * semantics); serial == 0: Hogwild over `grid` workgroups (0 = fill the device). */
+int w2b_train_tuples(w2b_trainer *t, int64_t n, const int32_t *center, const int32_t *ctx_off,
+                     const int32_t *ctx, const int32_t *neg, float alpha, int32_t serial,
+                     double *loss_out /* or NULL */);
+/* same, operands already resident in device memory; asynchronous on the trainer's stream */
+int w2b_train_tuples_device(w2b_trainer *t, int64_t n, const void *center_dev, const void *ctx_off_dev,
+                            const void *ctx_dev, const void *neg_dev, float alpha, int32_t grid);
+
+/* ---- streams / timing ------------------------------------------------------------------------- */
+int w2b_synchronize(w2b_trainer *t);
+/* hipEvent timing of the training kernels launched since the last reset (sum over launches). */
+int w2b_timing_enable(w2b_trainer *t, int32_t on);
+int w2b_timing_read(w2b_trainer *t, double *kernel_ms, int64_t *launches); /* syncs, then resets */
+
+/* ---- multi-GPU: one process per GPU, replicas + periodic all-reduce over RCCL ----------------
+ * Replaces the shared-memory Hogwild of ref :535-536 across devices. */
+#define W2B_UNIQUE_ID_BYTES 128
+int w2b_comm_unique_id(void *out128);                      /* rank 0 creates, others receive */
+int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id128);
+/* mode 0: delta-sum  W = base + sum_r (W_r - base);  mode 1: average  W = mean_r W_r.
+ * A communicator of size 1 (or none) is a no-op that leaves the model bit-identical. */
+int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

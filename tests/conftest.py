@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_count():
+    try:
+        import word2bits_amd
+        return word2bits_amd.lib().w2b_device_count()
+    except Exception:
+        return -1
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """Skips on machines without a GPU; on a GPU box a missing/unloadable library is an ERROR."""
+    import word2bits_amd
+    L = word2bits_amd.lib()          # ImportError here is a hard failure, never a fallback
+    if L.w2b_device_count() <= 0:
+        pytest.skip("no HIP device visible")
+    return L

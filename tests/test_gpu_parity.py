@@ -1,0 +1,192 @@
+"""-m gpu: the HIP hot path against the CPU oracle, through the C ABI (ctypes).
+
+Tolerances (fp32, stated per SURVEY 8c rung 3): the kernel re-associates only the dot product
+f (tree instead of the CPU's serial chain), so after ONE centre-word update from identical state
+rows agree to 1e-6 abs unless f sits within rounding of a sigmoid-table bin edge (then one g
+moves by one table step, <= 2e-4 * alpha); quantized views (levels) of the rows are bit-exact.
+"""
+import numpy as np
+import pytest
+
+import word2bits_amd as w2b
+from w2b_testlib import OracleState, oracle, fptr
+
+pytestmark = pytest.mark.gpu
+
+SINGLE_STEP_ATOL = 2e-5     # one sigmoid-bin flip: |dg| <= ~3e-3*alpha=1.5e-4, times |avg|<=~0.1
+SINGLE_STEP_MEAN = 2e-7
+
+
+def make_pair(gpu, V, D, window, negative, bitlevel, reg=0.0, seed=0, table_size=20000):
+    rng = np.random.default_rng(seed)
+    cn = np.concatenate([[0], np.sort(rng.integers(5, 2000, V - 1))[::-1]]).astype(np.int64)
+    o = OracleState(cn, D, window=window, negative=negative, bitlevel=bitlevel, reg=reg, sample=0.0,
+                    table_size=table_size)
+    t = w2b.Trainer(V, D, window, negative, bitlevel, num_threads=1, iter=1, alpha=0.05, sample=0.0, reg=reg,
+                    train_words=int(cn.sum()), compute_loss=True)
+    # spread the init a little so that bitlevel>=2 sees both levels
+    o.u *= 3.0
+    o.v *= 3.0
+    t.set_model(o.u, o.v)
+    return o, t, rng
+
+
+def disjoint_tuples(rng, V, n, window, negative, with_dups=True):
+    """n tuples over pairwise disjoint row sets (collision-free batch); duplicates only INSIDE a tuple."""
+    perm_u = rng.permutation(np.arange(1, V))
+    perm_v = rng.permutation(np.arange(1, V))
+    pu = pv = 0
+    center, ctx_off, ctx, neg = [], [0], [], []
+    for i in range(n):
+        cw = int(rng.integers(1, 2 * window + 1))
+        rows = list(perm_u[pu:pu + cw]); pu += cw
+        if with_dups and cw >= 3 and i % 3 == 0:
+            rows[-1] = rows[0]                       # a word twice in the window (ref :494-503)
+        if with_dups and cw >= 4 and i % 6 == 0:
+            rows[-2] = rows[0]                       # ... three times
+        c = int(perm_v[pv]); pv += 1
+        ng = list(perm_v[pv:pv + negative]); pv += negative
+        if with_dups and negative >= 3 and i % 2 == 0:
+            ng[2] = ng[0]                            # the same negative drawn twice (ref :450-491)
+        if with_dups and negative >= 2 and i % 5 == 0:
+            ng[1] = -1                               # skipped draw (target == word, ref :458)
+        if with_dups and negative >= 4 and i % 7 == 0:
+            ng[3] = c                                # explicit target == word
+        center.append(c); ctx += rows; ctx_off.append(len(ctx)); neg += ng
+    assert pu < V and pv < V
+    return (np.array(center, np.int32), np.array(ctx_off, np.int32), np.array(ctx, np.int32),
+            np.array(neg, np.int32).reshape(n, negative))
+
+
+def quantized(x, bitlevel):
+    out = np.empty_like(x)
+    oracle().w2bo_quantize_array(fptr(np.ascontiguousarray(x)), fptr(out), x.size, bitlevel)
+    return out
+
+
+@pytest.mark.parametrize("D,window,negative,bitlevel,reg", [
+    (800, 8, 24, 1, 0.0),      # BASELINE configs[1] shape
+    (200, 8, 24, 1, 0.0),      # configs[0] shape
+    (400, 8, 24, 2, 0.0),      # configs[2] shape
+    (1000, 5, 12, 0, 0.0),     # configs[4] shape, full precision
+    (1000, 5, 12, 1, 0.0),
+    (100, 5, 5, 1, 0.0),       # reference defaults
+    (100, 5, 5, 4, 0.001),
+    (64, 3, 7, 8, 0.0),
+    (50, 4, 3, 1, 0.0),        # -size not a multiple of 4: scalar-column path
+    (30, 2, 1, 3, 0.0),        # degenerate bitlevel 3 (+-0)
+    (1200, 2, 3, 2, 0.0),      # > 1024 floats: 5-wave workgroup
+    (36, 40, 70, 1, 0.0),      # window > 32 and negative > 63: multi-trip list building
+])
+def test_single_step_parity_collision_free(gpu, D, window, negative, bitlevel, reg):
+    n = 24
+    V = n * (2 * window + negative + 2) + 64
+    o, t, rng = make_pair(gpu, V, D, window, negative, bitlevel, reg)
+    u0, v0 = o.u.copy(), o.v.copy()
+    center, ctx_off, ctx, neg = disjoint_tuples(rng, V, n, window, negative)
+    lo = o.train_tuples(center, ctx_off, ctx, neg, 0.05)
+    lg = t.train_tuples(center, ctx_off, ctx, neg, 0.05, serial=False)     # Hogwild over workgroups
+    u, v = t.get_model()
+    touched_u = np.unique(ctx)
+    assert not np.array_equal(o.u[touched_u], u0[touched_u]) or bitlevel == 3
+    du, dv = np.abs(u - o.u), np.abs(v - o.v)
+    assert du.max() <= SINGLE_STEP_ATOL and dv.max() <= SINGLE_STEP_ATOL, (du.max(), dv.max())
+    assert du.mean() <= SINGLE_STEP_MEAN and dv.mean() <= SINGLE_STEP_MEAN
+    # untouched rows are bit-identical
+    mask_u = np.ones(V, bool); mask_u[touched_u] = False
+    assert np.array_equal(u[mask_u], u0[mask_u])
+    # quantized levels: bit-exact wherever the master is not within tolerance of a level boundary
+    if bitlevel in (1, 2):
+        qg, qo = quantized(u, bitlevel), quantized(o.u, bitlevel)
+        diff = (qg.view(np.uint32) != qo.view(np.uint32))
+        edge = np.abs(o.u) if bitlevel == 1 else np.abs(np.abs(o.u) - 0.5)
+        assert not np.any(diff & (edge > SINGLE_STEP_ATOL))
+        assert diff.mean() < 1e-4
+    assert lg == pytest.approx(lo, rel=2e-5, abs=1e-3)
+    t.close()
+
+
+@pytest.mark.parametrize("bitlevel", [0, 1, 2])
+def test_serial_chain_matches_oracle(gpu, bitlevel):
+    """One workgroup applies colliding tuples strictly in order == the reference's -threads 1."""
+    V, D, window, negative, n = 40, 96, 4, 6, 300
+    o, t, rng = make_pair(gpu, V, D, window, negative, bitlevel, seed=3)
+    center = rng.integers(1, V, n).astype(np.int32)
+    cws = rng.integers(1, 2 * window + 1, n)
+    ctx_off = np.concatenate([[0], np.cumsum(cws)]).astype(np.int32)
+    ctx = rng.integers(1, V, ctx_off[-1]).astype(np.int32)
+    neg = rng.integers(1, V, (n, negative)).astype(np.int32)
+    lo = o.train_tuples(center, ctx_off, ctx, neg, 0.025)
+    lg = t.train_tuples(center, ctx_off, ctx, neg, 0.025, serial=True)
+    u, v = t.get_model()
+    du, dv = np.abs(u - o.u), np.abs(v - o.v)
+    if bitlevel == 1:
+        # discrete forward values: a sign flip of a near-zero master changes later steps; compare signs
+        agree = np.mean(np.signbit(u) == np.signbit(o.u))
+        assert agree >= 0.995, agree
+        assert np.median(du) <= 1e-5
+    else:
+        assert du.max() <= 2e-3 and dv.max() <= 2e-3, (du.max(), dv.max())
+        assert du.mean() <= 2e-5 and dv.mean() <= 2e-5
+    assert lg == pytest.approx(lo, rel=1e-3)
+    t.close()
+
+
+def test_init_net_bit_exact(gpu):
+    V, D = 777, 200          # V*D not a multiple of 65536: exercises the LUT phase between v and u
+    cn = np.ones(V, np.int64)
+    o = OracleState(cn, D, negative=0)
+    t = w2b.Trainer(V, D, negative=0, num_threads=1)
+    t.init_net()
+    u, v = t.get_model()
+    assert np.array_equal(u.view(np.uint32), o.u.view(np.uint32))
+    assert np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
+    t.close()
+
+
+@pytest.mark.parametrize("bitlevel", [0, 1, 2, 3, 4, 8])
+def test_export_quantized_bit_exact(gpu, bitlevel):
+    V, D = 300, 100
+    rng = np.random.default_rng(bitlevel)
+    u = (rng.standard_normal((V, D)) * 0.6).astype(np.float32)
+    v = (rng.standard_normal((V, D)) * 0.6).astype(np.float32)
+    u[0, :4] = [0.0, -0.0, 0.5, -0.5]
+    v[0, :4] = [0.0, 0.0, 0.0, 0.0]
+    t = w2b.Trainer(V, D, bitlevel=bitlevel, negative=0, num_threads=1)
+    t.set_model(u, v)
+    got = t.export_quantized()
+    want = quantized(u + v, bitlevel)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if bitlevel == 1:        # README.md:125-131: +-0x3EAAAAAB
+        assert set(np.unique(got.view(np.uint32)).tolist()) <= {0x3EAAAAAB, 0xBEAAAAAB}
+    t.close()
+
+
+def test_full_size_properties_cfg2(gpu):
+    """BASELINE configs[1] sizes (V=400K, D=800, K=24): size-independent properties instead of an
+    oracle diff: untouched rows keep their init bits, touched rows move, everything finite, and the
+    exported view only holds the two legal 1-bit levels."""
+    V, D, K, W = 400_000, 800, 24, 8
+    rng = np.random.default_rng(5)
+    t = w2b.Trainer(V, D, W, K, 1, num_threads=1, sample=0.0, compute_loss=False)
+    t.init_net()
+    n = 2048
+    center = rng.integers(1, V, n).astype(np.int32)
+    ctx_off = (np.arange(n + 1) * 9).astype(np.int32)
+    ctx = rng.integers(1, V, 9 * n).astype(np.int32)
+    neg = rng.integers(1, V, (n, K)).astype(np.int32)
+    t.train_tuples(center, ctx_off, ctx, neg, 0.05)
+    u, v = t.get_model()
+    assert np.isfinite(u).all() and np.isfinite(v).all()
+    o = OracleState(np.ones(8, np.int64), D, negative=0)     # LUT period check of the init pattern
+    tu = np.zeros(V, bool); tu[ctx] = True
+    tv = np.zeros(V, bool); tv[center] = True; tv[neg.ravel()] = True
+    # rows nobody touched still hold InitNet values: |x| <= 0.5 and exactly k/65536 - 0.5
+    unt = u[~tu]
+    assert np.array_equal((unt + 0.5) * 65536, np.round((unt + 0.5) * 65536))
+    assert (np.abs(v[tv] - 0).max() > 0)
+    moved_v = np.any(((v[tv] + 0.5) * 65536) != np.round((v[tv] + 0.5) * 65536), axis=1)
+    assert moved_v.mean() > 0.99
+    q = t.export_quantized()
+    assert set(np.unique(q.view(np.uint32)).tolist()) <= {0x3EAAAAAB, 0xBEAAAAAB}
+    t.close()

@@ -44,23 +44,24 @@ class OracleModel(C.Structure):
     ]
 
 
-_oracle = None
+_oracle = {}
 
 
-def build_oracle():
-    so = os.path.join(ORACLE_DIR, "libw2b_oracle.so")
+def build_oracle(fma=False):
+    name = "libw2b_oracle_fma.so" if fma else "libw2b_oracle.so"
+    so = os.path.join(ORACLE_DIR, name)
     src = os.path.join(ORACLE_DIR, "w2b_oracle.c")
     if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "libw2b_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", ORACLE_DIR, name], stdout=subprocess.DEVNULL)
     return so
 
 
-def oracle():
-    """ctypes handle of the CPU oracle (built on demand with gcc)."""
-    global _oracle
-    if _oracle is not None:
-        return _oracle
-    L = C.CDLL(build_oracle())
+def oracle(fma=False):
+    """ctypes handle of the CPU oracle (built on demand with gcc).  fma=True: the same source
+    compiled with FMA contraction -- a second legitimate build used only as a drift yardstick."""
+    if fma in _oracle:
+        return _oracle[fma]
+    L = C.CDLL(build_oracle(fma))
     L.w2bo_quantize.restype = C.c_float
     L.w2bo_quantize.argtypes = [C.c_float, C.c_int]
     L.w2bo_quantize_array.argtypes = [c_f32p, c_f32p, C.c_longlong, C.c_int]
@@ -106,7 +107,7 @@ def oracle():
     L.w2bo_run.restype = C.c_int
     L.w2bo_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_double)]
-    _oracle = L
+    _oracle[fma] = L
     return L
 
 
@@ -114,8 +115,8 @@ class OracleState:
     """Convenience owner of an oracle model (numpy-backed buffers)."""
 
     def __init__(self, cn, dim, window=5, negative=5, bitlevel=1, num_threads=1, iters=1, alpha=0.05,
-                 sample=1e-3, reg=0.0, table_size=100000, compute_loss=1, init=True):
-        L = oracle()
+                 sample=1e-3, reg=0.0, table_size=100000, compute_loss=1, init=True, fma=False):
+        L = oracle(fma)
         self.L = L
         self.cn = np.ascontiguousarray(cn, dtype=np.int64)
         V = len(self.cn)

@@ -1,0 +1,260 @@
+// w2b_corpus.cpp -- host-side corpus ingest behind include/word2bits_corpus.h.
+// One pass over a memory-mapped training file builds the vocabulary, a second pass emits the
+// int32 token stream the GPU workers walk.  Semantics follow the reference's stdio reader
+// (ref src/word2bits.cpp:131-301, :377) -- see the notes at each function.
+#include "../../include/word2bits_corpus.h"
+#include "../../include/word2bits_hip.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int kMaxWord = 4096;          // MAX_STRING, ref :29
+constexpr int64_t kCheckpointEvery = 1 << 15;
+
+struct Reader {                          // byte cursor over the mapped file
+  const unsigned char *buf;
+  int64_t size, pos;
+};
+
+// One token as ReadWord delivers it (ref :131-155): bytes 13 are skipped, ' ' '\t' '\n' separate,
+// a newline is its own token "</s>", words are cut at kMaxWord-1 characters (the last slot keeps
+// being overwritten), a final word that runs into end-of-file is dropped.
+// Returns false at end of file.  `begin` = offset of the token's first byte.
+inline bool next_token(Reader &r, char *word, int &len, int64_t &begin) {
+  int a = 0;
+  while (true) {
+    if (r.pos >= r.size) return false;
+    const int ch = r.buf[r.pos++];
+    if (ch == 13) continue;
+    if (ch == ' ' || ch == '\t' || ch == '\n') {
+      if (a > 0) {
+        if (ch == '\n') r.pos--;       // the newline is delivered as the next token
+        break;
+      }
+      if (ch == '\n') {
+        memcpy(word, "</s>", 5);
+        len = 4;
+        begin = r.pos - 1;
+        return true;
+      }
+      continue;
+    }
+    if (a == 0) begin = r.pos - 1;
+    word[a++] = (char)ch;
+    if (a >= kMaxWord - 1) a--;
+  }
+  word[a] = 0;
+  len = a;
+  return true;
+}
+
+inline uint64_t fnv1a(const char *s, int len) {
+  uint64_t h = 1469598103934665603ULL;
+  for (int i = 0; i < len; i++) {
+    h ^= (unsigned char)s[i];
+    h *= 1099511628211ULL;
+  }
+  return h;
+}
+
+struct StringMap {                        // open addressing: word -> dense id
+  std::vector<int32_t> slot;
+  std::vector<uint64_t> hash;
+  std::vector<uint32_t> off;              // offset of each word in the arena
+  std::vector<char> arena;
+  uint64_t mask = 0;
+
+  void rehash(size_t cap) {
+    slot.assign(cap, -1);
+    mask = cap - 1;
+    for (size_t i = 0; i < hash.size(); i++) {
+      uint64_t h = hash[i] & mask;
+      while (slot[h] != -1) h = (h + 1) & mask;
+      slot[h] = (int32_t)i;
+    }
+  }
+  const char *word(int32_t id) const { return arena.data() + off[id]; }
+  int32_t find(const char *w, int len, uint64_t h) const {
+    uint64_t p = h & mask;
+    while (true) {
+      const int32_t id = slot[p];
+      if (id == -1) return -1;
+      if (hash[id] == h && !strcmp(word(id), w)) return id;
+      p = (p + 1) & mask;
+    }
+  }
+  int32_t add(const char *w, int len, uint64_t h) {
+    if ((hash.size() + 1) * 2 > slot.size()) rehash(slot.empty() ? 1 << 16 : slot.size() * 2);
+    const int32_t id = (int32_t)hash.size();
+    hash.push_back(h);
+    off.push_back((uint32_t)arena.size());
+    arena.insert(arena.end(), w, w + len + 1);
+    uint64_t p = h & mask;
+    while (slot[p] != -1) p = (p + 1) & mask;
+    slot[p] = id;
+    return id;
+  }
+};
+
+}  // namespace
+
+struct w2b_corpus {
+  std::vector<std::string> words;         // final vocabulary order (row order of u / v)
+  std::vector<int64_t> counts;
+  StringMap final_map;                    // word -> final id
+  int64_t train_words = 0, file_size = 0;
+  std::vector<int32_t> tokens;            // in-vocabulary token stream
+  // sparse index for the shard arithmetic: raw-token checkpoints
+  std::vector<int64_t> cp_byte, cp_index; // byte offset of a raw token / number of in-vocab tokens before it
+  int fd = -1;
+  const unsigned char *map = nullptr;
+};
+
+extern "C" void w2b_corpus_free(w2b_corpus *c) {
+  if (!c) return;
+  if (c->map && c->file_size > 0) munmap((void *)c->map, (size_t)c->file_size);
+  if (c->fd >= 0) close(c->fd);
+  delete c;
+}
+
+extern "C" int w2b_corpus_load(const char *train_file, int32_t min_count, w2b_corpus **out) {
+  if (!train_file || !out) return W2B_EINVAL;
+  *out = nullptr;
+  const int fd = open(train_file, O_RDONLY);
+  if (fd < 0) return W2B_EIO;
+  struct stat st;
+  if (fstat(fd, &st) != 0) { close(fd); return W2B_EIO; }
+  w2b_corpus *c = new w2b_corpus();
+  c->fd = fd;
+  c->file_size = st.st_size;
+  if (st.st_size > 0) {
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) { w2b_corpus_free(c); return W2B_EIO; }
+    c->map = (const unsigned char *)m;
+  }
+  // ---- pass 1: count (ref :277-293).  "</s>" is vocabulary entry 0 from the start (ref :276).
+  StringMap seen;
+  std::vector<int64_t> cn;
+  seen.add("</s>", 4, fnv1a("</s>", 4));
+  cn.push_back(0);
+  std::vector<int32_t> raw;               // first-appearance id of every raw token
+  char word[kMaxWord];
+  int len;
+  int64_t begin = 0;
+  Reader r{c->map, c->file_size, 0};
+  while (next_token(r, word, len, begin)) {
+    const uint64_t h = fnv1a(word, len);
+    int32_t id = seen.find(word, len, h);
+    if (id < 0) { id = seen.add(word, len, h); cn.push_back(0); }
+    cn[id]++;
+    raw.push_back(id);
+  }
+  // ---- SortVocab (ref :215-242): "</s>" stays first, the rest by count descending.  glibc's qsort
+  // is a merge sort for arrays of this size, i.e. ties keep first-appearance order: stable_sort.
+  const int32_t nseen = (int32_t)cn.size();
+  std::vector<int32_t> order(nseen);
+  for (int32_t i = 0; i < nseen; i++) order[i] = i;
+  std::stable_sort(order.begin() + 1, order.end(), [&](int32_t a, int32_t b) { return cn[a] > cn[b]; });
+  std::vector<int32_t> remap(nseen, -1);
+  for (int32_t k = 0; k < nseen; k++) {
+    const int32_t id = order[k];
+    if (cn[id] < min_count && k != 0) continue;          // ref :225
+    remap[id] = (int32_t)c->words.size();
+    c->words.emplace_back(seen.word(id));
+    c->counts.push_back(cn[id]);
+    c->train_words += cn[id];                             // ref :233
+  }
+  for (size_t i = 0; i < c->words.size(); i++)
+    c->final_map.add(c->words[i].c_str(), (int)c->words[i].size(),
+                     fnv1a(c->words[i].c_str(), (int)c->words[i].size()));
+  // ---- pass 2: token stream + sparse byte index
+  c->tokens.reserve(raw.size());
+  r.pos = 0;
+  int64_t k = 0;
+  while (next_token(r, word, len, begin)) {
+    if ((k % kCheckpointEvery) == 0) {
+      c->cp_byte.push_back(begin);
+      c->cp_index.push_back((int64_t)c->tokens.size());
+    }
+    const int32_t id = remap[raw[k]];
+    if (id >= 0) c->tokens.push_back(id);
+    k++;
+  }
+  *out = c;
+  return W2B_OK;
+}
+
+extern "C" int64_t w2b_corpus_vocab_size(const w2b_corpus *c) { return (int64_t)c->words.size(); }
+extern "C" int64_t w2b_corpus_train_words(const w2b_corpus *c) { return c->train_words; }
+extern "C" int64_t w2b_corpus_file_size(const w2b_corpus *c) { return c->file_size; }
+extern "C" const char *w2b_corpus_word(const w2b_corpus *c, int64_t i) { return c->words[i].c_str(); }
+extern "C" const int64_t *w2b_corpus_counts(const w2b_corpus *c) { return c->counts.data(); }
+extern "C" int64_t w2b_corpus_num_tokens(const w2b_corpus *c) { return (int64_t)c->tokens.size(); }
+extern "C" const int32_t *w2b_corpus_tokens(const w2b_corpus *c) { return c->tokens.data(); }
+
+extern "C" int32_t w2b_corpus_search(const w2b_corpus *c, const char *w) {
+  const int len = (int)strlen(w);
+  return c->final_map.find(w, len, fnv1a(w, len));
+}
+
+extern "C" int w2b_corpus_shards(const w2b_corpus *c, int32_t num_threads, int64_t *starts,
+                                 int32_t *first_override) {
+  if (!c || num_threads < 1 || !starts) return W2B_EINVAL;
+  char word[kMaxWord];
+  int len;
+  for (int32_t w = 0; w < num_threads; w++) {
+    const int64_t off = c->file_size / (int64_t)num_threads * (int64_t)w;    // ref :377
+    // walk whole tokens from the last checkpoint at or before `off`
+    size_t cp = std::upper_bound(c->cp_byte.begin(), c->cp_byte.end(), off) - c->cp_byte.begin();
+    int64_t index = 0, begin = 0, boundary = -1;
+    Reader r{c->map, c->file_size, 0};
+    if (cp > 0) { r.pos = c->cp_byte[cp - 1]; index = c->cp_index[cp - 1]; }
+    while (true) {
+      const int64_t save = r.pos;
+      if (!next_token(r, word, len, begin)) { boundary = -1; break; }      // ran into end of file
+      if (begin >= off) { boundary = begin; r.pos = save; break; }
+      if (w2b_corpus_search(c, word) >= 0) index++;
+    }
+    starts[w] = index;
+    int32_t ov = -2;
+    // what the reference's reader sees first after the seek: either the whole token at `boundary`,
+    // or the tail of a word that started before `off`.
+    Reader q{c->map, c->file_size, off};
+    int64_t qb = 0;
+    if (next_token(q, word, len, qb)) {
+      if (qb != boundary) ov = w2b_corpus_search(c, word);
+    }
+    if (first_override) first_override[w] = ov;
+  }
+  return W2B_OK;
+}
+
+extern "C" int w2b_save_vectors(const char *path, const w2b_corpus *c, const float *values, int64_t dim,
+                                int32_t binary) {
+  if (!path || !c || !values) return W2B_EINVAL;
+  FILE *fo = fopen(path, "wb");
+  if (!fo) return W2B_EIO;
+  static char big[1 << 20];
+  setvbuf(fo, big, _IOFBF, sizeof big);
+  const int64_t V = (int64_t)c->words.size();
+  fprintf(fo, "%lld %lld\n", (long long)V, (long long)dim);
+  for (int64_t a = 0; a < V; a++) {
+    fputs(c->words[a].c_str(), fo);
+    fputc(' ', fo);
+    const float *row = values + a * dim;
+    if (binary) fwrite(row, sizeof(float), (size_t)dim, fo);
+    else for (int64_t b = 0; b < dim; b++) fprintf(fo, "%lf ", row[b]);
+    fputc('\n', fo);
+  }
+  return fclose(fo) == 0 ? W2B_OK : W2B_EIO;
+}

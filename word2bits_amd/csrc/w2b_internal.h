@@ -1,0 +1,68 @@
+// w2b_internal.h -- structures shared by the HIP kernels (w2b_kernels.hip) and the host side of the
+// C ABI (w2b_trainer.cpp).  Not part of the public interface (include/word2bits_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define W2B_LCG_A 25214903917ULL   // ref src/word2bits.cpp:352 (same constants at :405,:428,:455)
+#define W2B_LCG_C 11ULL
+#define W2B_MAX_SEN 1000           // ref src/word2bits.cpp:32
+#define W2B_MAXW 16                // max wavefronts per workgroup (1024 threads)
+
+// Racy globals of the reference that all workers share (ref src/word2bits.cpp:51,53):
+// alpha and word_count_actual.  One instance in device memory per trainer.
+struct W2bShared {
+  float alpha;
+  int pad0;
+  unsigned long long word_count_actual;
+  double loss_tuples;   // loss sum of the tuple form (form ii)
+  int workers_done;
+  int pad1;
+};
+
+// Per-worker locals of TrainModelThread (ref src/word2bits.cpp:364-375) that must survive between
+// launches because one epoch is cut into several kernel launches.
+struct W2bWorker {
+  unsigned long long rng;         // next_random
+  long long cursor;               // index of the next unread corpus token
+  long long word_count, last_word_count;
+  double loss;                    // total_loss
+  int sen_len, sen_pos;           // sentence_length, sentence_position
+  int first_override;             // pending truncated first word of the shard (-2 none)
+  int done;                       // epoch finished (local_iter reached 0)
+  int sen[W2B_MAX_SEN];           // sen[]
+};
+
+struct W2bParams {
+  float *u, *v;                   // [vocab_size][dim] fp32 masters
+  const float *exp_table;         // [1000]
+  const int32_t *table;           // unigram table
+  long long table_size;
+  const float *keep;              // sub-sampling threshold per word (nullptr when sample <= 0)
+  const int32_t *corpus;          // token ids, 0 = </s>
+  long long n_tokens;
+  W2bWorker *workers;
+  W2bShared *shared;
+  const unsigned long long *jump_a, *jump_c;   // LCG jump-ahead: x_{n+k} = jump_a[k]*x_n + jump_c[k]
+  long long vocab_size, train_words, iter;
+  int dim, window, negative, bitlevel, num_threads;
+  int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
+  float starting_alpha, sample, reg;
+};
+
+// launchers implemented in w2b_kernels.hip --------------------------------------------------------
+// block size chosen from dim: one thread per 16-byte (or 4-byte) column of a row
+int w2b_block_threads(int dim, int *vec_out);
+size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form);
+hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *center,
+                             const int32_t *ctx_off, const int32_t *ctx, const int32_t *neg,
+                             float alpha, int grid, int num_cus, int per_cu_override, bool loss,
+                             hipStream_t s);
+hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s);
+hipError_t w2b_launch_init_net(float *u, float *v, long long n_per_table, const float *lut,
+                               hipStream_t s);
+hipError_t w2b_launch_export(const float *u, const float *v, float *out, long long n, int bitlevel,
+                             hipStream_t s);
+hipError_t w2b_launch_sub(float *w, const float *base, long long n, hipStream_t s);       // w -= base
+hipError_t w2b_launch_add_snap(float *w, float *base, long long n, hipStream_t s);        // w += base; base = w
+hipError_t w2b_launch_scale_snap(float *w, float *base, float s, long long n, hipStream_t st); // w *= s; base = w

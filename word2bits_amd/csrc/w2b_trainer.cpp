@@ -1,0 +1,616 @@
+// w2b_trainer.cpp -- host side of the C ABI declared in include/word2bits_hip.h.
+// Owns device memory, streams, events and the RCCL communicator; all arithmetic of the hot
+// path lives in w2b_kernels.hip.  There is deliberately no CPU fallback in this file.
+#include "../../include/word2bits_hip.h"
+#include "w2b_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                         \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(W2B_EHIP, std::string(#x) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+#define NCCLCHK(x)                                                                        \
+  do {                                                                                    \
+    ncclResult_t r_ = (x);                                                                \
+    if (r_ != ncclSuccess)                                                                \
+      return fail(W2B_ERCCL, std::string(#x) + ": " + ncclGetErrorString(r_));            \
+  } while (0)
+
+struct w2b_trainer {
+  w2b_config cfg{};
+  int device = 0;
+  int num_cus = 0;
+  hipStream_t stream = nullptr;
+  float *uv = nullptr;          // u followed by v (one allocation: one all-reduce)
+  float *base = nullptr;        // snapshot for the delta-sum replica sync
+  long long table_elems = 0;    // vocab_size * layer1_size
+  float *exp_table = nullptr;
+  int32_t *table = nullptr;
+  long long table_size = 0;
+  float *keep = nullptr;
+  const int32_t *corpus = nullptr;
+  int32_t *corpus_owned = nullptr;
+  long long n_tokens = 0;
+  W2bWorker *workers = nullptr;
+  W2bShared *shared = nullptr;
+  unsigned long long *jump_a = nullptr, *jump_c = nullptr;
+  std::vector<long long> shard_start;
+  std::vector<int> shard_override;
+  bool shards_set = false;
+  // staging for the host-pointer tuple form
+  int32_t *st_center = nullptr, *st_off = nullptr, *st_ctx = nullptr, *st_neg = nullptr;
+  size_t cap_center = 0, cap_off = 0, cap_ctx = 0, cap_neg = 0;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev;    // pairs
+  std::vector<hipEvent_t> ev_pool;
+  // RCCL
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  int grid_per_cu = 0;
+};
+
+// --------------------------------------------------------------------------------- host tables
+extern "C" const char *w2b_version(void) { return "word2bits-hip 0.1 (gfx950)"; }
+extern "C" const char *w2b_last_error(void) { return g_err.c_str(); }
+
+extern "C" int w2b_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ref src/word2bits.cpp:614-618 -- float expf of the host libm, exactly as the reference builds it
+extern "C" void w2b_build_exp_table(float *out) {
+  for (int i = 0; i < W2B_EXP_TABLE_SIZE; i++) {
+    const float arg = (i / (float)W2B_EXP_TABLE_SIZE * 2 - 1) * W2B_MAX_EXP;
+    const float e = expf(arg);
+    out[i] = e / (e + 1);
+  }
+}
+
+// ref src/word2bits.cpp:112-128
+extern "C" int w2b_build_unigram_table(const int64_t *cn, int64_t V, int32_t *table, int64_t tsz) {
+  if (!cn || !table || V <= 0 || tsz <= 0) return fail(W2B_EINVAL, "w2b_build_unigram_table: bad argument");
+  std::vector<double> w((size_t)V);
+  double total = 0;
+  for (int64_t a = 0; a < V; a++) {
+    w[a] = pow((double)cn[a], 0.75);
+    total += w[a];
+  }
+  int64_t i = 0;
+  double edge = w[0] / total;
+  for (int64_t a = 0; a < tsz; a++) {
+    table[a] = (int32_t)i;
+    if (a / (double)tsz > edge) {
+      i++;
+      if (i < V) edge += w[i] / total;
+    }
+    if (i >= V) i = V - 1;
+  }
+  return W2B_OK;
+}
+
+// ref src/word2bits.cpp:403-404
+extern "C" void w2b_build_keep_prob(const int64_t *cn, int64_t V, float sample, int64_t train_words,
+                                    float *out) {
+  const float st = sample * train_words;
+  for (int64_t i = 0; i < V; i++) out[i] = (sqrtf(cn[i] / st) + 1) * st / cn[i];
+}
+
+// ref src/word2bits.cpp:73-108 (host twin of the device quantizer; used by the save path of the CLI)
+extern "C" float w2b_quantize(float x, int32_t bitlevel) {
+  if (bitlevel == 0) return x;
+  const float sgn = x < 0 ? -1.f : 1.f;
+  if (bitlevel == 1) return sgn / 3;
+  const float mag = x * sgn;
+  float lvl = 0;
+  if (bitlevel == 2) lvl = (mag >= 0 && mag <= .5f) ? .25f : .75f;
+  if (bitlevel >= 4) {
+    const int steps = 1 << (bitlevel - 1);
+    const float scaled = mag * (float)steps;
+    int k = (int)(scaled + .5f);
+    if (k > steps) k = steps;
+    lvl = k / (float)steps;
+  }
+  return sgn * lvl;
+}
+
+// --------------------------------------------------------------------------------- lifetime
+static W2bParams make_params(const w2b_trainer *t) {
+  W2bParams p{};
+  p.u = t->uv;
+  p.v = t->uv + t->table_elems;
+  p.exp_table = t->exp_table;
+  p.table = t->table;
+  p.table_size = t->table_size;
+  p.keep = (t->cfg.sample > 0) ? t->keep : nullptr;
+  p.corpus = t->corpus;
+  p.n_tokens = t->n_tokens;
+  p.workers = t->workers;
+  p.shared = t->shared;
+  p.jump_a = t->jump_a;
+  p.jump_c = t->jump_c;
+  p.vocab_size = t->cfg.vocab_size;
+  p.train_words = t->cfg.train_words;
+  p.iter = t->cfg.iter;
+  p.dim = t->cfg.layer1_size;
+  p.window = t->cfg.window;
+  p.negative = t->cfg.negative;
+  p.bitlevel = t->cfg.bitlevel;
+  p.num_threads = t->cfg.num_threads;
+  p.total_threads = t->cfg.total_threads > 0 ? t->cfg.total_threads : t->cfg.num_threads;
+  p.starting_alpha = t->cfg.alpha;
+  p.sample = t->cfg.sample;
+  p.reg = t->cfg.reg;
+  return p;
+}
+
+extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
+  if (!cfg || !out) return fail(W2B_EINVAL, "w2b_trainer_create: null argument");
+  *out = nullptr;
+  if (cfg->vocab_size < 2 || cfg->layer1_size < 1 || cfg->window < 1 || cfg->negative < 0 ||
+      cfg->num_threads < 1 || cfg->bitlevel < 0 || cfg->bitlevel > 31 || cfg->iter < 0 ||
+      cfg->worker_offset < 0 || cfg->total_threads < 0 ||
+      (cfg->total_threads > 0 && cfg->worker_offset + cfg->num_threads > cfg->total_threads))
+    return fail(W2B_EINVAL, "w2b_trainer_create: bad configuration value");
+  int vec = 0;
+  const int threads = w2b_block_threads(cfg->layer1_size, &vec);
+  if (threads > 1024)
+    return fail(W2B_EUNSUPPORTED, "layer1_size too large for one workgroup (max 4096 when a multiple "
+                                  "of 4, else 1024)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(W2B_ENOGPU, "no HIP device visible (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(W2B_EINVAL, "device ordinal out of range");
+  HIPCHK(hipSetDevice(cfg->device));
+  w2b_trainer *t = new w2b_trainer();
+  t->cfg = *cfg;
+  t->device = cfg->device;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+  t->num_cus = prop.multiProcessorCount;
+  if (const char *e = getenv("W2B_GRID_PER_CU")) t->grid_per_cu = atoi(e);
+  HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+  t->table_elems = (long long)cfg->vocab_size * cfg->layer1_size;
+  HIPCHK(hipMalloc(&t->uv, sizeof(float) * 2 * t->table_elems));
+  HIPCHK(hipMemsetAsync(t->uv, 0, sizeof(float) * 2 * t->table_elems, t->stream));
+  HIPCHK(hipMalloc(&t->exp_table, sizeof(float) * (W2B_EXP_TABLE_SIZE + 8)));
+  {
+    std::vector<float> et(W2B_EXP_TABLE_SIZE + 8, 0.f);
+    w2b_build_exp_table(et.data());
+    HIPCHK(hipMemcpy(t->exp_table, et.data(), sizeof(float) * et.size(), hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMalloc(&t->shared, sizeof(W2bShared)));
+  {
+    W2bShared sh{};
+    sh.alpha = cfg->alpha;
+    HIPCHK(hipMemcpy(t->shared, &sh, sizeof sh, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMalloc(&t->workers, sizeof(W2bWorker) * cfg->num_threads));
+  HIPCHK(hipMemset(t->workers, 0, sizeof(W2bWorker) * cfg->num_threads));
+  {
+    // LCG jump-ahead table: x_{n+k} = A^k x_n + C (A^k - 1)/(A - 1)   (mod 2^64)
+    const int nj = (cfg->negative + 2 > 66) ? cfg->negative + 2 : 66;
+    std::vector<unsigned long long> ja(nj), jc(nj);
+    ja[0] = 1;
+    jc[0] = 0;
+    for (int k = 1; k < nj; k++) {
+      ja[k] = ja[k - 1] * W2B_LCG_A;
+      jc[k] = jc[k - 1] * W2B_LCG_A + W2B_LCG_C;
+    }
+    HIPCHK(hipMalloc(&t->jump_a, sizeof(unsigned long long) * nj));
+    HIPCHK(hipMalloc(&t->jump_c, sizeof(unsigned long long) * nj));
+    HIPCHK(hipMemcpy(t->jump_a, ja.data(), sizeof(unsigned long long) * nj, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t->jump_c, jc.data(), sizeof(unsigned long long) * nj, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipStreamSynchronize(t->stream));
+  *out = t;
+  return W2B_OK;
+}
+
+extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  (void)hipStreamSynchronize(t->stream);
+  if (t->comm) ncclCommDestroy(t->comm);
+  for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : t->ev_pool) (void)hipEventDestroy(e);
+  void *ptrs[] = {t->uv, t->base, t->exp_table, t->table, t->keep, t->corpus_owned, t->workers, t->shared,
+                  t->jump_a, t->jump_c, t->st_center, t->st_off, t->st_ctx, t->st_neg};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  (void)hipStreamDestroy(t->stream);
+  delete t;
+}
+
+#define NEED(t)                                                                  \
+  do {                                                                           \
+    if (!(t)) return fail(W2B_EINVAL, "null trainer");                          \
+    HIPCHK(hipSetDevice((t)->device));                                           \
+  } while (0)
+
+// --------------------------------------------------------------------------------- model
+extern "C" int w2b_init_net(w2b_trainer *t) {
+  NEED(t);
+  // ref :343-361: value_k = ((x_k & 0xFFFF) / 65536.f) - 0.5 with x_0 = 1; the low 16 bits have
+  // period 65536, so a LUT indexed by the draw number modulo 65536 reproduces the sequence.
+  std::vector<float> lut(65536);
+  unsigned long long x = 1;
+  for (int k = 0; k < 65536; k++) {
+    x = x * W2B_LCG_A + W2B_LCG_C;
+    lut[k] = (float)(((x & 0xFFFF) / (float)65536) - 0.5);
+  }
+  float *dl = nullptr;
+  HIPCHK(hipMalloc(&dl, sizeof(float) * 65536));
+  HIPCHK(hipMemcpyAsync(dl, lut.data(), sizeof(float) * 65536, hipMemcpyHostToDevice, t->stream));
+  HIPCHK(w2b_launch_init_net(t->uv, t->uv + t->table_elems, t->table_elems, dl, t->stream));
+  if (t->base)
+    HIPCHK(hipMemcpyAsync(t->base, t->uv, sizeof(float) * 2 * t->table_elems, hipMemcpyDeviceToDevice,
+                          t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  HIPCHK(hipFree(dl));
+  return W2B_OK;
+}
+
+extern "C" int w2b_set_model(w2b_trainer *t, const float *u, const float *v) {
+  NEED(t);
+  if (!u || !v) return fail(W2B_EINVAL, "w2b_set_model: null table");
+  const size_t bytes = sizeof(float) * t->table_elems;
+  HIPCHK(hipMemcpyAsync(t->uv, u, bytes, hipMemcpyHostToDevice, t->stream));
+  HIPCHK(hipMemcpyAsync(t->uv + t->table_elems, v, bytes, hipMemcpyHostToDevice, t->stream));
+  if (t->base) HIPCHK(hipMemcpyAsync(t->base, t->uv, 2 * bytes, hipMemcpyDeviceToDevice, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return W2B_OK;
+}
+
+extern "C" int w2b_get_model(w2b_trainer *t, float *u, float *v) {
+  NEED(t);
+  const size_t bytes = sizeof(float) * t->table_elems;
+  HIPCHK(hipStreamSynchronize(t->stream));
+  if (u) HIPCHK(hipMemcpy(u, t->uv, bytes, hipMemcpyDeviceToHost));
+  if (v) HIPCHK(hipMemcpy(v, t->uv + t->table_elems, bytes, hipMemcpyDeviceToHost));
+  return W2B_OK;
+}
+
+extern "C" int w2b_model_device_ptrs(w2b_trainer *t, void **u_dev, void **v_dev) {
+  if (!t) return fail(W2B_EINVAL, "null trainer");
+  if (u_dev) *u_dev = t->uv;
+  if (v_dev) *v_dev = t->uv + t->table_elems;
+  return W2B_OK;
+}
+
+extern "C" int w2b_export_quantized(w2b_trainer *t, float *out) {
+  NEED(t);
+  if (!out) return fail(W2B_EINVAL, "w2b_export_quantized: null output");
+  // exported in slabs so that a 14.8 GB table does not need a second full-size device buffer
+  const long long slab = 64ll << 20;
+  float *tmp = nullptr;
+  const long long n = t->table_elems;
+  HIPCHK(hipMalloc(&tmp, sizeof(float) * (n < slab ? n : slab)));
+  for (long long o = 0; o < n; o += slab) {
+    const long long m = (n - o < slab) ? n - o : slab;
+    hipError_t e = w2b_launch_export(t->uv + o, t->uv + t->table_elems + o, tmp, m, t->cfg.bitlevel, t->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out + o, tmp, sizeof(float) * m, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(tmp);
+      return fail(W2B_EHIP, std::string("w2b_export_quantized: ") + hipGetErrorString(e));
+    }
+  }
+  HIPCHK(hipFree(tmp));
+  return W2B_OK;
+}
+
+// --------------------------------------------------------------------------------- sampler state
+extern "C" int w2b_set_unigram_table(w2b_trainer *t, const int32_t *table, int64_t tsz) {
+  NEED(t);
+  if (!table || tsz <= 0) return fail(W2B_EINVAL, "w2b_set_unigram_table: bad argument");
+  HIPCHK(hipStreamSynchronize(t->stream));
+  if (t->table) HIPCHK(hipFree(t->table));
+  t->table = nullptr;
+  HIPCHK(hipMalloc(&t->table, sizeof(int32_t) * tsz));
+  HIPCHK(hipMemcpy(t->table, table, sizeof(int32_t) * tsz, hipMemcpyHostToDevice));
+  t->table_size = tsz;
+  return W2B_OK;
+}
+
+extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t table_size) {
+  NEED(t);
+  if (!cn) return fail(W2B_EINVAL, "w2b_set_vocab_counts: null counts");
+  const int64_t V = t->cfg.vocab_size;
+  std::vector<float> keep((size_t)V, 1.f);
+  if (t->cfg.sample > 0) w2b_build_keep_prob(cn, V, t->cfg.sample, t->cfg.train_words, keep.data());
+  if (!t->keep) HIPCHK(hipMalloc(&t->keep, sizeof(float) * V));
+  HIPCHK(hipMemcpy(t->keep, keep.data(), sizeof(float) * V, hipMemcpyHostToDevice));
+  if (table_size > 0) {
+    std::vector<int32_t> tab((size_t)table_size);
+    int rc = w2b_build_unigram_table(cn, V, tab.data(), table_size);
+    if (rc) return rc;
+    return w2b_set_unigram_table(t, tab.data(), table_size);
+  }
+  return W2B_OK;
+}
+
+extern "C" int w2b_set_exp_table(w2b_trainer *t, const float *et) {
+  NEED(t);
+  if (!et) return fail(W2B_EINVAL, "w2b_set_exp_table: null");
+  HIPCHK(hipStreamSynchronize(t->stream));
+  HIPCHK(hipMemcpy(t->exp_table, et, sizeof(float) * W2B_EXP_TABLE_SIZE, hipMemcpyHostToDevice));
+  return W2B_OK;
+}
+
+// --------------------------------------------------------------------------------- timing helpers
+static hipError_t timing_begin(w2b_trainer *t) {
+  if (!t->timing) return hipSuccess;
+  hipEvent_t a, b;
+  if (t->ev_pool.size() >= 2) {
+    a = t->ev_pool.back(); t->ev_pool.pop_back();
+    b = t->ev_pool.back(); t->ev_pool.pop_back();
+  } else {
+    hipError_t e = hipEventCreate(&a);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&b);
+    if (e != hipSuccess) return e;
+  }
+  t->ev.push_back(a);
+  t->ev.push_back(b);
+  return hipEventRecord(a, t->stream);
+}
+static hipError_t timing_end(w2b_trainer *t) {
+  if (!t->timing) return hipSuccess;
+  return hipEventRecord(t->ev.back(), t->stream);
+}
+
+extern "C" int w2b_timing_enable(w2b_trainer *t, int32_t on) {
+  if (!t) return fail(W2B_EINVAL, "null trainer");
+  t->timing = on != 0;
+  return W2B_OK;
+}
+
+extern "C" int w2b_timing_read(w2b_trainer *t, double *kernel_ms, int64_t *launches) {
+  NEED(t);
+  HIPCHK(hipStreamSynchronize(t->stream));
+  double ms = 0;
+  for (size_t i = 0; i + 1 < t->ev.size(); i += 2) {
+    float m = 0;
+    HIPCHK(hipEventElapsedTime(&m, t->ev[i], t->ev[i + 1]));
+    ms += m;
+  }
+  if (kernel_ms) *kernel_ms = ms;
+  if (launches) *launches = (int64_t)(t->ev.size() / 2);
+  for (hipEvent_t e : t->ev) t->ev_pool.push_back(e);
+  t->ev.clear();
+  return W2B_OK;
+}
+
+extern "C" int w2b_synchronize(w2b_trainer *t) {
+  NEED(t);
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return W2B_OK;
+}
+
+// --------------------------------------------------------------------------------- form (i): workers
+extern "C" int w2b_set_corpus(w2b_trainer *t, const int32_t *ids, int64_t n) {
+  NEED(t);
+  if (!ids || n < 0) return fail(W2B_EINVAL, "w2b_set_corpus: bad argument");
+  HIPCHK(hipStreamSynchronize(t->stream));
+  if (t->corpus_owned) HIPCHK(hipFree(t->corpus_owned));
+  t->corpus_owned = nullptr;
+  HIPCHK(hipMalloc(&t->corpus_owned, sizeof(int32_t) * (n > 0 ? n : 1)));
+  HIPCHK(hipMemcpy(t->corpus_owned, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  t->corpus = t->corpus_owned;
+  t->n_tokens = n;
+  return W2B_OK;
+}
+
+extern "C" int w2b_set_corpus_device(w2b_trainer *t, const void *ids_dev, int64_t n) {
+  NEED(t);
+  if (!ids_dev || n < 0) return fail(W2B_EINVAL, "w2b_set_corpus_device: bad argument");
+  HIPCHK(hipStreamSynchronize(t->stream));
+  if (t->corpus_owned) HIPCHK(hipFree(t->corpus_owned));
+  t->corpus_owned = nullptr;
+  t->corpus = (const int32_t *)ids_dev;
+  t->n_tokens = n;
+  return W2B_OK;
+}
+
+extern "C" int w2b_set_shards(w2b_trainer *t, const int64_t *starts, const int32_t *ov) {
+  if (!t || !starts) return fail(W2B_EINVAL, "w2b_set_shards: bad argument");
+  const int nw = t->cfg.num_threads;
+  t->shard_start.assign(starts, starts + nw);
+  t->shard_override.assign(nw, -2);
+  if (ov) t->shard_override.assign(ov, ov + nw);
+  t->shards_set = true;
+  return W2B_OK;
+}
+
+extern "C" int w2b_epoch_begin(w2b_trainer *t) {
+  NEED(t);
+  if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_epoch_begin: corpus/shards not set");
+  if (t->cfg.negative > 0 && !t->table) return fail(W2B_ESTATE, "w2b_epoch_begin: unigram table not set");
+  if (t->cfg.sample > 0 && !t->keep) return fail(W2B_ESTATE, "w2b_epoch_begin: vocab counts not set");
+  const int nw = t->cfg.num_threads;
+  std::vector<W2bWorker> w((size_t)nw);
+  memset(w.data(), 0, sizeof(W2bWorker) * nw);
+  for (int i = 0; i < nw; i++) {
+    w[i].rng = (unsigned long long)(t->cfg.worker_offset + i);   // global worker id, ref :368
+    w[i].cursor = t->shard_start[i];           // ref :377
+    w[i].first_override = t->shard_override[i];
+  }
+  HIPCHK(hipStreamSynchronize(t->stream));
+  HIPCHK(hipMemcpy(t->workers, w.data(), sizeof(W2bWorker) * nw, hipMemcpyHostToDevice));
+  int zero = 0;
+  HIPCHK(hipMemcpy(&t->shared->workers_done, &zero, sizeof zero, hipMemcpyHostToDevice));
+  return W2B_OK;
+}
+
+extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
+  NEED(t);
+  if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_train_step: corpus/shards not set");
+  if (max_positions <= 0) return fail(W2B_EINVAL, "w2b_train_step: max_positions must be positive");
+  const W2bParams p = make_params(t);
+  HIPCHK(timing_begin(t));
+  HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
+  HIPCHK(timing_end(t));
+  return W2B_OK;
+}
+
+extern "C" int w2b_epoch_status(w2b_trainer *t, int32_t *finished, int64_t *wca, float *alpha,
+                                double *loss_sum) {
+  NEED(t);
+  HIPCHK(hipStreamSynchronize(t->stream));
+  W2bShared sh;
+  HIPCHK(hipMemcpy(&sh, t->shared, sizeof sh, hipMemcpyDeviceToHost));
+  if (finished) *finished = (sh.workers_done >= t->cfg.num_threads) ? 1 : 0;
+  if (wca) *wca = (int64_t)sh.word_count_actual;
+  if (alpha) *alpha = sh.alpha;
+  if (loss_sum) {
+    const int nw = t->cfg.num_threads;
+    std::vector<W2bWorker> w((size_t)nw);
+    HIPCHK(hipMemcpy(w.data(), t->workers, sizeof(W2bWorker) * nw, hipMemcpyDeviceToHost));
+    double s = 0;
+    for (int i = 0; i < nw; i++) s += w[i].loss;   // ref :537-538
+    *loss_sum = s;
+  }
+  return W2B_OK;
+}
+
+// --------------------------------------------------------------------------------- form (ii): tuples
+extern "C" int w2b_train_tuples_device(w2b_trainer *t, int64_t n, const void *center, const void *ctx_off,
+                                       const void *ctx, const void *neg, float alpha, int32_t grid) {
+  NEED(t);
+  if (n < 0 || !center || !ctx_off || !ctx || (!neg && t->cfg.negative > 0))
+    return fail(W2B_EINVAL, "w2b_train_tuples_device: bad argument");
+  if (n == 0) return W2B_OK;
+  const W2bParams p = make_params(t);
+  HIPCHK(timing_begin(t));
+  HIPCHK(w2b_launch_tuples(p, n, (const int32_t *)center, (const int32_t *)ctx_off, (const int32_t *)ctx,
+                           (const int32_t *)neg, alpha, grid > 0 ? grid : 0, t->num_cus, t->grid_per_cu,
+                           t->cfg.compute_loss != 0, t->stream));
+  HIPCHK(timing_end(t));
+  return W2B_OK;
+}
+
+static int grow(int32_t **p, size_t *cap, size_t need) {
+  if (need <= *cap) return W2B_OK;
+  if (*p) HIPCHK(hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  HIPCHK(hipMalloc(p, sizeof(int32_t) * need));
+  *cap = need;
+  return W2B_OK;
+}
+
+extern "C" int w2b_train_tuples(w2b_trainer *t, int64_t n, const int32_t *center, const int32_t *ctx_off,
+                                const int32_t *ctx, const int32_t *neg, float alpha, int32_t serial,
+                                double *loss_out) {
+  NEED(t);
+  if (n < 0 || !center || !ctx_off || !ctx || (!neg && t->cfg.negative > 0))
+    return fail(W2B_EINVAL, "w2b_train_tuples: bad argument");
+  const int K = t->cfg.negative;
+  const int64_t V = t->cfg.vocab_size;
+  // validate ids on the host: a bad row index would be an out-of-bounds device access
+  for (int64_t i = 0; i < n; i++) {
+    if (center[i] < 0 || center[i] >= V) return fail(W2B_EINVAL, "w2b_train_tuples: centre id out of range");
+    if (ctx_off[i + 1] < ctx_off[i] || ctx_off[i + 1] - ctx_off[i] > 2 * t->cfg.window)
+      return fail(W2B_EINVAL, "w2b_train_tuples: context list longer than 2*window or CSR not monotone");
+    for (int j = 0; j < K; j++)
+      if (neg[i * K + j] >= V) return fail(W2B_EINVAL, "w2b_train_tuples: negative id out of range");
+  }
+  const int64_t nctx = n ? ctx_off[n] : 0;
+  if (n && ctx_off[0] != 0) return fail(W2B_EINVAL, "w2b_train_tuples: ctx_off[0] must be 0");
+  for (int64_t j = 0; j < nctx; j++)
+    if (ctx[j] < 0 || ctx[j] >= V) return fail(W2B_EINVAL, "w2b_train_tuples: context id out of range");
+  if (n == 0) {
+    if (loss_out) *loss_out = 0;
+    return W2B_OK;
+  }
+  int rc;
+  if ((rc = grow(&t->st_center, &t->cap_center, n))) return rc;
+  if ((rc = grow(&t->st_off, &t->cap_off, n + 1))) return rc;
+  if ((rc = grow(&t->st_ctx, &t->cap_ctx, nctx > 0 ? nctx : 1))) return rc;
+  if ((rc = grow(&t->st_neg, &t->cap_neg, (size_t)n * (K > 0 ? K : 1)))) return rc;
+  HIPCHK(hipMemcpyAsync(t->st_center, center, sizeof(int32_t) * n, hipMemcpyHostToDevice, t->stream));
+  HIPCHK(hipMemcpyAsync(t->st_off, ctx_off, sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, t->stream));
+  if (nctx) HIPCHK(hipMemcpyAsync(t->st_ctx, ctx, sizeof(int32_t) * nctx, hipMemcpyHostToDevice, t->stream));
+  if (K) HIPCHK(hipMemcpyAsync(t->st_neg, neg, sizeof(int32_t) * n * K, hipMemcpyHostToDevice, t->stream));
+  double zero = 0;
+  if (t->cfg.compute_loss)
+    HIPCHK(hipMemcpyAsync(&t->shared->loss_tuples, &zero, sizeof zero, hipMemcpyHostToDevice, t->stream));
+  rc = w2b_train_tuples_device(t, n, t->st_center, t->st_off, t->st_ctx, t->st_neg, alpha, serial ? 1 : 0);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(t->stream));
+  if (loss_out) {
+    *loss_out = 0;
+    if (t->cfg.compute_loss)
+      HIPCHK(hipMemcpy(loss_out, &t->shared->loss_tuples, sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return W2B_OK;
+}
+
+// --------------------------------------------------------------------------------- multi-GPU (RCCL)
+extern "C" int w2b_comm_unique_id(void *out128) {
+  if (!out128) return fail(W2B_EINVAL, "w2b_comm_unique_id: null");
+  static_assert(sizeof(ncclUniqueId) == W2B_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  memcpy(out128, &id, sizeof id);
+  return W2B_OK;
+}
+
+extern "C" int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id128) {
+  NEED(t);
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(W2B_EINVAL, "w2b_comm_init: bad rank");
+  t->nranks = nranks;
+  t->rank = rank;
+  if (nranks == 1) return W2B_OK;   // replicas of one: nothing to exchange
+  if (!id128) return fail(W2B_EINVAL, "w2b_comm_init: null id");
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  NCCLCHK(ncclCommInitRank(&t->comm, nranks, id, rank));
+  HIPCHK(hipMalloc(&t->base, sizeof(float) * 2 * t->table_elems));
+  HIPCHK(hipMemcpyAsync(t->base, t->uv, sizeof(float) * 2 * t->table_elems, hipMemcpyDeviceToDevice, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return W2B_OK;
+}
+
+extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
+  NEED(t);
+  if (t->nranks <= 1 || !t->comm) return W2B_OK;
+  const long long n = 2 * t->table_elems;
+  // one all-reduce over [u || v]; chunked so that each RCCL call stays below 2^31 elements
+  const long long chunk = 1ll << 30;
+  if (mode == 0) {
+    HIPCHK(w2b_launch_sub(t->uv, t->base, n, t->stream));             // W <- W - base
+    for (long long o = 0; o < n; o += chunk) {
+      const long long m = (n - o < chunk) ? n - o : chunk;
+      NCCLCHK(ncclAllReduce(t->uv + o, t->uv + o, (size_t)m, ncclFloat, ncclSum, t->comm, t->stream));
+    }
+    HIPCHK(w2b_launch_add_snap(t->uv, t->base, n, t->stream));        // W <- base + sum; base <- W
+  } else if (mode == 1) {
+    for (long long o = 0; o < n; o += chunk) {
+      const long long m = (n - o < chunk) ? n - o : chunk;
+      NCCLCHK(ncclAllReduce(t->uv + o, t->uv + o, (size_t)m, ncclFloat, ncclSum, t->comm, t->stream));
+    }
+    HIPCHK(w2b_launch_scale_snap(t->uv, t->base, 1.f / (float)t->nranks, n, t->stream));
+  } else {
+    return fail(W2B_EINVAL, "w2b_sync_replicas: unknown mode");
+  }
+  return W2B_OK;
+}

@@ -1,0 +1,244 @@
+// word2bits_main.cpp -- the ./word2bits command line on top of the HIP C ABI.
+//
+// Same flags, defaults, stdout lines and output-file format as the reference program
+// (ref src/word2bits.cpp:579-621 main/ArgPos, :518-577 TrainModel) so that the reference's
+// compute_accuracy evaluator runs unchanged on the result.  What differs is where the work
+// happens: the corpus is tokenised once on the host (word2bits_corpus.h) and every epoch is a
+// sequence of GPU launches in which each of the -threads Hogwild workers is one workgroup.
+// GPU-only additions use new flag names: -gpus, -sync-every, -positions, -device, -table-size.
+#include <pthread.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/word2bits_corpus.h"
+#include "../../include/word2bits_hip.h"
+
+namespace {
+
+struct Options {                       // defaults: ref src/word2bits.cpp:48-54,59
+  std::string train_file, output_file;
+  int binary = 0, debug_mode = 2, window = 5, min_count = 5, num_threads = 12, bitlevel = 1;
+  long long layer1_size = 100, iter = 5, classes = 0;
+  int save_every_epoch = 0, negative = 5;
+  float alpha = 0.05f, sample = 1e-3f, reg = 0.f;
+  // GPU-only
+  int gpus = 1, device = 0;
+  long long sync_every = 0;            // positions per worker between replica syncs (0: once per launch)
+  long long positions = 4096;          // sentence positions per worker per launch
+  long long table_size = W2B_UNIGRAM_TABLE_SIZE;
+};
+
+// ArgPos, ref :579-589: exact-match search; a flag in last position has no value -> exit(1)
+int arg_pos(const char *flag, int argc, char **argv) {
+  for (int a = 1; a < argc; a++)
+    if (!strcmp(flag, argv[a])) {
+      if (a == argc - 1) {
+        printf("Argument missing for %s\n", flag);
+        exit(1);
+      }
+      return a;
+    }
+  return -1;
+}
+
+void die(const char *what, int rc) {
+  fprintf(stderr, "word2bits: %s failed (%d): %s\n", what, rc, w2b_last_error());
+  exit(2);
+}
+#define CK(call)                         \
+  do {                                   \
+    int rc_ = (call);                    \
+    if (rc_ != W2B_OK) die(#call, rc_);  \
+  } while (0)
+
+struct Replica {                        // one GPU
+  int index = 0;
+  w2b_trainer *t = nullptr;
+};
+
+void save(const Options &o, const w2b_corpus *c, w2b_trainer *t, const std::string &path) {
+  const long long V = w2b_corpus_vocab_size(c), D = o.layer1_size;
+  if (o.classes != 0) {                 // ref :542,562: nothing but the fopen/fclose happens
+    FILE *f = fopen(path.c_str(), "wb");
+    if (f) fclose(f);
+    return;
+  }
+  std::vector<float> q((size_t)V * D);
+  CK(w2b_export_quantized(t, q.data()));                 // quantize(u+v), ref :549-550,568-569
+  int rc = w2b_save_vectors(path.c_str(), c, q.data(), D, o.binary);
+  if (rc != W2B_OK) {
+    fprintf(stderr, "word2bits: cannot write %s\n", path.c_str());
+    exit(2);
+  }
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  Options o;
+  int i;
+  // flag list and order: ref :596-611
+  if ((i = arg_pos("-save-every-epoch", argc, argv)) > 0) o.save_every_epoch = atoi(argv[i + 1]);
+  if ((i = arg_pos("-bitlevel", argc, argv)) > 0) o.bitlevel = atoi(argv[i + 1]);
+  if ((i = arg_pos("-size", argc, argv)) > 0) o.layer1_size = atoi(argv[i + 1]);
+  if ((i = arg_pos("-reg", argc, argv)) > 0) o.reg = (float)atof(argv[i + 1]);
+  if ((i = arg_pos("-train", argc, argv)) > 0) o.train_file = argv[i + 1];
+  if ((i = arg_pos("-debug", argc, argv)) > 0) o.debug_mode = atoi(argv[i + 1]);
+  if ((i = arg_pos("-binary", argc, argv)) > 0) o.binary = atoi(argv[i + 1]);
+  if ((i = arg_pos("-alpha", argc, argv)) > 0) o.alpha = (float)atof(argv[i + 1]);
+  if ((i = arg_pos("-output", argc, argv)) > 0) o.output_file = argv[i + 1];
+  if ((i = arg_pos("-window", argc, argv)) > 0) o.window = atoi(argv[i + 1]);
+  if ((i = arg_pos("-sample", argc, argv)) > 0) o.sample = (float)atof(argv[i + 1]);
+  if ((i = arg_pos("-negative", argc, argv)) > 0) o.negative = atoi(argv[i + 1]);
+  if ((i = arg_pos("-threads", argc, argv)) > 0) o.num_threads = atoi(argv[i + 1]);
+  if ((i = arg_pos("-iter", argc, argv)) > 0) o.iter = atoi(argv[i + 1]);
+  if ((i = arg_pos("-min-count", argc, argv)) > 0) o.min_count = atoi(argv[i + 1]);
+  if ((i = arg_pos("-classes", argc, argv)) > 0) o.classes = atoi(argv[i + 1]);
+  // GPU-only flags (new names; the reference ignores unknown flags, so scripts stay portable)
+  if ((i = arg_pos("-gpus", argc, argv)) > 0) o.gpus = atoi(argv[i + 1]);
+  if ((i = arg_pos("-device", argc, argv)) > 0) o.device = atoi(argv[i + 1]);
+  if ((i = arg_pos("-sync-every", argc, argv)) > 0) o.sync_every = atoll(argv[i + 1]);
+  if ((i = arg_pos("-positions", argc, argv)) > 0) o.positions = atoll(argv[i + 1]);
+  if ((i = arg_pos("-table-size", argc, argv)) > 0) o.table_size = atoll(argv[i + 1]);
+
+  // ---- TrainModel, ref :518-577
+  printf("Starting training using file %s\n", o.train_file.c_str());
+  w2b_corpus *corpus = nullptr;
+  if (w2b_corpus_load(o.train_file.c_str(), o.min_count, &corpus) != W2B_OK) {
+    printf("ERROR: training data file not found!\n");      // ref :272-273
+    exit(1);
+  }
+  const long long V = w2b_corpus_vocab_size(corpus);
+  const long long train_words = w2b_corpus_train_words(corpus);
+  if (o.debug_mode > 0) {                                    // ref :295-298
+    printf("Vocab size: %lld\n", V);
+    printf("Words in train file: %lld\n", train_words);
+  }
+  if (o.output_file.empty()) return 0;                       // ref :527
+
+  int ndev = w2b_device_count();
+  if (ndev <= 0) {
+    fprintf(stderr, "word2bits: no HIP device visible; this build has no CPU path\n");
+    return 2;
+  }
+  if (o.gpus < 1) o.gpus = 1;
+  if (o.gpus > ndev) {
+    fprintf(stderr, "word2bits: -gpus %d requested but %d visible\n", o.gpus, ndev);
+    return 2;
+  }
+  if (o.num_threads < 1) {                                   // GPU extension: -threads 0 = fill the device
+    o.num_threads = 1024 * o.gpus;
+    if (o.debug_mode > 0) printf("Hogwild workers (workgroups): %d\n", o.num_threads);
+  }
+  if (o.gpus > 1 && o.num_threads % o.gpus != 0) {
+    fprintf(stderr, "word2bits: -threads must be a multiple of -gpus\n");
+    return 2;
+  }
+
+  // shards of all workers (ref :377) -- worker ids are global across GPUs
+  std::vector<int64_t> starts(o.num_threads);
+  std::vector<int32_t> overrides(o.num_threads);
+  CK(w2b_corpus_shards(corpus, o.num_threads, starts.data(), overrides.data()));
+
+  const int per_gpu = o.num_threads / o.gpus;
+  std::vector<Replica> reps(o.gpus);
+  char uid[W2B_UNIQUE_ID_BYTES];
+  if (o.gpus > 1) CK(w2b_comm_unique_id(uid));
+  struct InitArg { const Options *o; Replica *r; const w2b_corpus *c; const int64_t *st; const int32_t *ov;
+                   int per_gpu; long long V, tw; const char *uid; };
+  auto init_replica = [](void *p) -> void * {
+    InitArg *a = (InitArg *)p;
+    const Options &o = *a->o;
+    w2b_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.vocab_size = a->V;
+    cfg.train_words = a->tw;
+    cfg.iter = o.iter;
+    cfg.layer1_size = (int32_t)o.layer1_size;
+    cfg.window = o.window;
+    cfg.negative = o.negative;
+    cfg.bitlevel = o.bitlevel;
+    cfg.num_threads = a->per_gpu;
+    cfg.alpha = o.alpha;
+    cfg.sample = o.sample;
+    cfg.reg = o.reg;
+    cfg.compute_loss = 1;
+    cfg.device = o.device + a->r->index;
+    cfg.worker_offset = a->r->index * a->per_gpu;             // worker_offset: global id of local worker 0
+    cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
+    CK(w2b_trainer_create(&cfg, &a->r->t));
+    CK(w2b_init_net(a->r->t));                              // ref :528
+    CK(w2b_set_vocab_counts(a->r->t, w2b_corpus_counts(a->c), o.negative > 0 ? o.table_size : 0));  // ref :529
+    CK(w2b_set_corpus(a->r->t, w2b_corpus_tokens(a->c), w2b_corpus_num_tokens(a->c)));
+    CK(w2b_set_shards(a->r->t, a->st + a->r->index * a->per_gpu, a->ov + a->r->index * a->per_gpu));
+    if (o.gpus > 1) CK(w2b_comm_init(a->r->t, o.gpus, a->r->index, a->uid));
+    return nullptr;
+  };
+  {
+    std::vector<InitArg> args(o.gpus);
+    std::vector<pthread_t> th(o.gpus);
+    for (int g = 0; g < o.gpus; g++) {
+      reps[g].index = g;
+      args[g] = InitArg{&o, &reps[g], corpus, starts.data(), overrides.data(), per_gpu, V, train_words, uid};
+      if (o.gpus == 1) init_replica(&args[g]);
+      else pthread_create(&th[g], nullptr, init_replica, &args[g]);   // RCCL init must run concurrently
+    }
+    if (o.gpus > 1) for (int g = 0; g < o.gpus; g++) pthread_join(th[g], nullptr);
+  }
+
+  const auto t_start = std::chrono::steady_clock::now();
+  for (int iteration = 0; iteration < o.iter; iteration++) {
+    printf("Starting epoch: %d\n", iteration);                // ref :533
+    for (auto &r : reps) CK(w2b_epoch_begin(r.t));             // pthread_create, ref :535
+    double last_loss = 0, epoch_loss = 0;
+    bool finished = false;
+    while (!finished) {
+      for (auto &r : reps) CK(w2b_train_step(r.t, o.positions));
+      finished = true;
+      long long wca = 0;
+      float alpha = 0;
+      epoch_loss = 0;
+      for (auto &r : reps) {
+        int32_t fin = 0;
+        int64_t w = 0;
+        float a = 0;
+        double l = 0;
+        CK(w2b_epoch_status(r.t, &fin, &w, &a, &l));
+        finished = finished && fin;
+        wca += w;
+        alpha = a;
+        epoch_loss += l;
+      }
+      if (o.gpus > 1) {                                       // replicas: periodic all-reduce over xGMI
+        std::vector<pthread_t> th(o.gpus);
+        auto sync = [](void *p) -> void * { CK(w2b_sync_replicas((w2b_trainer *)p, 0)); CK(w2b_synchronize((w2b_trainer *)p)); return nullptr; };
+        for (int g = 0; g < o.gpus; g++) pthread_create(&th[g], nullptr, sync, reps[g].t);
+        for (int g = 0; g < o.gpus; g++) pthread_join(th[g], nullptr);
+      }
+      if (o.debug_mode > 1) {                                 // progress line, ref :384-387
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        printf("%cAlpha: %f  Progress: %.2f%%  Cost: %f Words/thread/sec: %.2fk  ", 13, alpha,
+               wca / (float)(o.iter * train_words + 1) * 100, epoch_loss - last_loss,
+               wca / (secs + 1e-9) / 1000.0 / o.num_threads);
+        fflush(stdout);
+        last_loss = epoch_loss;
+      }
+    }
+    printf("Epoch Loss: %lf\n", epoch_loss);                  // ref :539
+    if (o.save_every_epoch) {                                 // ref :540-557
+      char name[8192];
+      snprintf(name, sizeof name, "%s_epoch%d", o.output_file.c_str(), iteration);
+      save(o, corpus, reps[0].t, name);
+    }
+  }
+  save(o, corpus, reps[0].t, o.output_file);                  // ref :560-576
+  for (auto &r : reps) w2b_trainer_destroy(r.t);
+  w2b_corpus_free(corpus);
+  return 0;
+}

@@ -1,0 +1,255 @@
+"""Host-side mirror of the reference's training interface on top of the HIP C ABI.
+
+Names follow the reference (ref src/word2bits.cpp): `Trainer` holds what the reference keeps in
+process globals (:45-61); `Trainer.train_epoch()` is one iteration of TrainModel's epoch loop
+(:532-539, pthread_create/join of TrainModelThread); `train_model()` is TrainModel (:518-577).
+All arithmetic happens in libword2bits_hip.so on the GPU.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import Config, check, lib
+
+
+def _f32(a):
+    return a.ctypes.data_as(_lib.f32p)
+
+
+def _i32(a):
+    return a.ctypes.data_as(_lib.i32p)
+
+
+def _i64(a):
+    return a.ctypes.data_as(_lib.i64p)
+
+
+class Corpus:
+    """Vocabulary + token stream of a training file (LearnVocabFromTrainFile, ref :265-301)."""
+
+    def __init__(self, train_file, min_count=5):
+        self._h = _lib.vp()
+        rc = lib().w2b_corpus_load(train_file.encode(), int(min_count), C.byref(self._h))
+        if rc != 0:
+            raise _lib.W2bError(rc, "ERROR: training data file not found!")   # ref :272
+        L = lib()
+        self.vocab_size = L.w2b_corpus_vocab_size(self._h)
+        self.train_words = L.w2b_corpus_train_words(self._h)
+        self.file_size = L.w2b_corpus_file_size(self._h)
+        self.num_tokens = L.w2b_corpus_num_tokens(self._h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def words(self):
+        L = lib()
+        return [L.w2b_corpus_word(self._h, i).decode("latin1") for i in range(self.vocab_size)]
+
+    def counts(self):
+        p = lib().w2b_corpus_counts(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.vocab_size,)).copy()
+
+    def tokens(self):
+        if self.num_tokens == 0:
+            return np.zeros(0, np.int32)
+        p = lib().w2b_corpus_tokens(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.num_tokens,)).copy()
+
+    def search(self, word):
+        return lib().w2b_corpus_search(self._h, word.encode("latin1"))
+
+    def shards(self, num_threads):
+        starts = np.zeros(num_threads, np.int64)
+        ov = np.zeros(num_threads, np.int32)
+        check(lib().w2b_corpus_shards(self._h, num_threads, _i64(starts), _i32(ov)))
+        return starts, ov
+
+    def save_vectors(self, path, values, binary):
+        values = np.ascontiguousarray(values, np.float32)
+        check(lib().w2b_save_vectors(path.encode(), self._h, _f32(values), values.shape[1], int(binary)))
+
+    def close(self):
+        if self._h:
+            lib().w2b_corpus_free(self._h)
+            self._h = _lib.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Trainer:
+    """One model replica on one GPU (the reference's globals u, v, alpha, word_count_actual, ...)."""
+
+    def __init__(self, vocab_size, layer1_size=100, window=5, negative=5, bitlevel=1, num_threads=12,
+                 iter=5, alpha=0.05, sample=1e-3, reg=0.0, train_words=0, compute_loss=True, device=0,
+                 worker_offset=0, total_threads=0):
+        cfg = Config()
+        cfg.vocab_size, cfg.train_words, cfg.iter = int(vocab_size), int(train_words), int(iter)
+        cfg.layer1_size, cfg.window, cfg.negative = int(layer1_size), int(window), int(negative)
+        cfg.bitlevel, cfg.num_threads = int(bitlevel), int(num_threads)
+        cfg.alpha, cfg.sample, cfg.reg = float(alpha), float(sample), float(reg)
+        cfg.compute_loss, cfg.device = int(bool(compute_loss)), int(device)
+        cfg.worker_offset, cfg.total_threads = int(worker_offset), int(total_threads)
+        self.cfg = cfg
+        self._h = _lib.vp()
+        check(lib().w2b_trainer_create(C.byref(cfg), C.byref(self._h)))
+        self.vocab_size, self.layer1_size = int(vocab_size), int(layer1_size)
+        self.num_threads = int(num_threads)
+
+    # ---- model
+    def init_net(self):
+        check(lib().w2b_init_net(self._h))
+
+    def set_model(self, u, v):
+        u = np.ascontiguousarray(u, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        assert u.shape == v.shape == (self.vocab_size, self.layer1_size)
+        check(lib().w2b_set_model(self._h, _f32(u), _f32(v)))
+
+    def get_model(self):
+        u = np.empty((self.vocab_size, self.layer1_size), np.float32)
+        v = np.empty_like(u)
+        check(lib().w2b_get_model(self._h, _f32(u), _f32(v)))
+        return u, v
+
+    def export_quantized(self):
+        out = np.empty((self.vocab_size, self.layer1_size), np.float32)
+        check(lib().w2b_export_quantized(self._h, _f32(out)))
+        return out
+
+    def model_device_ptrs(self):
+        u, v = _lib.vp(), _lib.vp()
+        check(lib().w2b_model_device_ptrs(self._h, C.byref(u), C.byref(v)))
+        return u.value, v.value
+
+    # ---- sampler state
+    def set_vocab_counts(self, cn, table_size=100000000):
+        cn = np.ascontiguousarray(cn, np.int64)
+        assert len(cn) == self.vocab_size
+        check(lib().w2b_set_vocab_counts(self._h, _i64(cn), int(table_size)))
+
+    def set_unigram_table(self, table):
+        table = np.ascontiguousarray(table, np.int32)
+        check(lib().w2b_set_unigram_table(self._h, _i32(table), len(table)))
+
+    def set_exp_table(self, tab):
+        tab = np.ascontiguousarray(tab, np.float32)
+        check(lib().w2b_set_exp_table(self._h, _f32(tab)))
+
+    # ---- form (i): workers
+    def set_corpus(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        check(lib().w2b_set_corpus(self._h, _i32(ids), len(ids)))
+
+    def set_corpus_device(self, dev_ptr, n_tokens):
+        check(lib().w2b_set_corpus_device(self._h, _lib.vp(dev_ptr), int(n_tokens)))
+
+    def set_shards(self, starts, first_override=None):
+        starts = np.ascontiguousarray(starts, np.int64)
+        assert len(starts) == self.num_threads
+        ov = None
+        if first_override is not None:
+            ov = np.ascontiguousarray(first_override, np.int32)
+        check(lib().w2b_set_shards(self._h, _i64(starts), None if ov is None else _i32(ov)))
+
+    def epoch_begin(self):
+        check(lib().w2b_epoch_begin(self._h))
+
+    def train_step(self, max_positions):
+        check(lib().w2b_train_step(self._h, int(max_positions)))
+
+    def epoch_status(self, want_loss=True):
+        fin, wca, alpha, loss = C.c_int32(0), C.c_int64(0), C.c_float(0), C.c_double(0)
+        check(lib().w2b_epoch_status(self._h, C.byref(fin), C.byref(wca), C.byref(alpha),
+                                     C.byref(loss) if want_loss else None))
+        return bool(fin.value), wca.value, alpha.value, loss.value
+
+    def train_epoch(self, positions_per_launch=4096):
+        """pthread_create + pthread_join of one epoch (ref :535-536). Returns the epoch loss."""
+        self.epoch_begin()
+        while True:
+            self.train_step(positions_per_launch)
+            fin, _, _, loss = self.epoch_status()
+            if fin:
+                return loss
+
+    # ---- form (ii): tuples
+    def train_tuples(self, center, ctx_off, ctx, neg, alpha, serial=False):
+        center = np.ascontiguousarray(center, np.int32)
+        ctx_off = np.ascontiguousarray(ctx_off, np.int32)
+        ctx = np.ascontiguousarray(ctx, np.int32)
+        neg = np.ascontiguousarray(neg, np.int32)
+        loss = C.c_double(0)
+        check(lib().w2b_train_tuples(self._h, len(center), _i32(center), _i32(ctx_off), _i32(ctx), _i32(neg),
+                                     float(alpha), int(bool(serial)), C.byref(loss)))
+        return loss.value
+
+    def train_tuples_device(self, n, center_ptr, ctx_off_ptr, ctx_ptr, neg_ptr, alpha, grid=0):
+        check(lib().w2b_train_tuples_device(self._h, int(n), _lib.vp(center_ptr), _lib.vp(ctx_off_ptr),
+                                            _lib.vp(ctx_ptr), _lib.vp(neg_ptr), float(alpha), int(grid)))
+
+    # ---- stream / timing / replicas
+    def synchronize(self):
+        check(lib().w2b_synchronize(self._h))
+
+    def timing_enable(self, on=True):
+        check(lib().w2b_timing_enable(self._h, int(bool(on))))
+
+    def timing_read(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(lib().w2b_timing_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+        check(lib().w2b_comm_init(self._h, int(nranks), int(rank), buf))
+
+    def sync_replicas(self, mode=0):
+        check(lib().w2b_sync_replicas(self._h, int(mode)))
+
+    def close(self):
+        if self._h:
+            lib().w2b_trainer_destroy(self._h)
+            self._h = _lib.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().w2b_comm_unique_id(buf))
+    return buf.raw
+
+
+def train_model(train_file, output_file, bitlevel=1, size=100, window=5, negative=5, threads=12, iter=5,
+                min_count=5, alpha=0.05, sample=1e-3, reg=0.0, binary=0, table_size=100000000,
+                positions_per_launch=4096, device=0, verbose=False):
+    """TrainModel (ref :518-577) on one GPU: vocab, InitNet, unigram table, `iter` epochs, save.
+    Returns the list of epoch losses."""
+    corpus = Corpus(train_file, min_count)
+    t = Trainer(corpus.vocab_size, size, window, negative, bitlevel, threads, iter, alpha, sample, reg,
+                corpus.train_words, True, device)
+    t.init_net()
+    t.set_vocab_counts(corpus.counts(), table_size if negative > 0 else 0)
+    t.set_corpus(corpus.tokens())
+    starts, ov = corpus.shards(threads)
+    t.set_shards(starts, ov)
+    losses = []
+    for it in range(iter):
+        if verbose:
+            print("Starting epoch: %d" % it)
+        losses.append(t.train_epoch(positions_per_launch))
+        if verbose:
+            print("Epoch Loss: %f" % losses[-1])
+    corpus.save_vectors(output_file, t.export_quantized(), binary)
+    t.close()
+    corpus.close()
+    return losses
