@@ -13,8 +13,20 @@ from w2b_testlib import OracleState, oracle, fptr
 
 pytestmark = pytest.mark.gpu
 
-SINGLE_STEP_ATOL = 2e-5     # one sigmoid-bin flip: |dg| <= ~3e-3*alpha=1.5e-4, times |avg|<=~0.1
-SINGLE_STEP_MEAN = 2e-7
+# One centre-word update from identical state.  Elements agree to rounding (<= 2e-6) except where
+# the re-associated f lands in the neighbouring sigmoid-table bin: then g moves by one table step
+# (<= 0.25 * 1/83 * alpha = 1.5e-4 at alpha 0.05) and the rows of that one target/word move by
+# |dg| * |quantized level|.  So: max <= 1.6e-4 * max|level|, and all but a few rows within 2e-6.
+ROUNDING_ATOL = 2e-6
+SINGLE_STEP_MEAN = 5e-7
+
+
+def max_level(bitlevel, scale=1.5):
+    return {0: scale, 1: 1.0 / 3, 2: 0.75, 3: 0.0}.get(bitlevel, 1.0)
+
+
+def single_step_atol(bitlevel):
+    return 1.6e-4 * max_level(bitlevel) + ROUNDING_ATOL
 
 
 def make_pair(gpu, V, D, window, negative, bitlevel, reg=0.0, seed=0, table_size=20000):
@@ -90,8 +102,12 @@ def test_single_step_parity_collision_free(gpu, D, window, negative, bitlevel, r
     touched_u = np.unique(ctx)
     assert not np.array_equal(o.u[touched_u], u0[touched_u]) or bitlevel == 3
     du, dv = np.abs(u - o.u), np.abs(v - o.v)
-    assert du.max() <= SINGLE_STEP_ATOL and dv.max() <= SINGLE_STEP_ATOL, (du.max(), dv.max())
+    atol = single_step_atol(bitlevel)
+    assert du.max() <= atol and dv.max() <= atol, (du.max(), dv.max(), atol)
     assert du.mean() <= SINGLE_STEP_MEAN and dv.mean() <= SINGLE_STEP_MEAN
+    # a bin flip moves the rows of ONE tuple: at most a few of the n tuples may be affected at all
+    bad_rows = (du.max(axis=1) > ROUNDING_ATOL).sum() + (dv.max(axis=1) > ROUNDING_ATOL).sum()
+    assert bad_rows <= 3 * (2 * window + negative + 1), bad_rows
     # untouched rows are bit-identical
     mask_u = np.ones(V, bool); mask_u[touched_u] = False
     assert np.array_equal(u[mask_u], u0[mask_u])
@@ -100,35 +116,44 @@ def test_single_step_parity_collision_free(gpu, D, window, negative, bitlevel, r
         qg, qo = quantized(u, bitlevel), quantized(o.u, bitlevel)
         diff = (qg.view(np.uint32) != qo.view(np.uint32))
         edge = np.abs(o.u) if bitlevel == 1 else np.abs(np.abs(o.u) - 0.5)
-        assert not np.any(diff & (edge > SINGLE_STEP_ATOL))
+        assert not np.any(diff & (edge > atol))
         assert diff.mean() < 1e-4
-    assert lg == pytest.approx(lo, rel=2e-5, abs=1e-3)
+    assert lg == pytest.approx(lo, rel=1e-4, abs=1e-2)
     t.close()
+
+
+def drift(a, b):
+    """(mean |a-b|, fraction of sign disagreements)"""
+    return float(np.abs(a - b).mean()), float(np.mean(np.signbit(a) != np.signbit(b)))
 
 
 @pytest.mark.parametrize("bitlevel", [0, 1, 2])
 def test_serial_chain_matches_oracle(gpu, bitlevel):
-    """One workgroup applies colliding tuples strictly in order == the reference's -threads 1."""
+    """One workgroup applies colliding tuples strictly in order == the reference's -threads 1.
+    300 colliding updates on 40 rows are chaotic for quantized forward values, so the bound is
+    calibrated, not guessed: the HIP path may drift from the bit-reference oracle at most 3x as far as
+    the oracle's own FMA-contracted build does (= what the reference's stock -march=native build
+    does to its dot products), plus a rounding floor."""
     V, D, window, negative, n = 40, 96, 4, 6, 300
     o, t, rng = make_pair(gpu, V, D, window, negative, bitlevel, seed=3)
+    y = OracleState(o.cn, D, window=window, negative=negative, bitlevel=bitlevel, sample=0.0, table_size=20000,
+                    fma=True)
+    y.u[:], y.v[:] = o.u, o.v
     center = rng.integers(1, V, n).astype(np.int32)
     cws = rng.integers(1, 2 * window + 1, n)
     ctx_off = np.concatenate([[0], np.cumsum(cws)]).astype(np.int32)
     ctx = rng.integers(1, V, ctx_off[-1]).astype(np.int32)
     neg = rng.integers(1, V, (n, negative)).astype(np.int32)
     lo = o.train_tuples(center, ctx_off, ctx, neg, 0.025)
+    y.train_tuples(center, ctx_off, ctx, neg, 0.025)
     lg = t.train_tuples(center, ctx_off, ctx, neg, 0.025, serial=True)
     u, v = t.get_model()
-    du, dv = np.abs(u - o.u), np.abs(v - o.v)
-    if bitlevel == 1:
-        # discrete forward values: a sign flip of a near-zero master changes later steps; compare signs
-        agree = np.mean(np.signbit(u) == np.signbit(o.u))
-        assert agree >= 0.995, agree
-        assert np.median(du) <= 1e-5
-    else:
-        assert du.max() <= 2e-3 and dv.max() <= 2e-3, (du.max(), dv.max())
-        assert du.mean() <= 2e-5 and dv.mean() <= 2e-5
-    assert lg == pytest.approx(lo, rel=1e-3)
+    for got, ref, yard in ((u, o.u, y.u), (v, o.v, y.v)):
+        gm, gs = drift(got, ref)
+        ym, ys = drift(yard, ref)
+        assert gm <= 3 * ym + 2e-5, (gm, ym)
+        assert gs <= 3 * ys + 2e-3, (gs, ys)
+    assert lg == pytest.approx(lo, rel=2e-3)
     t.close()
 
 

@@ -23,44 +23,92 @@ def counts_of(ids, V):
     return cn
 
 
+def drift(a, b):
+    return float(np.abs(a - b).mean()), float(np.mean(np.signbit(a) != np.signbit(b)))
+
+
+def setup(V, ids, D, window, negative, bitlevel, sample, iters, num_threads=1, fma=False):
+    cn = counts_of(ids, V)
+    tw = int(cn.sum())
+    o = OracleState(cn, D, window=window, negative=negative, bitlevel=bitlevel, num_threads=num_threads,
+                    iters=iters, sample=sample, table_size=50000, fma=fma)
+    o.m.train_words = tw
+    return cn, tw, o
+
+
+@pytest.mark.parametrize("bitlevel,sample,D,window,negative", [
+    (1, 0.0, 64, 5, 5),
+    (1, 1e-3, 200, 8, 24),
+    (0, 1e-3, 200, 8, 24),
+    (2, 0.0, 100, 3, 7),
+])
+def test_single_worker_short_horizon_tight(gpu, bitlevel, sample, D, window, negative):
+    """3000 positions over a 5000-word vocabulary: rows are rarely revisited, so the worker form
+    (on-device sentence reader / window / negative draws / alpha) must track the oracle closely."""
+    V, n = 5000, 3000
+    rng = np.random.default_rng(4)
+    ids = token_stream(rng, V, n)
+    cn, tw, o = setup(V, ids, D, window, negative, bitlevel, sample, 1)
+    _, _, y = setup(V, ids, D, window, negative, bitlevel, sample, 1, fma=True)
+    t = w2b.Trainer(V, D, window, negative, bitlevel, num_threads=1, iter=1, sample=sample, train_words=tw)
+    t.set_model(o.u, o.v)
+    t.set_vocab_counts(cn, 50000)
+    t.set_corpus(ids)
+    t.set_shards(np.zeros(1, np.int64))
+    lo = o.train_epoch_tokens(ids, np.zeros(1, np.int64))
+    y.train_epoch_tokens(ids, np.zeros(1, np.int64))
+    lg = t.train_epoch(positions_per_launch=501)
+    fin, wca, alpha, _ = t.epoch_status()
+    assert fin and wca == o.m.word_count_actual and np.float32(alpha) == np.float32(o.m.alpha)
+    u, v = t.get_model()
+    for got, ref, yard in ((u, o.u, y.u), (v, o.v, y.v)):
+        gm, gs = drift(got, ref)
+        ym, ys = drift(yard, ref)
+        assert gm <= 3 * ym + 1e-5, (gm, ym)            # no farther than 3x the reference's own FMA build
+        assert gs <= 3 * ys + 2e-4, (gs, ys)
+    assert lg == pytest.approx(lo, rel=2e-3)
+    t.close()
+
+
 @pytest.mark.parametrize("bitlevel,sample,D,window,negative", [
     (1, 1e-3, 64, 5, 5),
     (0, 1e-2, 48, 3, 7),
     (2, 0.0, 100, 8, 24),
     (1, 0.0, 800, 8, 24),
 ])
-def test_single_worker_matches_oracle(gpu, bitlevel, sample, D, window, negative):
+def test_single_worker_long_horizon_statistical(gpu, bitlevel, sample, D, window, negative):
+    """2 epochs x 30000 tokens on 150 rows: every row is rewritten thousands of times and quantized
+    training is chaotic (two builds of the REFERENCE disagree on 4-25% of the signs here), so only
+    the integer bookkeeping is exact; values are held to 'no farther from the bit-reference than
+    1.5x the drift of the oracle's own FMA build' and the epoch loss to 1%."""
     V, n = 150, 30000
     rng = np.random.default_rng(11)
     ids = token_stream(rng, V, n)
     ids[2000:3300] = zipf_ids(rng, V, 1300)  # one 1300-token line: sentence chunking at 1000 (ref :410)
-    cn = counts_of(ids, V)
-    tw = int(cn.sum())
-    o = OracleState(cn, D, window=window, negative=negative, bitlevel=bitlevel, num_threads=1, iters=2,
-                    sample=sample, table_size=50000)
+    cn, tw, o = setup(V, ids, D, window, negative, bitlevel, sample, 2)
+    _, _, y = setup(V, ids, D, window, negative, bitlevel, sample, 2, fma=True)
     t = w2b.Trainer(V, D, window, negative, bitlevel, num_threads=1, iter=2, alpha=0.05, sample=sample,
                     train_words=tw, compute_loss=True)
-    o.m.train_words = tw
     t.set_model(o.u, o.v)
     t.set_vocab_counts(cn, 50000)
     t.set_corpus(ids)
     t.set_shards(np.zeros(1, np.int64))
     for ep in range(2):
         lo = o.train_epoch_tokens(ids, np.zeros(1, np.int64))
+        y.train_epoch_tokens(ids, np.zeros(1, np.int64))
         lg = t.train_epoch(positions_per_launch=777)     # odd launch size: exercises save/restore
         fin, wca, alpha, _ = t.epoch_status()
         assert fin
         assert wca == o.m.word_count_actual                      # integer bookkeeping: exact
         assert np.float32(alpha) == np.float32(o.m.alpha)        # alpha staircase: exact
-        assert lg == pytest.approx(lo, rel=2e-3)
+        assert lg == pytest.approx(lo, rel=1e-2)
     u, v = t.get_model()
-    du, dv = np.abs(u - o.u), np.abs(v - o.v)
-    if bitlevel == 1:
-        assert np.mean(np.signbit(u) == np.signbit(o.u)) >= 0.99
-        assert np.median(du) <= 1e-4
-    else:
-        assert du.mean() <= 1e-4 and dv.mean() <= 1e-4, (du.mean(), dv.mean())
-        assert du.max() <= 5e-2
+    assert np.isfinite(u).all() and np.isfinite(v).all()
+    for got, ref, yard in ((u, o.u, y.u), (v, o.v, y.v)):
+        gm, gs = drift(got, ref)
+        ym, ys = drift(yard, ref)
+        assert gm <= 1.5 * ym + 1e-4, (gm, ym)
+        assert gs <= 1.5 * ys + 1e-3, (gs, ys)
     t.close()
 
 
@@ -81,11 +129,11 @@ def test_shard_override_and_multi_worker_bookkeeping(gpu):
     t.set_vocab_counts(cn, 50000)
     t.set_corpus(ids)
     t.set_shards(starts, ov)
-    o.train_epoch_tokens(ids, starts, ov)
+    o_loss = o.train_epoch_tokens(ids, starts, ov)
     t.train_epoch(positions_per_launch=500)
     fin, wca, alpha, loss = t.epoch_status()
     assert fin and wca == o.m.word_count_actual
     u, v = t.get_model()
     assert np.isfinite(u).all() and np.isfinite(v).all()
-    assert np.abs(u - o.u).mean() < 5e-2
+    assert loss == pytest.approx(o_loss, rel=5e-2)            # racy values, same objective
     t.close()

@@ -1,0 +1,151 @@
+"""not gpu: host-side product code (corpus ingest, tables, C-ABI surface, CLI argument handling)
+against the CPU oracle and the committed reference fixtures.  No compute entry point is called."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import word2bits_amd as w2b
+from word2bits_amd import _lib
+from w2b_testlib import GOLDEN, ROOT, oracle, write_corpus, read_vectors, fptr, iptr, lptr
+
+META = json.load(open(os.path.join(GOLDEN, "golden.json")))
+CORPUS = os.path.join(GOLDEN, "corpus_small.txt")
+
+
+def test_library_exports_every_declared_symbol():
+    L = w2b.lib()
+    declared = set()
+    for h in ("word2bits_hip.h", "word2bits_corpus.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        declared |= set(re.findall(r"\b(w2b_[a-z0-9_]+)\s*\(", src))
+    assert len(declared) >= 40
+    for name in declared:
+        assert hasattr(L, name), "library does not export " + name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_no_cpu_fallback_without_gpu():
+    if w2b.lib().w2b_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(w2b.W2bError) as e:
+        w2b.Trainer(100, 8)
+    assert e.value.code == _lib.W2B_ENOGPU
+
+
+def test_config_struct_layout_matches_header():
+    assert C.sizeof(_lib.Config) == 3 * 8 + 5 * 4 + 3 * 4 + 2 * 4 + 2 * 4 + 5 * 4 + 4  # incl. tail padding
+
+
+@pytest.mark.parametrize("min_count", [1, 2, 5])
+def test_corpus_ingest_matches_oracle_and_reference(min_count, tmp_path):
+    O = oracle()
+    for path in (CORPUS, write_corpus(str(tmp_path / "c.txt"), seed=5, vocab=400, n_tokens=20000)):
+        c = w2b.Corpus(path, min_count)
+        vb = O.w2bo_vocab_learn(path.encode(), min_count)
+        assert c.vocab_size == O.w2bo_vocab_size(vb)
+        assert c.train_words == O.w2bo_vocab_train_words(vb)
+        assert c.file_size == O.w2bo_vocab_file_size(vb) == os.path.getsize(path)
+        assert c.words() == [O.w2bo_vocab_word(vb, i).decode() for i in range(c.vocab_size)]
+        assert c.counts().tolist() == [O.w2bo_vocab_count(vb, i) for i in range(c.vocab_size)]
+        ids, bg = C.POINTER(C.c_int)(), C.POINTER(C.c_longlong)()
+        n = O.w2bo_tokenize_file(vb, path.encode(), C.byref(ids), C.byref(bg))
+        oid = np.ctypeslib.as_array(ids, shape=(n,)).copy()
+        assert np.array_equal(oid[oid >= 0], c.tokens())
+        for nt in (1, 2, 3, 5, 12, 31):
+            st, ov = c.shards(nt)
+            for w in range(nt):
+                o = C.c_int(0)
+                s = O.w2bo_shard_start(vb, path.encode(), c.file_size // nt * w, bg, n, C.byref(o))
+                assert int((oid[:s] >= 0).sum()) == st[w] and o.value == ov[w]
+        O.w2bo_vocab_free(vb)
+        c.close()
+    # against the reference's own stdout (golden.json)
+    for m in META.values():
+        if m["flags"]["min_count"] == min_count:
+            c = w2b.Corpus(CORPUS, min_count)
+            assert (c.vocab_size, c.train_words) == (m["vocab_size"], m["train_words"])
+            c.close()
+
+
+def test_shard_seek_inside_a_word_that_is_itself_a_word(tmp_path):
+    """ref :377: fseek lands mid-word; the tail may be a vocabulary word ('xab' -> 'ab')."""
+    p = str(tmp_path / "s.txt")
+    open(p, "w").write("ab xab ab ab\nxab b ab xab b b\n")
+    c = w2b.Corpus(p, 1)
+    assert c.words()[0] == "</s>" and set(c.words()[1:]) == {"ab", "xab", "b"}
+    for off, expect in ((4, "ab"), (5, "b"), (3, None), (2, None)):
+        # emulate num_threads so that file_size // nt * w == off is not needed: use the oracle helper
+        vb = oracle().w2bo_vocab_learn(p.encode(), 1)
+        ids, bg = C.POINTER(C.c_int)(), C.POINTER(C.c_longlong)()
+        n = oracle().w2bo_tokenize_file(vb, p.encode(), C.byref(ids), C.byref(bg))
+        o = C.c_int(0)
+        oracle().w2bo_shard_start(vb, p.encode(), off, bg, n, C.byref(o))
+        assert o.value == (-2 if expect is None else c.search(expect))
+    # the product's shard arithmetic on the same file: 30 bytes / 6 threads = offsets 0,5,10,...
+    st, ov = c.shards(6)
+    assert ov[1] == c.search("b") and st[0] == 0
+    c.close()
+
+
+def test_host_tables_match_oracle():
+    L, O = w2b.lib(), oracle()
+    a, b = np.zeros(1000, np.float32), np.zeros(1001, np.float32)
+    L.w2b_build_exp_table(a.ctypes.data_as(_lib.f32p))
+    O.w2bo_build_exp_table(fptr(b))
+    assert np.array_equal(a.view(np.uint32), b[:1000].view(np.uint32))
+    rng = np.random.default_rng(0)
+    cn = np.concatenate([[3], np.sort(rng.integers(5, 9000, 999))[::-1]]).astype(np.int64)
+    t1, t2 = np.zeros(200000, np.int32), np.zeros(200000, np.int32)
+    assert L.w2b_build_unigram_table(cn.ctypes.data_as(_lib.i64p), len(cn), t1.ctypes.data_as(_lib.i32p), len(t1)) == 0
+    O.w2bo_build_unigram_table(lptr(cn), len(cn), iptr(t2), len(t2))
+    assert np.array_equal(t1, t2)
+    k1 = np.zeros(len(cn), np.float32)
+    L.w2b_build_keep_prob(cn.ctypes.data_as(_lib.i64p), len(cn), 1e-3, int(cn.sum()), k1.ctypes.data_as(_lib.f32p))
+    k2 = np.array([O.w2bo_keep_prob(int(c), 1e-3, int(cn.sum())) for c in cn], np.float32)
+    assert np.array_equal(k1.view(np.uint32), k2.view(np.uint32))
+    xs = np.concatenate([rng.standard_normal(2000).astype(np.float32), np.float32([0, -0.0, .5, -.5, 1, 7, np.nan])])
+    for bl in (0, 1, 2, 3, 4, 5, 8, 16):
+        got = np.array([L.w2b_quantize(float(x), bl) for x in xs], np.float32)
+        want = np.array([O.w2bo_quantize(float(x), bl) for x in xs], np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), bl
+
+
+@pytest.mark.parametrize("name", ["b1_iter0", "b0_iter0_text", "b2_d10_text"])
+def test_save_vectors_reproduces_reference_file_format(name, tmp_path):
+    """Writer of ref :560-576: feed it the reference's own values, expect the reference's own bytes."""
+    flags = META[name]["flags"]
+    golden = os.path.join(GOLDEN, name + ".vec")
+    words, M = read_vectors(golden, flags["binary"])
+    c = w2b.Corpus(CORPUS, flags["min_count"])
+    assert c.words() == words
+    out = str(tmp_path / "o.vec")
+    c.save_vectors(out, M, flags["binary"])
+    assert open(out, "rb").read() == open(golden, "rb").read()
+    c.close()
+
+
+CLI = os.path.join(ROOT, "word2bits")
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="CLI not built")
+def test_cli_argument_handling_like_reference(tmp_path):
+    # a flag in last position without value (ref :582-585)
+    r = subprocess.run([CLI, "-train", CORPUS, "-size"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Argument missing for -size" in r.stdout
+    # missing training file (ref :271-274)
+    r = subprocess.run([CLI, "-train", str(tmp_path / "nope.txt"), "-output", str(tmp_path / "o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "ERROR: training data file not found!" in r.stdout
+    # no -output: vocabulary statistics only (ref :527), works without a GPU
+    r = subprocess.run([CLI, "-train", CORPUS, "-min-count", "2", "-bogus-flag", "1"], capture_output=True, text=True)
+    m = META["b1_d8"]
+    assert r.returncode == 0
+    assert "Starting training using file %s" % CORPUS in r.stdout
+    assert "Vocab size: %d" % m["vocab_size"] in r.stdout
+    assert "Words in train file: %d" % m["train_words"] in r.stdout

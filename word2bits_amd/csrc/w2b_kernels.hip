@@ -25,7 +25,7 @@
 #include <type_traits>
 
 #ifndef W2B_T
-#define W2B_T 13   // target rows kept in registers per chunk (negative=24 -> 25 targets = 13 + 12)
+#define W2B_T 9    // target rows kept in registers per chunk (negative=24 -> 25 targets = 9 + 9 + 7)
 #endif
 #ifndef W2B_CA
 #define W2B_CA 8   // context rows loaded per sub-chunk
@@ -34,10 +34,11 @@
 #define W2B_STASH 8 // context rows whose raw fp32 columns stay in LDS between phase A and phase C
 #endif
 #ifndef W2B_MINWAVES
-#define W2B_MINWAVES 3  // waves per SIMD the 256-thread kernels are register-allocated for (= workgroups per CU)
+#define W2B_MINWAVES 4  // waves per SIMD the 256-thread kernels are register-allocated for (= workgroups per CU)
 #endif
 #ifndef W2B_MEMMODE
-#define W2B_MEMMODE 0   // 0 plain global loads/stores; 1 agent-scope (sc1) buffer ops; 2 nontemporal
+#define W2B_MEMMODE 0   // cache policy of row accesses: 0 default (L2 write-back), 1 sc1 = agent scope
+                        // (coherent between the 8 XCD L2s), 2 nontemporal
 #endif
 
 namespace {
@@ -68,32 +69,13 @@ __device__ __forceinline__ float quant(float x, const QParam &q) {
 // ------------------------------------------------------------------------------------ row access
 template <int VEC> struct Col { float e[VEC]; };
 
-#if W2B_MEMMODE == 0
-template <int VEC>
-__device__ __forceinline__ Col<VEC> load_col(const float *tab, long long row, int dim, int col0) {
-  Col<VEC> c;
-  // the row id is workgroup-uniform: keep the row base in SGPRs (scalar address + per-lane offset)
-  const float *p = tab + (long long)__builtin_amdgcn_readfirstlane((int)row) * dim + col0;
-  if (VEC == 4) {
-    const float4 t = *reinterpret_cast<const float4 *>(p);
-    c.e[0] = t.x; c.e[1 % VEC] = t.y; c.e[2 % VEC] = t.z; c.e[3 % VEC] = t.w;
-  } else {
-    c.e[0] = *p;
-  }
-  return c;
-}
-template <int VEC>
-__device__ __forceinline__ void store_col(float *tab, long long row, int dim, int col0, const Col<VEC> &c) {
-  float *p = tab + (long long)__builtin_amdgcn_readfirstlane((int)row) * dim + col0;
-  if (VEC == 4) {
-    *reinterpret_cast<float4 *>(p) = make_float4(c.e[0], c.e[1 % VEC], c.e[2 % VEC], c.e[3 % VEC]);
-  } else {
-    *p = c.e[0];
-  }
-}
-#else
 // buffer ops with an explicit cache policy: aux bit4 = sc1 (agent scope), bit1 = nt
-#if W2B_MEMMODE == 1
+// Rows are addressed through a buffer resource whose base is the (workgroup-uniform) row start and
+// whose size is the row length: the row base lives in SGPRs, every lane contributes one 32-bit
+// offset, and lanes beyond the row are dropped by the hardware bounds check.
+#if W2B_MEMMODE == 0
+#define W2B_AUX 0
+#elif W2B_MEMMODE == 1
 #define W2B_AUX 16
 #else
 #define W2B_AUX 2
@@ -126,7 +108,6 @@ __device__ __forceinline__ void store_col(float *tab, long long row, int dim, in
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c.e[0]), r, col0 * 4, 0, W2B_AUX);
   }
 }
-#endif
 
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
