@@ -53,9 +53,12 @@ def parse():
     ap.add_argument("--ids", choices=["zipf", "uniform"], default="zipf")
     ap.add_argument("--sync-every", type=int, default=16)
     ap.add_argument("--sync-mode", type=int, default=0)
+    ap.add_argument("--sync-impl", choices=["lib", "torch"], default="lib")
     ap.add_argument("--cpu-baseline", choices=["reference", "port", "none"], default="reference")
     ap.add_argument("--cpu-tokens", type=int, default=2_000_000)
     ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--relaxed", type=int, default=0,
+                    help="1: plain cached row accesses (not coherent between XCDs); default 0 = agent-scope (sc1)")
     return ap.parse_args()
 
 
@@ -223,15 +226,37 @@ def main():
     props = torch.cuda.get_device_properties(dev)
     ncu = props.multi_processor_count
     workers = args.workers if args.workers > 0 else 4 * ncu
-    t = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=workers if args.form == "worker" else 1,
-                    iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words, compute_loss=False,
-                    device=local_rank)
+    from word2bits_amd import replicas
+    nw_local = workers if args.form == "worker" else 1
+    worker_offset, _ = replicas.worker_plan(nw_local * world, world, rank)   # global Hogwild worker ids
+    t = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=nw_local,
+                    iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words * world,
+                    compute_loss=False, device=local_rank, worker_offset=worker_offset,
+                    total_threads=nw_local * world, relaxed_coherence=bool(args.relaxed))
     t.init_net()                                  # InitNet values (LCG seed 1), ref :343-361
     t.set_vocab_counts(counts, 100_000_000)       # 1e8-entry unigram table, ref :112-128
+    sync_impl = "none (1 GPU)"
+    torch_sync = None
     if world > 1:
-        uid = [w2b.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        t.comm_init(world, rank, uid[0])
+        # replicas: the library's own RCCL communicator; if it cannot be set up in this environment the
+        # same protocol runs on torch.distributed (also RCCL) over a zero-copy view of [u||v]
+        ok = torch.ones(1, device=dev)
+        try:
+            if args.sync_impl != "lib":
+                raise RuntimeError("torch sync requested")
+            t.comm_init(world, rank, replicas.exchange_unique_id(dist, rank, w2b.comm_unique_id))
+        except Exception as e:
+            if args.sync_impl == "lib":
+                print("rank %d: library RCCL init failed (%r), using torch.distributed" % (rank, e), file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            torch_sync = replicas.TorchReplicaSync(dist, args.sync_mode)
+            model_view = t.model_tensor()
+            base_view = model_view.clone()
+            sync_impl = "torch.distributed all_reduce (RCCL) on a view of [u||v]"
+        else:
+            sync_impl = "library RCCL communicator (w2b_sync_replicas)"
 
     nsteps = args.steps + args.warmup
     if args.form == "tuples":
@@ -269,8 +294,8 @@ def main():
                                   args.grid)
     else:
         t.set_corpus_device(stream.data_ptr(), per_rank_tokens)
-        starts = (np.arange(workers, dtype=np.int64) * (per_rank_tokens // workers))
-        t.set_shards(starts)
+        # every rank holds its own stream: local shards are cut inside it
+        t.set_shards(replicas.token_shard_starts(per_rank_tokens, workers, 0, workers))
         t.epoch_begin()
         words_per_step = workers * args.positions
 
@@ -287,7 +312,12 @@ def main():
         for i in range(n0, n1):
             step(i)
             if world > 1 and (i + 1 - args.warmup) % args.sync_every == 0 and i >= args.warmup:
-                t.sync_replicas(args.sync_mode)
+                if torch_sync is not None:
+                    t.synchronize()
+                    torch_sync.sync(model_view, base_view)
+                    torch.cuda.synchronize()
+                else:
+                    t.sync_replicas(args.sync_mode)
 
     run(0, args.warmup, False)
     t.synchronize()
@@ -325,9 +355,11 @@ def main():
                                % (args.tokens // 1_000_000, args.ids, V, args.bitlevel, D, W, K, args.form,
                                   words_per_step),
                    "form": args.form, "vocab": V, "dim": D, "window": W, "negative": K,
-                   "bitlevel": args.bitlevel, "words_per_step_per_gpu": words_per_step,
-                   "replica_sync": ("rccl all-reduce [u||v] every %d steps, mode %d" %
-                                    (args.sync_every, args.sync_mode)) if world > 1 else "none (1 GPU)"},
+                   "bitlevel": args.bitlevel, "words_per_step_per_gpu": words_per_step, "ids": args.ids,
+                   "row_coherence": "relaxed (plain cached accesses)" if args.relaxed else
+                                    "agent scope (sc1): Hogwild coherent across the 8 XCD L2s",
+                   "replica_sync": ("%s every %d steps, mode %d (0 = delta-sum)" %
+                                    (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
                      "kernel": "k_train_%s" % ("tuples" if args.form == "tuples" else "workers"),

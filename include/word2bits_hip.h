@@ -61,7 +61,13 @@ typedef struct w2b_config {
    * the alpha schedule (ref :391) extrapolates local progress by total_threads/num_threads. */
   int32_t worker_offset;
   int32_t total_threads;
-  int32_t reserved[5];   /* must be zero */
+  /* Hogwild memory semantics of the fp32 master rows.  0 (default): every row access is agent-scope
+   * (sc1), i.e. coherent between the eight XCD L2s of an MI355X -- workers see each other's updates as
+   * threads do on a cache-coherent CPU (ref :490,501 write to shared memory).  1: plain cached
+   * accesses -- faster when ids are heavily skewed, but a hot row is then private to an XCD's L2 (or
+   * a CU's L1) until it is evicted or the launch ends; see DESIGN.md section 4. */
+  int32_t relaxed_coherence;
+  int32_t reserved[4];   /* must be zero */
 } w2b_config;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -104,7 +104,9 @@ def test_single_step_parity_collision_free(gpu, D, window, negative, bitlevel, r
     du, dv = np.abs(u - o.u), np.abs(v - o.v)
     atol = single_step_atol(bitlevel)
     assert du.max() <= atol and dv.max() <= atol, (du.max(), dv.max(), atol)
-    assert du.mean() <= SINGLE_STEP_MEAN and dv.mean() <= SINGLE_STEP_MEAN
+    # (a flipped bin moves ~cw+1 rows by <= atol: bounded contribution to the mean over all V rows)
+    mean_tol = SINGLE_STEP_MEAN + atol * 3 * (2 * window + 2) / V
+    assert du.mean() <= mean_tol and dv.mean() <= mean_tol, (du.mean(), dv.mean(), mean_tol)
     # a bin flip moves the rows of ONE tuple: at most a few of the n tuples may be affected at all
     bad_rows = (du.max(axis=1) > ROUNDING_ATOL).sum() + (dv.max(axis=1) > ROUNDING_ATOL).sum()
     assert bad_rows <= 3 * (2 * window + negative + 1), bad_rows

@@ -17,7 +17,7 @@ ap.add_argument("--negative", type=int, default=24)
 ap.add_argument("--iter", type=int, default=5)
 ap.add_argument("--cpu-threads", default="1,8")
 ap.add_argument("--gpu-threads", default="1,8,256,1024")
-ap.add_argument("--variants", default=",_sc1")
+ap.add_argument("--variants", default="coherent,relaxed")
 ap.add_argument("--repeats", type=int, default=120)
 ap.add_argument("--tmp", default="/tmp/w2b_acc")
 a = ap.parse_args()
@@ -53,19 +53,18 @@ for th in [int(x) for x in a.cpu_threads.split(",") if x]:
     report("reference-cpu", th, time.time() - t0, out)
 
 for var in a.variants.split(","):
-    lib = os.path.join(ROOT, "word2bits_amd", "libword2bits_hip%s.so" % var)
-    if not os.path.exists(lib):
-        continue
+    relaxed = (var == "relaxed")
     for th in [int(x) for x in a.gpu_threads.split(",") if x]:
         out = os.path.join(a.tmp, "gpu%s_%d.bin" % (var, th))
         code = ("import sys,time; sys.path.insert(0,%r); import word2bits_amd as w; t0=time.time(); "
                 "l=w.train_model(%r,%r,bitlevel=%d,size=%d,window=%d,negative=%d,threads=%d,iter=%d,min_count=5,binary=1,"
-                "positions_per_launch=%d); print('LOSS', l[-1], time.time()-t0)" %
-                (ROOT, corpus, out, a.bitlevel, a.size, a.window, a.negative, th, a.iter, 65536 if th < 64 else 4096))
-        env = dict(os.environ, W2B_LIB=lib)
+                "positions_per_launch=%d,relaxed_coherence=%r); print('LOSS', l[-1], time.time()-t0)" %
+                (ROOT, corpus, out, a.bitlevel, a.size, a.window, a.negative, th, a.iter, 65536 if th < 64 else 4096,
+                 relaxed))
+        env = dict(os.environ)
         t0 = time.time()
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         if p.returncode != 0:
-            print(json.dumps({"kind": "hip" + var, "threads": th, "error": p.stderr[-400:]}), flush=True)
+            print(json.dumps({"kind": "hip_" + var, "threads": th, "error": p.stderr[-400:]}), flush=True)
             continue
-        report("hip" + (var or "_default"), th, time.time() - t0, out, {"last_epoch_loss": float(p.stdout.split()[1])})
+        report("hip_" + var, th, time.time() - t0, out, {"last_epoch_loss": float(p.stdout.split()[1])})

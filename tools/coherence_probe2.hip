@@ -8,7 +8,7 @@
 #include <cstdio>
 #include <vector>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int AUX>
+template <int AUX, int SAUX = AUX>
 __global__ void sparse_rmw(float *row, int dim, int iters, int sleep_units) {
   __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)row, 0, dim * 4, 0x27000);
   const int off = threadIdx.x * 16;
@@ -23,18 +23,18 @@ __global__ void sparse_rmw(float *row, int dim, int iters, int sleep_units) {
     t.y = __float_as_uint(__uint_as_float(t.y) + 1.f);
     t.z = __float_as_uint(__uint_as_float(t.z) + 1.f);
     t.w = __float_as_uint(__uint_as_float(t.w) + 1.f);
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, SAUX);
     __syncthreads();
   }
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e), #x); return 1; } } while (0)
-template <int AUX> int run(const char *name, float *row, int G, int N, int sleep_units) {
+template <int AUX, int SAUX = AUX> int run(const char *name, float *row, int G, int N, int sleep_units) {
   const int dim = 800;
   CK(hipMemset(row, 0, dim * 4));
   CK(hipDeviceSynchronize());
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   CK(hipEventRecord(a));
-  hipLaunchKernelGGL(sparse_rmw<AUX>, dim3(G), dim3(256), 0, 0, row, dim, N, sleep_units);
+  hipLaunchKernelGGL((sparse_rmw<AUX, SAUX>), dim3(G), dim3(256), 0, 0, row, dim, N, sleep_units);
   CK(hipEventRecord(b));
   CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -55,6 +55,9 @@ int main() {
       run<2>("nt", row, G, 400, sl);
       run<16>("sc1", row, G, 400, sl);
       run<17>("sc0sc1", row, G, 400, sl);
+      run<2, 16>("nt+sc1", row, G, 400, sl);     // L1-bypassing L2-cached loads, write-through stores
+      run<0, 16>("pl+sc1", row, G, 400, sl);     // plain loads, write-through stores
+      run<16, 0>("sc1+pl", row, G, 400, sl);
     }
   }
   // fine-grained / uncached allocations with plain accesses

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum,TCC_MISS_sum collected in SEPARATE
+runs, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) into profiles/<round>_pmc.json.
+
+HBM bytes per launch of the training kernel:
+    read  = FETCH_SIZE [KB] * 1024 * 2     (gfx950: FETCH_SIZE reports exactly 1/2 of a wide coalesced
+                                            16-B/lane stream -- the guide's correction; our row loads are
+                                            buffer_load_dwordx4 of 1 KiB per wavefront)
+    write = WRITE_SIZE [KB] * 1024         (uncalibrated in the guide; compared against the algorithmic
+                                            write bytes below as a plausibility check)
+usage: pmc_summary.py <fetch.csv> <write.csv> <l2.csv> <out.json> [kernel substring]
+"""
+import csv
+import json
+import sys
+
+
+def per_dispatch(path, kernel_sub):
+    agg = {}
+    for r in csv.DictReader(open(path)):
+        if kernel_sub in r.get("Kernel_Name", ""):
+            c = r["Counter_Name"]
+            a = agg.setdefault(c, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return {c: (v[1] / v[0], v[0]) for c, v in agg.items()}
+
+
+def main():
+    fetch, write, l2, out = sys.argv[1:5]
+    ksub = sys.argv[5] if len(sys.argv) > 5 else "k_train_tuples"
+    f = per_dispatch(fetch, ksub)
+    w = per_dispatch(write, ksub)
+    l = per_dispatch(l2, ksub) if l2 != "-" else {}
+    fetch_kb, nf = f["FETCH_SIZE"]
+    write_kb, nw = w["WRITE_SIZE"]
+    res = {
+        "kernel": ksub,
+        "dispatches_sampled": {"FETCH_SIZE": nf, "WRITE_SIZE": nw},
+        "FETCH_SIZE_KB_per_launch": fetch_kb,
+        "WRITE_SIZE_KB_per_launch": write_kb,
+        "hbm_read_bytes_per_launch": fetch_kb * 1024 * 2,
+        "hbm_write_bytes_per_launch": write_kb * 1024,
+        "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
+        "fetch_correction": "x2 (gfx950 FETCH_SIZE half-count on 16-B/lane coalesced reads, MI355X_MICROARCH.md HBM section)",
+    }
+    if l:
+        hit, miss = l["TCC_HIT_sum"][0], l["TCC_MISS_sum"][0]
+        res["l2_hit_rate"] = hit / (hit + miss)
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -29,7 +29,8 @@ class Config(C.Structure):
         ("bitlevel", C.c_int32), ("num_threads", C.c_int32),
         ("alpha", C.c_float), ("sample", C.c_float), ("reg", C.c_float),
         ("compute_loss", C.c_int32), ("device", C.c_int32),
-        ("worker_offset", C.c_int32), ("total_threads", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("worker_offset", C.c_int32), ("total_threads", C.c_int32), ("relaxed_coherence", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 

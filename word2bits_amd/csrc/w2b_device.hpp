@@ -1,0 +1,379 @@
+#pragma once
+// w2b_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the Word2Bits training hot path.
+//
+// Reference math: TrainModelThread, ref src/word2bits.cpp:426-503 (phases A/B/C of one centre word),
+// quantize ref :73-108, sigmoid table ref :473-475, LCG ref :428,455, sentence reader ref :394-413.
+//
+// Decomposition (MI355X-first, not a translation of the CPU loops):
+//   * one WORKGROUP per centre word, one THREAD per 16-byte column of an embedding row
+//     (dim=800 -> 200 active lanes of a 256-thread workgroup).  A wavefront's load of a row is one
+//     contiguous, fully coalesced 1 KiB segment; every thread issues the loads of up to 8 context
+//     rows and W2B_T target rows back-to-back, so one workgroup keeps tens of 3.2 KB rows in
+//     flight -- the kernel is a pure HBM gather/scatter stream (0.6 flop/byte, no MFMA).
+//   * per-thread partial dot products are reduced with wavefront shuffles, then across the
+//     wavefronts through LDS; lane i of every wavefront computes the gradient scalar g of target i
+//     (sigmoid-table lookup) and v_readlane broadcasts it.
+//   * because a thread owns the same column of every row, the context sum (ref :439-441), the
+//     error accumulation (ref :486-488) and the duplicate-row updates (ref :494-503) are executed
+//     in exactly the reference's order per element; only the dot product f (ref :464-466) is
+//     re-associated (tree instead of serial chain) -- this is the one source of fp32 deviation.
+//   * duplicate target rows inside one centre word are serialised by cutting the chunk at the
+//     duplicate (the later occurrence re-reads the row the earlier one wrote, as the CPU does).
+//   * quantisation is on READ (straight-through): masters stay fp32 (SURVEY finding 3).
+//
+// Compiled with -ffp-contract=off so that a*b+c is two roundings, as in the bit-reference build.
+#include "w2b_internal.h"
+#include <type_traits>
+
+#ifndef W2B_T
+#define W2B_T 9    // target rows kept in registers per chunk (negative=24 -> 25 targets = 9 + 9 + 7)
+#endif
+#ifndef W2B_CA
+#define W2B_CA 8   // context rows loaded per sub-chunk
+#endif
+#ifndef W2B_STASH
+#define W2B_STASH 8 // context rows whose raw fp32 columns stay in LDS between phase A and phase C
+#endif
+#ifndef W2B_MINWAVES
+#define W2B_MINWAVES 4  // waves per SIMD the 256-thread kernels are register-allocated for (= workgroups per CU)
+#endif
+
+namespace {
+
+// ------------------------------------------------------------------------------------ quantizer
+// QM: 0 identity, 1 one bit, 2 two bits, 3 generic run-time bitlevel (>=3)
+struct QParam { int bitlevel; int steps_i; float steps_f; };
+
+template <int QM>
+__device__ __forceinline__ float quant(float x, const QParam &q) {
+  if (QM == 0) return x;
+  const float sgn = (x < 0.f) ? -1.f : 1.f;          // +0, -0, NaN -> +1 (ref :80)
+  if (QM == 1) return sgn / 3.f;                      // ref :85-87
+  const float mag = x * sgn;
+  if (QM == 2) {                                       // ref :91-94
+    const float lvl = (mag >= 0.f && mag <= .5f) ? .25f : .75f;
+    return sgn * lvl;
+  }
+  float lvl = 0.f;                                     // bitlevel 3 falls through to +-0
+  if (q.bitlevel >= 4) {                               // ref :99-104
+    int k = (int)(mag * q.steps_f + .5f);              // v_cvt saturates where x86 yields INT_MIN
+    k = k > q.steps_i ? q.steps_i : k;
+    lvl = (float)k / q.steps_f;
+  }
+  return sgn * lvl;
+}
+
+// ------------------------------------------------------------------------------------ row access
+template <int VEC> struct Col { float e[VEC]; };
+
+// buffer ops with an explicit cache policy: aux bit4 = sc1 (agent scope), bit1 = nt
+// Rows are addressed through a buffer resource whose base is the (workgroup-uniform) row start and
+// whose size is the row length: the row base lives in SGPRs, every lane contributes one 32-bit
+// offset, and lanes beyond the row are dropped by the hardware bounds check.
+// MM (memory mode, run-time selectable per trainer): 0 = sc1, agent scope: coherent between the eight
+// XCD L2s (Hogwild as on a cache-coherent CPU; the default); 1 = plain cached accesses (relaxed: a hot
+// row is private to an XCD's L2 / a CU's L1 until it is evicted or the launch ends); 2 = nontemporal.
+// experimental: 2 = nontemporal (L1-bypassing, L2-cached) loads + sc1 write-through stores;
+//               3 = plain loads + sc1 write-through stores
+template <int MM> struct Aux {
+  static constexpr int load = (MM == 0) ? 16 : ((MM == 2) ? 2 : 0);
+  static constexpr int store = (MM == 1) ? 0 : 16;
+};
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int VEC, int MM>
+__device__ __forceinline__ Col<VEC> load_col(const float *tab, long long row, int dim, int col0) {
+  Col<VEC> c;
+  const float *rowp = tab + __builtin_amdgcn_readfirstlane((int)row) * (long long)dim;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, dim * 4, 0x27000);
+  if (VEC == 4) {
+    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, col0 * 4, 0, Aux<MM>::load);
+    c.e[0] = __uint_as_float(t.x); c.e[1 % VEC] = __uint_as_float(t.y);
+    c.e[2 % VEC] = __uint_as_float(t.z); c.e[3 % VEC] = __uint_as_float(t.w);
+  } else {
+    c.e[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, col0 * 4, 0, Aux<MM>::load));
+  }
+  return c;
+}
+template <int VEC, int MM>
+__device__ __forceinline__ void store_col(float *tab, long long row, int dim, int col0, const Col<VEC> &c) {
+  float *rowp = tab + __builtin_amdgcn_readfirstlane((int)row) * (long long)dim;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, dim * 4, 0x27000);
+  if (VEC == 4) {
+    u32x4 t;
+    t.x = __float_as_uint(c.e[0]); t.y = __float_as_uint(c.e[1 % VEC]);
+    t.z = __float_as_uint(c.e[2 % VEC]); t.w = __float_as_uint(c.e[3 % VEC]);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, col0 * 4, 0, Aux<MM>::store);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c.e[0]), r, col0 * 4, 0, Aux<MM>::store);
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+// LDS traffic between lanes of ONE wavefront is executed in order by the hardware; this only stops
+// the compiler from moving LDS accesses across the point.
+#define W2B_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+__device__ __forceinline__ unsigned long long lane_lt_mask(int lane) {
+  return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// ------------------------------------------------------------------------------------ LDS carving
+// All regions are 4-byte typed; the carve keeps the float region 16-byte aligned.
+struct WordLds {
+  int *ctx;     // [maxc]  context rows of u, window order (ref :431-436)
+  int *umult;   // [maxc]  multiplicity at the first occurrence of a row, 0 at later duplicates
+  int *tgt;     // [maxt]  target rows of v: [0] = centre word (label 1), then kept negatives (label 0)
+  int *prev;    // [maxt]  index of the previous occurrence of the same target row, or -1
+  float *red;   // [2][W2B_T][W2B_MAXW] cross-wave partial dot products (double buffered)
+  float *stash; // [W2B_STASH][blockDim][VEC] raw u columns of the first context rows, private to the
+                // owning thread: phase C updates them without a second trip to memory
+};
+
+__device__ __forceinline__ int round4(int x) { return (x + 3) & ~3; }
+
+__device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int negative, int vec) {
+  const int maxc = round4(2 * window + 1), maxt = round4(negative + 1);
+  WordLds L;
+  L.stash = reinterpret_cast<float *>(base);
+  base += W2B_STASH * blockDim.x * vec;
+  L.red = reinterpret_cast<float *>(base);
+  int *p = base + 2 * W2B_T * W2B_MAXW;
+  L.ctx = p; p += maxc;
+  L.umult = p; p += maxc;
+  L.tgt = p; p += maxt;
+  L.prev = p; p += maxt;
+  return L;
+}
+
+// ------------------------------------------------------------------------------------ one centre word
+// Preconditions: L.ctx[0..cw), L.tgt[0..nt) published by a __syncthreads(); cw >= 1, nt >= 1.
+// Ends with a __syncthreads() (lists may be overwritten afterwards).
+template <int QM, int VEC, bool LOSS, int MM>
+__device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &L, const QParam &qp,
+                                             const int cw, const int nt, const float alpha,
+                                             double &loss_acc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int dim = P.dim, col0 = tid * VEC;
+  const bool active = col0 < dim;
+  const float ar2 = (2.f * alpha) * P.reg;                      // 2*alpha*reg (ref :490,:501)
+
+  // ---- duplicate bookkeeping (tiny, O(n^2) over <= 2*window / negative+1 entries)
+  for (int i = tid; i < nt; i += blockDim.x) {
+    const int me = L.tgt[i];
+    int pd = -1;
+    for (int j = 0; j < i; j++) pd = (L.tgt[j] == me) ? j : pd;
+    L.prev[i] = pd;
+  }
+  for (int i = tid; i < cw; i += blockDim.x) {
+    const int me = L.ctx[i];
+    bool first = true;
+    for (int j = 0; j < i; j++) first = first && (L.ctx[j] != me);
+    int mult = 0;
+    if (first) for (int j = i; j < cw; j++) mult += (L.ctx[j] == me);
+    L.umult[i] = mult;
+  }
+  __syncthreads();
+
+  auto chunk_end = [&](int start) {
+    int end = start + 1;
+    while (end < nt && end - start < W2B_T && L.prev[end] < start) end++;
+    return end;
+  };
+
+  Col<VEC> x[W2B_T];
+  int start = 0, end = chunk_end(0);
+  // issue the first chunk of target-row loads before the context phase so both gathers overlap
+#pragma unroll
+  for (int i = 0; i < W2B_T; i++) {
+#pragma unroll
+    for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
+    if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, L.tgt[start + i], dim, col0);
+  }
+
+  // ---- phase A: context_avg = (1/cw) * sum_j quantize(u[ctx_j])   (ref :431-449)
+  Col<VEC> avg;
+  float regsq = 0.f;
+#pragma unroll
+  for (int e = 0; e < VEC; e++) avg.e[e] = 0.f;
+  for (int j0 = 0; j0 < cw; j0 += W2B_CA) {
+    Col<VEC> r[W2B_CA];
+#pragma unroll
+    for (int jj = 0; jj < W2B_CA; jj++)
+      if (active && j0 + jj < cw) r[jj] = load_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0);
+#pragma unroll
+    for (int jj = 0; jj < W2B_CA; jj++)
+      if (active && j0 + jj < cw) {
+        if (j0 + jj < W2B_STASH) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) L.stash[((j0 + jj) * blockDim.x + tid) * VEC + e] = r[jj].e[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          const float q = quant<QM>(r[jj].e[e], qp);
+          avg.e[e] += q;
+          if (LOSS) regsq += q * q;
+        }
+      }
+  }
+  {
+    const float cwf = (float)cw;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) avg.e[e] = active ? avg.e[e] / cwf : 0.f;   // ref :449
+  }
+
+  // ---- phase B: targets (ref :450-492)
+  Col<VEC> err;
+#pragma unroll
+  for (int e = 0; e < VEC; e++) err.e[e] = 0.f;
+  int par = 0;
+  for (;;) {
+    const int n = end - start;
+    float p[W2B_T], p2[W2B_T];
+#pragma unroll
+    for (int i = 0; i < W2B_T; i++) {
+      float s = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        const float q = quant<QM>(x[i].e[e], qp);
+        s += avg.e[e] * q;                                      // ref :466 (re-associated)
+        if (LOSS) s2 += q * q;
+      }
+      p[i] = active ? s : 0.f;
+      p2[i] = active ? s2 : 0.f;
+    }
+    float *red = L.red + par * (W2B_T * W2B_MAXW);
+#pragma unroll
+    for (int i = 0; i < W2B_T; i++) {
+      if (i < n) {
+        const float s = wave_sum(p[i]);
+        if (lane == 0) red[i * W2B_MAXW + wave] = s;
+      }
+    }
+    __syncthreads();
+    // lane i of every wavefront: f_i, then g_i (ref :473-475)
+    float gl = 0.f;
+    if (lane < n) {
+      float f = 0.f;
+      for (int w = 0; w < nwaves; w++) f += red[lane * W2B_MAXW + w];
+      const float label = (start + lane == 0) ? 1.f : 0.f;      // target 0 is the centre word
+      float g;
+      if (f > 6.f) g = (label - 1.f) * alpha;
+      else if (f < -6.f) g = label * alpha;
+      else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
+      gl = g;
+      if (LOSS && wave == 0) {                                  // ref :480-483
+        const float dp = (label != 0.f) ? f : -f;
+        float sg;
+        if (dp > 6.f) sg = 1.f;
+        else if (dp < -6.f) sg = 1e-9f;
+        else sg = 1.f / (1.f + expf(-dp));
+        loss_acc += (double)logf(sg);
+      }
+    }
+    if (LOSS && P.reg != 0.f) {                                 // reg * sum q^2 of every target row
+#pragma unroll
+      for (int i = 0; i < W2B_T; i++)
+        if (i < n) {
+          const float s2 = wave_sum(p2[i]);
+          if (lane == 0) loss_acc -= (double)(P.reg * s2);
+        }
+    }
+    // error accumulation + row update, in target order (ref :486-491)
+#pragma unroll
+    for (int i = 0; i < W2B_T; i++) {
+      if (i < n) {
+        const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
+        if (active) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) {
+            const float xv = x[i].e[e];
+            err.e[e] += g * quant<QM>(xv, qp);
+            x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
+          }
+          store_col<VEC, MM>(P.v, L.tgt[start + i], dim, col0, x[i]);
+        }
+      }
+    }
+    start = end;
+    if (start >= nt) break;
+    end = chunk_end(start);
+    par ^= 1;
+#pragma unroll
+    for (int i = 0; i < W2B_T; i++)
+      if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, L.tgt[start + i], dim, col0);
+  }
+
+  // ---- phase C: u[ctx_j] += context_avge - 2*alpha*reg*u[ctx_j]   (ref :494-503)
+  for (int j0 = 0; j0 < cw; j0 += W2B_CA) {
+    Col<VEC> r[W2B_CA];
+#pragma unroll
+    for (int jj = 0; jj < W2B_CA; jj++)
+      if (active && j0 + jj < cw && L.umult[j0 + jj] > 0) {
+        if (j0 + jj < W2B_STASH) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) r[jj].e[e] = L.stash[((j0 + jj) * blockDim.x + tid) * VEC + e];
+        } else {
+          r[jj] = load_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0);
+        }
+      }
+#pragma unroll
+    for (int jj = 0; jj < W2B_CA; jj++)
+      if (active && j0 + jj < cw) {
+        const int m = L.umult[j0 + jj];
+        if (m > 0) {
+          for (int k = 0; k < m; k++) {      // a row that occurs m times in the window is updated m times
+#pragma unroll
+            for (int e = 0; e < VEC; e++) r[jj].e[e] = r[jj].e[e] + (err.e[e] - ar2 * r[jj].e[e]);
+          }
+          store_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0, r[jj]);
+        }
+      }
+  }
+  if (LOSS && P.reg != 0.f) {
+    const float s = wave_sum(regsq);
+    if (lane == 0) loss_acc -= (double)(P.reg * s);             // ref :437-445 (summed over the window)
+  }
+  __syncthreads();
+}
+
+
+struct WorkerLds {            // scalars of one worker, owned by wavefront 0
+  unsigned long long rng;
+  long long cursor, wc, last_wc;
+  int sen_len, sen_pos, override_, eof, done, cw, nt, pad;
+  float alpha;
+};
+
+template <typename F>
+hipError_t dispatch_q(int bitlevel, F &&f) {
+  switch (bitlevel) {
+    case 0: return f(std::integral_constant<int, 0>());
+    case 1: return f(std::integral_constant<int, 1>());
+    case 2: return f(std::integral_constant<int, 2>());
+    default: return f(std::integral_constant<int, 3>());
+  }
+}
+
+
+// mem-mode dispatch: f(std::integral_constant<int, MM>)
+template <typename F>
+hipError_t dispatch_mm(int mem_mode, F &&f) {
+  switch (mem_mode) {
+    case 1: return f(std::integral_constant<int, 1>());
+#ifdef W2B_EXPERIMENTAL_MEMMODES
+    case 2: return f(std::integral_constant<int, 2>());
+    case 3: return f(std::integral_constant<int, 3>());
+#endif
+    default: return f(std::integral_constant<int, 0>());
+  }
+}
+
+}  // namespace

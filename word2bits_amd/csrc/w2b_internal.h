@@ -47,6 +47,7 @@ struct W2bParams {
   long long vocab_size, train_words, iter;
   int dim, window, negative, bitlevel, num_threads;
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
+  int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
   float starting_alpha, sample, reg;
 };
 

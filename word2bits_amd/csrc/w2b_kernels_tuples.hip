@@ -1,0 +1,93 @@
+// w2b_kernels_tuples.hip -- form (ii): explicit (centre, context, negatives) tuples.  See w2b_device.hpp.
+#include "w2b_device.hpp"
+
+namespace {
+// ------------------------------------------------------------------------------------ form (ii): tuples
+template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM>
+__global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES : 1)) k_train_tuples(const W2bParams P, const long long n,
+                                                      const int32_t *__restrict__ center,
+                                                      const int32_t *__restrict__ ctx_off,
+                                                      const int32_t *__restrict__ ctx,
+                                                      const int32_t *__restrict__ neg,
+                                                      const float alpha) {
+  extern __shared__ int smem[];
+  const WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
+  int *s_cnt = L.prev + round4(P.negative + 1);   // [0] cw, [1] nt
+  const int tid = threadIdx.x, lane = tid & 63;
+  QParam qp;
+  qp.bitlevel = P.bitlevel;
+  qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
+  qp.steps_f = (float)qp.steps_i;
+  double loss_acc = 0.0;
+  const int K = P.negative;
+  for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+    if (tid < 64) {
+      const int c0 = ctx_off[i], cw = ctx_off[i + 1] - c0;
+      for (int j = lane; j < cw; j += 64) L.ctx[j] = ctx[c0 + j];
+      const int word = center[i];
+      int cnt = 0;
+      for (int d0 = 0; d0 < K; d0 += 64) {
+        const int d = d0 + lane;
+        const int t = (d < K) ? neg[i * K + d] : -1;
+        const bool keep = (t >= 0) && (t != word);             // skipped draw, ref :458
+        const unsigned long long m = __ballot(keep);
+        if (keep) L.tgt[1 + cnt + __popcll(m & lane_lt_mask(lane))] = t;
+        cnt += __popcll(m);
+      }
+      if (lane == 0) { L.tgt[0] = word; s_cnt[0] = cw; s_cnt[1] = 1 + cnt; }
+    }
+    __syncthreads();
+    const int cw = s_cnt[0], nt = s_cnt[1];
+    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc);
+    else __syncthreads();
+  }
+  if (LOSS) {
+    if (tid < 64) {
+      const double s = wave_sum_d(loss_acc);
+      if (lane == 0) atomicAdd(&P.shared->loss_tuples, s);
+    } else if ((tid & 63) == 0 && loss_acc != 0.0) {
+      atomicAdd(&P.shared->loss_tuples, loss_acc);   // reg terms booked by lane 0 of the other waves
+    }
+  }
+}
+
+}  // namespace
+
+// instantiation), so the grid-stride loop has no tail of late-starting workgroups.
+template <typename KernelT>
+static int auto_grid(KernelT kernel, int threads, size_t lds, int num_cus, int per_cu_override, long long n) {
+  int nb = 0;
+  if (per_cu_override > 0) nb = per_cu_override;
+  else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds) != hipSuccess || nb < 1) nb = 2;
+  long long g = (long long)num_cus * nb;
+  if (g > n) g = n;
+  return (int)(g < 1 ? 1 : g);
+}
+
+hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *center, const int32_t *ctx_off,
+                             const int32_t *ctx, const int32_t *neg, float alpha, int grid, int num_cus,
+                             int per_cu_override, bool loss, hipStream_t s) {
+  int vec;
+  const int threads = w2b_block_threads(p.dim, &vec);
+  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, false);
+  return dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
+  constexpr int MM = decltype(mm)::value;
+  return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
+    constexpr int QM = decltype(qm)::value;
+#define W2B_LAUNCH_T2(VEC, LOSS, MAXT)                                                                      \
+    do {                                                                                                     \
+      auto kern = k_train_tuples<QM, VEC, LOSS, MAXT, MM>;                                                       \
+      const int g = grid > 0 ? grid : auto_grid(kern, threads, lds, num_cus, per_cu_override, n);            \
+      hipLaunchKernelGGL(kern, dim3(g), dim3(threads), lds, s, p, n, center, ctx_off, ctx, neg, alpha);      \
+    } while (0)
+#define W2B_LAUNCH_T(VEC, LOSS) \
+    do { if (threads <= 256) W2B_LAUNCH_T2(VEC, LOSS, 256); else W2B_LAUNCH_T2(VEC, LOSS, 1024); } while (0)
+    if (vec == 4) { if (loss) W2B_LAUNCH_T(4, true); else W2B_LAUNCH_T(4, false); }
+    else { if (loss) W2B_LAUNCH_T(1, true); else W2B_LAUNCH_T(1, false); }
+#undef W2B_LAUNCH_T
+#undef W2B_LAUNCH_T2
+    return hipGetLastError();
+  });
+  });
+}
+

@@ -1,0 +1,211 @@
+// w2b_kernels_workers.hip -- form (i): one workgroup per Hogwild worker, walking its corpus shard like
+// TrainModelThread (ref src/word2bits.cpp:363-516).  See w2b_device.hpp.
+#include "w2b_device.hpp"
+
+namespace {
+// ------------------------------------------------------------------------------------ form (i): workers
+
+__device__ __forceinline__ unsigned long long lcg_jump(const W2bParams &P, unsigned long long x, int k) {
+  return P.jump_a[k] * x + P.jump_c[k];
+}
+
+// The sentence reader of ref :394-413, executed by wavefront 0 (64 tokens per trip).
+// All scalars are wave-uniform.
+__device__ __forceinline__ void read_sentence(const W2bParams &P, int *s_sen, unsigned long long &rng,
+                                              long long &cursor, long long &wc, int &ovr, int &eof,
+                                              int &len_out, const int lane) {
+  int len = 0;
+  bool stop = false;
+  const bool sub = (P.sample > 0.f);
+  if (ovr != -2) {                       // truncated first word of the shard (mid-word fseek, ref :377)
+    const int w = ovr;
+    ovr = -2;
+    if (w != -1) {
+      wc++;
+      if (w == 0) stop = true;
+      else {
+        bool kept = true;
+        if (sub) {
+          rng = rng * W2B_LCG_A + W2B_LCG_C;
+          kept = !(P.keep[w] < (float)(rng & 0xFFFF) / 65536.f);
+        }
+        if (kept) { if (lane == 0) s_sen[0] = w; len = 1; }
+      }
+    }
+  }
+  while (!stop) {
+    const long long i = cursor + lane;
+    const bool in = i < P.n_tokens;
+    const int tok = in ? P.corpus[i] : 0;
+    const bool isw = in && tok != 0;
+    const unsigned long long mw = __ballot(isw);
+    const unsigned long long lt = lane_lt_mask(lane);
+    bool kept = isw;
+    if (sub && isw) {
+      const unsigned long long x = lcg_jump(P, rng, __popcll(mw & lt) + 1);
+      kept = !(P.keep[tok] < (float)(x & 0xFFFF) / 65536.f);    // ref :403-406
+    }
+    const unsigned long long mk = __ballot(kept);
+    const int kpos = __popcll(mk & lt);
+    const bool lim = kept && (len + kpos + 1 >= W2B_MAX_SEN);    // ref :410
+    const unsigned long long mt = __ballot(!in || (in && tok == 0) || lim);
+    const unsigned long long min_ = __ballot(in);
+    const int e = mt ? (__ffsll((long long)mt) - 1) : 64;
+    const int ncons = e + ((e < 64 && ((min_ >> e) & 1ull)) ? 1 : 0);
+    const unsigned long long cmask = (ncons >= 64) ? ~0ull : ((1ull << ncons) - 1ull);
+    if (kept && lane < ncons) s_sen[len + kpos] = tok;
+    len += __popcll(mk & cmask);
+    wc += ncons;
+    cursor += ncons;
+    if (sub) rng = lcg_jump(P, rng, __popcll(mw & cmask));
+    if (e < 64) {
+      stop = true;
+      if (!((min_ >> e) & 1ull)) eof = 1;
+    }
+  }
+  len_out = len;
+}
+
+template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM>
+__global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES : 1)) k_train_workers(const W2bParams P, const long long max_positions) {
+  extern __shared__ int smem[];
+  const WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
+  int *s_sen = L.prev + round4(P.negative + 1);
+  WorkerLds *S = reinterpret_cast<WorkerLds *>(s_sen + round4(W2B_MAX_SEN) + 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wid = blockIdx.x;
+  if (wid >= P.num_threads) return;
+  W2bWorker *G = P.workers + wid;
+  if (G->done) return;
+  QParam qp;
+  qp.bitlevel = P.bitlevel;
+  qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
+  qp.steps_f = (float)qp.steps_i;
+  // restore the worker
+  for (int i = tid; i < G->sen_len; i += blockDim.x) s_sen[i] = G->sen[i];
+  if (tid == 0) {
+    S->rng = G->rng; S->cursor = G->cursor; S->wc = G->word_count; S->last_wc = G->last_word_count;
+    S->sen_len = G->sen_len; S->sen_pos = G->sen_pos; S->override_ = G->first_override;
+    S->eof = 0; S->done = 0; S->cw = 0; S->nt = 0; S->alpha = 0.f;
+  }
+  __syncthreads();
+  double loss_acc = 0.0;
+  const int W = P.window, K = P.negative;
+  for (long long it = 0; it < max_positions; ++it) {
+    if (wave == 0) {
+      unsigned long long rng = S->rng;
+      long long cursor = S->cursor, wc = S->wc, last_wc = S->last_wc;
+      int sen_len = S->sen_len, sen_pos = S->sen_pos, ovr = S->override_, eof = S->eof;
+      int done = 0, cw = 0, nt = 0;
+      float alpha = 0.f;
+      if (wc - last_wc > 10000) {                                    // ref :379-393
+        if (lane == 0) {
+          const unsigned long long d = (unsigned long long)(wc - last_wc);
+          const unsigned long long wca = atomicAdd(&P.shared->word_count_actual, d) + d;
+          // other replicas are assumed to progress at the same pace (exact for a single replica)
+          const long long wca_all = (long long)wca * (P.total_threads / P.num_threads);
+          float a = P.starting_alpha * (1.f - (float)wca_all / (float)(P.iter * P.train_words + 1));
+          if ((double)a < (double)P.starting_alpha * 0.0001) a = (float)((double)P.starting_alpha * 0.0001);
+          __hip_atomic_store(&P.shared->alpha, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        last_wc = wc;
+      }
+      if (sen_len == 0) {                                            // ref :394-413
+        read_sentence(P, s_sen, rng, cursor, wc, ovr, eof, sen_len, lane);
+        sen_pos = 0;
+        W2B_WAVE_SYNC();
+      }
+      if (eof || wc > P.train_words / P.total_threads) {              // ref :414-423 (local_iter == 1)
+        if (lane == 0)
+          atomicAdd(&P.shared->word_count_actual, (unsigned long long)(wc - last_wc));
+        last_wc = wc;
+        done = 1;
+      } else {
+        const int word = (sen_len > 0) ? s_sen[sen_pos] : 0;          // ref :424
+        rng = rng * W2B_LCG_A + W2B_LCG_C;                            // ref :428-429
+        const int b = (int)(rng % (unsigned long long)W);
+        const int hi = 2 * W + 1 - b;
+        for (int a0 = b; a0 < hi; a0 += 64) {                         // ref :431-436
+          const int a = a0 + lane;
+          const int c = sen_pos - W + a;
+          const bool ok = (a < hi) && (a != W) && (c >= 0) && (c < sen_len);
+          const unsigned long long m = __ballot(ok);
+          if (ok) L.ctx[cw + __popcll(m & lane_lt_mask(lane))] = s_sen[c];
+          cw += __popcll(m);
+        }
+        if (cw > 0) {                                                 // ref :450-460
+          int cnt = 0;
+          for (int d0 = 1; d0 <= K; d0 += 64) {
+            const int d = d0 + lane;
+            bool keep = false;
+            int t = 0;
+            if (d <= K) {
+              const unsigned long long x = lcg_jump(P, rng, d);
+              t = P.table[(x >> 16) % (unsigned long long)P.table_size];
+              if (t == 0) t = (int)(x % (unsigned long long)(P.vocab_size - 1)) + 1;
+              keep = (t != word);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) L.tgt[1 + cnt + __popcll(m & lane_lt_mask(lane))] = t;
+            cnt += __popcll(m);
+          }
+          if (lane == 0) L.tgt[0] = word;
+          nt = 1 + cnt;
+          rng = lcg_jump(P, rng, K);
+          alpha = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sen_pos++;                                                    // ref :505-509
+        if (sen_pos >= sen_len) sen_len = 0;
+      }
+      if (lane == 0) {
+        S->rng = rng; S->cursor = cursor; S->wc = wc; S->last_wc = last_wc;
+        S->sen_len = sen_len; S->sen_pos = sen_pos; S->override_ = ovr; S->eof = eof;
+        S->done = done; S->cw = cw; S->nt = nt; S->alpha = alpha;
+      }
+    }
+    __syncthreads();
+    if (S->done) break;
+    const int cw = S->cw, nt = S->nt;
+    const float alpha = S->alpha;
+    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc);
+    else __syncthreads();
+  }
+  // save the worker
+  __syncthreads();
+  const int sl = S->sen_len;
+  for (int i = tid; i < sl; i += blockDim.x) G->sen[i] = s_sen[i];
+  double lsum = 0.0;
+  if (LOSS) {
+    // wave 0 holds the log-sigmoid terms on its lanes; lane 0 of every wave holds reg terms
+    if (wave == 0) lsum = wave_sum_d(loss_acc);
+    else if (lane == 0 && loss_acc != 0.0) atomicAdd(&G->loss, loss_acc);
+  }
+  if (tid == 0) {
+    G->rng = S->rng; G->cursor = S->cursor; G->word_count = S->wc; G->last_word_count = S->last_wc;
+    G->sen_len = S->sen_len; G->sen_pos = S->sen_pos; G->first_override = S->override_;
+    if (LOSS) atomicAdd(&G->loss, lsum);
+    if (S->done) { G->done = 1; atomicAdd(&P.shared->workers_done, 1); }
+  }
+}
+
+}  // namespace
+
+hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s) {
+  int vec;
+  const int threads = w2b_block_threads(p.dim, &vec);
+  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, true);
+  return dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
+  constexpr int MM = decltype(mm)::value;
+  return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
+    constexpr int QM = decltype(qm)::value;
+#define W2B_LAUNCH_W(VEC, LOSS) \
+    do { if (threads <= 256) hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 256, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); \
+         else hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 1024, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); } while (0)
+    if (vec == 4) { if (loss) W2B_LAUNCH_W(4, true); else W2B_LAUNCH_W(4, false); }
+    else { if (loss) W2B_LAUNCH_W(1, true); else W2B_LAUNCH_W(1, false); }
+#undef W2B_LAUNCH_W
+    return hipGetLastError();
+  });
+  });
+}
+

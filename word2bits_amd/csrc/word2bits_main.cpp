@@ -5,7 +5,7 @@
 // compute_accuracy evaluator runs unchanged on the result.  What differs is where the work
 // happens: the corpus is tokenised once on the host (word2bits_corpus.h) and every epoch is a
 // sequence of GPU launches in which each of the -threads Hogwild workers is one workgroup.
-// GPU-only additions use new flag names: -gpus, -sync-every, -positions, -device, -table-size.
+// GPU-only additions use new flag names: -gpus, -positions, -device, -table-size, -relaxed.
 #include <pthread.h>
 #include <unistd.h>
 
@@ -32,6 +32,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   long long sync_every = 0;            // positions per worker between replica syncs (0: once per launch)
   long long positions = 4096;          // sentence positions per worker per launch
   long long table_size = W2B_UNIGRAM_TABLE_SIZE;
+  int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
 };
 
 // ArgPos, ref :579-589: exact-match search; a flag in last position has no value -> exit(1)
@@ -106,6 +107,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-sync-every", argc, argv)) > 0) o.sync_every = atoll(argv[i + 1]);
   if ((i = arg_pos("-positions", argc, argv)) > 0) o.positions = atoll(argv[i + 1]);
   if ((i = arg_pos("-table-size", argc, argv)) > 0) o.table_size = atoll(argv[i + 1]);
+  if ((i = arg_pos("-relaxed", argc, argv)) > 0) o.relaxed = atoi(argv[i + 1]);
 
   // ---- TrainModel, ref :518-577
   printf("Starting training using file %s\n", o.train_file.c_str());
@@ -171,6 +173,7 @@ int main(int argc, char **argv) {
     cfg.compute_loss = 1;
     cfg.device = o.device + a->r->index;
     cfg.worker_offset = a->r->index * a->per_gpu;             // worker_offset: global id of local worker 0
+    cfg.relaxed_coherence = o.relaxed;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
     CK(w2b_init_net(a->r->t));                              // ref :528

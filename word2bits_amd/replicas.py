@@ -1,0 +1,74 @@
+"""Multi-GPU plan of the hot path: one process per GPU, corpus shards <-> ranks, replicas of
+[u || v] combined by a periodic all-reduce.  The reference's only parallelism is
+Hogwild over pthreads that share one model (ref src/word2bits.cpp:535-536); across GPUs there is no
+shared memory, so each rank trains a full replica on its own corpus shard and the replicas are
+summed as DELTAS:  W <- base + sum_r (W_r - base)  -- the closest analogue of all threads adding
+their updates into one shared table.
+
+Two interchangeable implementations of the exchange:
+  * the library's own RCCL communicator (w2b_comm_init / w2b_sync_replicas) -- used by the CLI
+    and by bench.py on GPUs;
+  * `TorchReplicaSync` below, the same protocol on torch.distributed tensors -- it runs on CPU
+    tensors over gloo, which is how the N>1 logic is tested without GPUs.
+"""
+import numpy as np
+
+
+def worker_plan(total_workers, world, rank):
+    """Global Hogwild worker ids owned by `rank`: a contiguous block, as the CLI assigns them
+    (word2bits_main.cpp: worker_offset = rank * per_gpu).  total_workers must divide evenly."""
+    if total_workers % world:
+        raise ValueError("-threads (%d) must be a multiple of the number of GPUs (%d)" % (total_workers, world))
+    per = total_workers // world
+    return rank * per, per
+
+
+def token_shard_starts(n_tokens, total_workers, worker_offset, num_workers):
+    """Start index of each local worker inside a token stream of n_tokens when the stream is cut into
+    total_workers equal shards (the token-stream analogue of file_size/num_threads*id, ref :377)."""
+    ids = np.arange(worker_offset, worker_offset + num_workers, dtype=np.int64)
+    return ids * (n_tokens // total_workers)
+
+
+def exchange_unique_id(dist, rank, make_id):
+    """rank 0 creates the RCCL unique id, everyone receives it over the existing process group."""
+    box = [make_id() if rank == 0 else None]
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+class TorchReplicaSync:
+    """Delta-sum (mode 0) / average (mode 1) replica exchange on torch tensors.
+
+    `model` is the flat [u || v] tensor of this rank, `base` the snapshot taken at the previous
+    exchange.  With world size 1 both modes leave `model` bit-identical (no arithmetic is done)."""
+
+    def __init__(self, dist, mode=0):
+        self.dist = dist
+        self.mode = mode
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def sync(self, model, base):
+        if self.world == 1:
+            return model
+        if self.mode == 0:
+            model.sub_(base)                       # W <- W - base
+            self.dist.all_reduce(model)            # sum of deltas
+            model.add_(base)                       # W <- base + sum
+            base.copy_(model)
+        elif self.mode == 1:
+            self.dist.all_reduce(model)
+            model.mul_(1.0 / self.world)
+            base.copy_(model)
+        else:
+            raise ValueError("unknown sync mode")
+        return model
+
+
+def global_progress_alpha(starting_alpha, words_done_all_ranks, iters, train_words):
+    """alpha schedule of ref :391 on the GLOBAL word count (float32 arithmetic as in the reference)."""
+    a = np.float32(starting_alpha) * (np.float32(1) - np.float32(words_done_all_ranks) /
+                                      np.float32(iters * train_words + 1))
+    floor = np.float32(starting_alpha * 0.0001)
+    return float(max(a, floor))
