@@ -53,9 +53,16 @@ def parse():
     ap.add_argument("--ids", choices=["zipf", "uniform"], default="zipf")
     ap.add_argument("--sync-every", type=int, default=16)
     ap.add_argument("--sync-mode", type=int, default=0)
-    ap.add_argument("--sync-impl", choices=["lib", "torch"], default="lib")
+    ap.add_argument("--sync-impl", choices=["lib", "torch"], default="torch",
+                    help="replica exchange: torch = torch.distributed all_reduce (RCCL) on a zero-copy view of the "
+                         "library's [u||v] buffer (default: the process group the launcher already set up); "
+                         "lib = the library's own RCCL communicator (w2b_comm_init / w2b_sync_replicas, what the "
+                         "CLI uses)")
     ap.add_argument("--cpu-baseline", choices=["reference", "port", "none"], default="reference")
-    ap.add_argument("--cpu-tokens", type=int, default=2_000_000)
+    ap.add_argument("--cpu-tokens", type=int, default=6_000_000)
+    ap.add_argument("--also-relaxed", type=int, default=1,
+                    help="N=1 only: after the headline (coherent) run, time the same steps with relaxed row "
+                         "coherence and report it as an extra object")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--relaxed", type=int, default=0,
                     help="1: plain cached row accesses (not coherent between XCDs); default 0 = agent-scope (sc1)")
@@ -91,7 +98,6 @@ def cpu_baseline_reference(args):
     """Time the UNMODIFIED reference program (training phase only) on this host.
     Corpus per BASELINE.md section 4 / SURVEY Appendix C.8: every vocabulary word 5x (so that
     -min-count 5 keeps V rows), then a Zipf(1) stream; newline every 1000 tokens."""
-    import pty
     import re
     import select
     import subprocess
@@ -119,20 +125,18 @@ def cpu_baseline_reference(args):
     cmd = [exe, "-train", path, "-output", "/dev/null", "-bitlevel", str(args.bitlevel), "-size", str(args.dim),
            "-window", str(args.window), "-negative", str(args.negative), "-iter", "1", "-sample", "0",
            "-binary", "1", "-min-count", "5", "-threads", str(cores)]
-    master, slave = pty.openpty()          # a tty keeps the program's stdout line-buffered
-    p = subprocess.Popen(cmd, stdout=slave, stderr=subprocess.DEVNULL, close_fds=True)
-    os.close(slave)
+    # stdbuf -o0 (LD_PRELOAD libstdbuf) makes the program's stdout unbuffered, so the two marker lines
+    # arrive when they are printed; no pty is needed (the GPU box has none to give)
+    p = subprocess.Popen(["stdbuf", "-o0"] + cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, bufsize=0)
+    fd = p.stdout.fileno()
     t_start = t_end = None
     words = None
     buf = b""
     deadline = time.time() + 600
     while time.time() < deadline:
-        r, _, _ = select.select([master], [], [], 1.0)
+        r, _, _ = select.select([fd], [], [], 1.0)
         if r:
-            try:
-                chunk = os.read(master, 65536)
-            except OSError:
-                chunk = b""
+            chunk = os.read(fd, 65536)
             if not chunk:
                 break
             now = time.time()
@@ -145,11 +149,12 @@ def cpu_baseline_reference(args):
             if t_end is None and b"Epoch Loss:" in buf:
                 t_end = now
                 break
+            if len(buf) > (1 << 20):
+                buf = buf[-4096:]
         elif p.poll() is not None:
             break
     p.kill()                                 # the save loop that follows is not part of the metric
     p.wait()
-    os.close(master)
     try:
         os.remove(path)
         os.rmdir(tmpdir)
@@ -229,17 +234,22 @@ def main():
     from word2bits_amd import replicas
     nw_local = workers if args.form == "worker" else 1
     worker_offset, _ = replicas.worker_plan(nw_local * world, world, rank)   # global Hogwild worker ids
-    t = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=nw_local,
-                    iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words * world,
-                    compute_loss=False, device=local_rank, worker_offset=worker_offset,
-                    total_threads=nw_local * world, relaxed_coherence=bool(args.relaxed))
-    t.init_net()                                  # InitNet values (LCG seed 1), ref :343-361
-    t.set_vocab_counts(counts, 100_000_000)       # 1e8-entry unigram table, ref :112-128
+
+    def make_trainer(relaxed):
+        tr = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=nw_local,
+                         iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words * world,
+                         compute_loss=False, device=local_rank, worker_offset=worker_offset,
+                         total_threads=nw_local * world, relaxed_coherence=relaxed)
+        tr.init_net()                                  # InitNet values (LCG seed 1), ref :343-361
+        tr.set_vocab_counts(counts, 100_000_000)       # 1e8-entry unigram table, ref :112-128
+        return tr
+
+    t = make_trainer(bool(args.relaxed))
     sync_impl = "none (1 GPU)"
     torch_sync = None
     if world > 1:
-        # replicas: the library's own RCCL communicator; if it cannot be set up in this environment the
-        # same protocol runs on torch.distributed (also RCCL) over a zero-copy view of [u||v]
+        # replicas: delta-sum exchange of [u||v] over RCCL, either through the process group that
+        # torch.distributed.run set up (default) or through the library's own communicator
         ok = torch.ones(1, device=dev)
         try:
             if args.sync_impl != "lib":
@@ -288,19 +298,25 @@ def main():
         del table_dev
         words_per_step = B
 
-        def step(i):
+        def prepare(tr):
+            pass
+
+        def step(i, tr=None):
             c, off, ctx, neg = batches[i]
-            t.train_tuples_device(B, c.data_ptr(), off.data_ptr(), ctx.data_ptr(), neg.data_ptr(), 0.05,
-                                  args.grid)
+            (tr or t).train_tuples_device(B, c.data_ptr(), off.data_ptr(), ctx.data_ptr(), neg.data_ptr(), 0.05,
+                                          args.grid)
     else:
-        t.set_corpus_device(stream.data_ptr(), per_rank_tokens)
-        # every rank holds its own stream: local shards are cut inside it
-        t.set_shards(replicas.token_shard_starts(per_rank_tokens, workers, 0, workers))
-        t.epoch_begin()
+        def prepare(tr):
+            tr.set_corpus_device(stream.data_ptr(), per_rank_tokens)
+            # every rank holds its own stream: local shards are cut inside it
+            tr.set_shards(replicas.token_shard_starts(per_rank_tokens, workers, 0, workers))
+            tr.epoch_begin()
+
+        prepare(t)
         words_per_step = workers * args.positions
 
-        def step(i):
-            t.train_step(args.positions)
+        def step(i, tr=None):
+            (tr or t).train_step(args.positions)
 
     torch.cuda.synchronize()
 
@@ -366,7 +382,39 @@ def main():
                      "algorithmic_bytes_per_word": bpw, "avg_launch_ms": avg_launch_s * 1e3,
                      "launches": launches},
     }
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.form)
+    if world == 1 and os.path.exists(pmc) and args.ids == "zipf" and not args.relaxed:
+        try:
+            pj = json.load(open(pmc))
+            if pj.get("words_per_launch") == words_per_step:
+                result["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
+                                                        "passes, FETCH x2 gfx950 correction) on this command" %
+                                                        os.path.basename(pmc))
+                result["roofline"]["algorithmic_bytes_per_launch"] = words_per_step * bpw
+        except Exception:
+            pass
     t.close()
+    if world == 1 and args.also_relaxed and not args.relaxed:
+        # same steps, same data, relaxed row coherence -- reported beside the headline
+        t2 = make_trainer(True)
+        prepare(t2)
+        for i in range(args.warmup):
+            step(i, t2)
+        t2.synchronize()
+        t2.timing_enable(True)
+        t2.timing_read()
+        r0 = time.perf_counter()
+        for i in range(args.warmup, nsteps):
+            step(i, t2)
+        t2.synchronize()
+        rdt = time.perf_counter() - r0
+        rms, rl = t2.timing_read()
+        result["relaxed_coherence"] = {
+            "value": words_per_step * args.steps / rdt, "unit": "words/s", "ms_per_step": rdt / args.steps * 1e3,
+            "roofline_frac": words_per_step * bpw / ((rms / 1e3) / max(1, rl)) / HBM_PEAK,
+            "note": "plain cached row accesses: hot rows are private per XCD L2 within a launch (not the default)"}
+        t2.close()
     if rank == 0:
         cb = None
         if world == 1 and args.cpu_baseline != "none":

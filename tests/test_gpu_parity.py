@@ -217,3 +217,27 @@ def test_full_size_properties_cfg2(gpu):
     q = t.export_quantized()
     assert set(np.unique(q.view(np.uint32)).tolist()) <= {0x3EAAAAAB, 0xBEAAAAAB}
     t.close()
+
+
+def test_model_tensor_view_and_single_rank_sync_noop(gpu):
+    """The zero-copy torch view of [u||v] (used for the torch.distributed replica exchange) aliases the
+    library's buffer; a communicator of size 1 leaves the model bit-identical."""
+    import torch
+    V, D = 500, 64
+    t = w2b.Trainer(V, D, negative=0, num_threads=1)
+    t.init_net()
+    u, v = t.get_model()
+    view = t.model_tensor()
+    assert view.shape == (2 * V * D,) and view.is_cuda
+    flat = view.cpu().numpy()
+    assert np.array_equal(flat[:V * D].reshape(V, D), u) and np.array_equal(flat[V * D:].reshape(V, D), v)
+    view[:D] += 1.0
+    torch.cuda.synchronize()
+    u2, _ = t.get_model()
+    assert np.array_equal(u2[0], u[0] + 1.0)
+    t.comm_init(1, 0, None)
+    t.sync_replicas(0)
+    t.sync_replicas(1)
+    u3, v3 = t.get_model()
+    assert np.array_equal(u3, u2) and np.array_equal(v3, v)
+    t.close()
