@@ -64,6 +64,8 @@ def parse():
                     help="N=1 only: after the headline (coherent) run, time the same steps with relaxed row "
                          "coherence and report it as an extra object")
     ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--window-cache", type=int, default=1,
+                    help="worker form: 1 = sentence-resident kernel (context window rows stay in LDS), 0 = plain")
     ap.add_argument("--relaxed", type=int, default=0,
                     help="1: plain cached row accesses (not coherent between XCDs); default 0 = agent-scope (sc1)")
     return ap.parse_args()
@@ -239,7 +241,8 @@ def main():
         tr = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=nw_local,
                          iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words * world,
                          compute_loss=False, device=local_rank, worker_offset=worker_offset,
-                         total_threads=nw_local * world, relaxed_coherence=relaxed)
+                         total_threads=nw_local * world, relaxed_coherence=relaxed,
+                         window_cache=bool(args.window_cache))
         tr.init_net()                                  # InitNet values (LCG seed 1), ref :343-361
         tr.set_vocab_counts(counts, 100_000_000)       # 1e8-entry unigram table, ref :112-128
         return tr
@@ -378,7 +381,8 @@ def main():
                                     (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
-                     "kernel": "k_train_%s" % ("tuples" if args.form == "tuples" else "workers"),
+                     "kernel": "k_train_%s" % ("tuples" if args.form == "tuples" else
+                                                 ("workers2" if args.window_cache else "workers")),
                      "algorithmic_bytes_per_word": bpw, "avg_launch_ms": avg_launch_s * 1e3,
                      "launches": launches},
     }

@@ -67,7 +67,12 @@ typedef struct w2b_config {
    * accesses -- faster when ids are heavily skewed, but a hot row is then private to an XCD's L2 (or
    * a CU's L1) until it is evicted or the launch ends; see DESIGN.md section 4. */
   int32_t relaxed_coherence;
-  int32_t reserved[4];   /* must be zero */
+  /* form (i) normally runs the sentence-resident kernel: the fp32 rows of the sliding context window
+   * stay in LDS while a worker walks a sentence (a row is read once when it enters the window and
+   * merged back once when it leaves).  1: use the plain kernel that reads/writes every context row of
+   * every position (also used automatically when the window does not fit in LDS). */
+  int32_t plain_worker_kernel;
+  int32_t reserved[3];   /* must be zero */
 } w2b_config;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -42,7 +42,8 @@ def setup(V, ids, D, window, negative, bitlevel, sample, iters, num_threads=1, f
     (0, 1e-3, 200, 8, 24),
     (2, 0.0, 100, 3, 7),
 ])
-def test_single_worker_short_horizon_tight(gpu, bitlevel, sample, D, window, negative):
+@pytest.mark.parametrize("window_cache", [True, False])
+def test_single_worker_short_horizon_tight(gpu, bitlevel, sample, D, window, negative, window_cache):
     """3000 positions over a 5000-word vocabulary: rows are rarely revisited, so the worker form
     (on-device sentence reader / window / negative draws / alpha) must track the oracle closely."""
     V, n = 5000, 3000
@@ -50,7 +51,8 @@ def test_single_worker_short_horizon_tight(gpu, bitlevel, sample, D, window, neg
     ids = token_stream(rng, V, n)
     cn, tw, o = setup(V, ids, D, window, negative, bitlevel, sample, 1)
     _, _, y = setup(V, ids, D, window, negative, bitlevel, sample, 1, fma=True)
-    t = w2b.Trainer(V, D, window, negative, bitlevel, num_threads=1, iter=1, sample=sample, train_words=tw)
+    t = w2b.Trainer(V, D, window, negative, bitlevel, num_threads=1, iter=1, sample=sample, train_words=tw,
+                    window_cache=window_cache)
     t.set_model(o.u, o.v)
     t.set_vocab_counts(cn, 50000)
     t.set_corpus(ids)
@@ -79,7 +81,8 @@ def test_single_worker_short_horizon_tight(gpu, bitlevel, sample, D, window, neg
     (2, 0.0, 100, 8, 24),
     (1, 0.0, 800, 8, 24),
 ])
-def test_single_worker_long_horizon_statistical(gpu, bitlevel, sample, D, window, negative):
+@pytest.mark.parametrize("window_cache", [True, False])
+def test_single_worker_long_horizon_statistical(gpu, bitlevel, sample, D, window, negative, window_cache):
     """2 epochs x 30000 tokens on 150 rows: every row is rewritten thousands of times and quantized
     training is chaotic (two builds of the REFERENCE disagree on 4-25% of the signs here), so only
     the integer bookkeeping is exact; values are held to 'no farther from the bit-reference than
@@ -91,7 +94,7 @@ def test_single_worker_long_horizon_statistical(gpu, bitlevel, sample, D, window
     cn, tw, o = setup(V, ids, D, window, negative, bitlevel, sample, 2)
     _, _, y = setup(V, ids, D, window, negative, bitlevel, sample, 2, fma=True)
     t = w2b.Trainer(V, D, window, negative, bitlevel, num_threads=1, iter=2, alpha=0.05, sample=sample,
-                    train_words=tw, compute_loss=True)
+                    train_words=tw, compute_loss=True, window_cache=window_cache)
     t.set_model(o.u, o.v)
     t.set_vocab_counts(cn, 50000)
     t.set_corpus(ids)
@@ -115,7 +118,8 @@ def test_single_worker_long_horizon_statistical(gpu, bitlevel, sample, D, window
     t.close()
 
 
-def test_shard_override_and_multi_worker_bookkeeping(gpu):
+@pytest.mark.parametrize("window_cache", [True, False])
+def test_shard_override_and_multi_worker_bookkeeping(gpu, window_cache):
     """4 workers (Hogwild): values are racy, but the integer bookkeeping is deterministic."""
     V, n, D = 120, 20000, 32
     rng = np.random.default_rng(2)
@@ -127,7 +131,7 @@ def test_shard_override_and_multi_worker_bookkeeping(gpu):
     o = OracleState(cn, D, window=5, negative=5, bitlevel=1, num_threads=4, iters=1, sample=1e-3,
                     table_size=50000)
     o.m.train_words = tw
-    t = w2b.Trainer(V, D, 5, 5, 1, num_threads=4, iter=1, sample=1e-3, train_words=tw)
+    t = w2b.Trainer(V, D, 5, 5, 1, num_threads=4, iter=1, sample=1e-3, train_words=tw, window_cache=window_cache)
     t.set_model(o.u, o.v)
     t.set_vocab_counts(cn, 50000)
     t.set_corpus(ids)
@@ -140,3 +144,33 @@ def test_shard_override_and_multi_worker_bookkeeping(gpu):
     assert np.isfinite(u).all() and np.isfinite(v).all()
     assert loss == pytest.approx(o_loss, rel=5e-2)            # racy values, same objective
     t.close()
+
+
+@pytest.mark.parametrize("D,window,negative,bitlevel", [(800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0), (96, 1, 2, 1)])
+def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, window, negative, bitlevel):
+    """The LDS-resident window is an optimisation, not a different algorithm: with one worker nobody else
+    touches a resident row, so the exact fp32 value is written back and the whole model must come out
+    BIT-IDENTICAL to the plain kernel (same launches, same dot-product reduction tree)."""
+    V, n = 300, 6000
+    rng = np.random.default_rng(9)
+    ids = token_stream(rng, V, n, line=23)          # short sentences: many window fills/flushes
+    ids[3000:4100] = zipf_ids(rng, V, 1100)          # and one sentence longer than 1000 tokens
+    cn = counts_of(ids, V)
+    tw = int(cn.sum())
+    out = []
+    for wc, pos in ((True, 333), (False, 333), (True, 50)):
+        t = w2b.Trainer(V, D, window, negative, bitlevel, num_threads=1, iter=1, sample=1e-3, train_words=tw,
+                        window_cache=wc)
+        t.init_net()
+        t.set_vocab_counts(cn, 50000)
+        t.set_corpus(ids)
+        t.set_shards(np.zeros(1, np.int64))
+        loss = t.train_epoch(positions_per_launch=pos)
+        u, v = t.get_model()
+        out.append((u, v, loss, t.epoch_status()[1]))
+        t.close()
+    for k in (1, 2):
+        assert out[0][3] == out[k][3]
+        assert np.array_equal(out[0][0].view(np.uint32), out[k][0].view(np.uint32))
+        assert np.array_equal(out[0][1].view(np.uint32), out[k][1].view(np.uint32))
+        assert out[0][2] == pytest.approx(out[k][2], rel=1e-9)

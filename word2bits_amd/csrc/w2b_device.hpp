@@ -108,10 +108,41 @@ __device__ __forceinline__ void store_col(float *tab, long long row, int dim, in
   }
 }
 
+// Wavefront (64-lane) reductions on the DPP cross-lane network: six dependent VALU operations, no LDS
+// round trips (a __shfl_xor ladder is six ds_bpermute latencies).  Steps: swap inside quads, mirror
+// inside half rows / rows of 16, then row_bcast:15 and row_bcast:31 carry the row sums up; lane 63 holds
+// the total and v_readlane returns it to every lane.  Deterministic association order.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+#define W2B_DPP_QUAD_1032 0xB1
+#define W2B_DPP_QUAD_2301 0x4E
+#define W2B_DPP_ROW_HALF_MIRROR 0x141
+#define W2B_DPP_ROW_MIRROR 0x140
+#define W2B_DPP_ROW_BCAST15 0x142
+#define W2B_DPP_ROW_BCAST31 0x143
 __device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-  return x;
+  x += dpp_f<W2B_DPP_QUAD_1032, 0xf>(x);
+  x += dpp_f<W2B_DPP_QUAD_2301, 0xf>(x);
+  x += dpp_f<W2B_DPP_ROW_HALF_MIRROR, 0xf>(x);
+  x += dpp_f<W2B_DPP_ROW_MIRROR, 0xf>(x);
+  x += dpp_f<W2B_DPP_ROW_BCAST15, 0xa>(x);
+  x += dpp_f<W2B_DPP_ROW_BCAST31, 0xc>(x);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ unsigned wave_xor(unsigned x) {
+  x ^= dpp_u<W2B_DPP_QUAD_1032, 0xf>(x);
+  x ^= dpp_u<W2B_DPP_QUAD_2301, 0xf>(x);
+  x ^= dpp_u<W2B_DPP_ROW_HALF_MIRROR, 0xf>(x);
+  x ^= dpp_u<W2B_DPP_ROW_MIRROR, 0xf>(x);
+  x ^= dpp_u<W2B_DPP_ROW_BCAST15, 0xa>(x);
+  x ^= dpp_u<W2B_DPP_ROW_BCAST31, 0xc>(x);
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 __device__ __forceinline__ double wave_sum_d(double x) {
 #pragma unroll
@@ -132,6 +163,7 @@ struct WordLds {
   int *umult;   // [maxc]  multiplicity at the first occurrence of a row, 0 at later duplicates
   int *tgt;     // [maxt]  target rows of v: [0] = centre word (label 1), then kept negatives (label 0)
   int *prev;    // [maxt]  index of the previous occurrence of the same target row, or -1
+  int *cend;    // [maxt]  end index of every target chunk (a chunk is cut at W2B_T rows or at a repeated row)
   float *red;   // [2][W2B_T][W2B_MAXW] cross-wave partial dot products (double buffered)
   float *stash; // [W2B_STASH][blockDim][VEC] raw u columns of the first context rows, private to the
                 // owning thread: phase C updates them without a second trip to memory
@@ -150,11 +182,65 @@ __device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int neg
   L.umult = p; p += maxc;
   L.tgt = p; p += maxt;
   L.prev = p; p += maxt;
+  L.cend = p; p += maxt;
   return L;
 }
 
+
+// ------------------------------------------------------------------------------------ list bookkeeping
+// Executed by ONE wavefront (all 64 lanes, wave-uniform arguments) right after it has written the lists:
+//   prev[i]  = index of the previous occurrence of target row i (-1: none)      -> duplicates serialise
+//   cend[k]  = end of the k-th chunk of at most T targets, cut early at a repeated row
+//   umult[j] = multiplicity of context row j at its first occurrence, 0 at later ones (plain kernel only)
+// Lane-parallel compares on register copies (v_readlane broadcasts) instead of O(n^2) LDS loops.
+template <int T>
+__device__ __forceinline__ void prep_lists(int *tgt, int *prev, int *cend, int nt, int *ctx, int *umult, int cw,
+                                           int lane) {
+  W2B_WAVE_SYNC();
+  for (int i0 = 0; i0 < nt; i0 += 64) {
+    const int i = i0 + lane;
+    const int me = (i < nt) ? tgt[i] : -1;
+    int pd = -1;
+    for (int j = 0; j < min(nt, i0 + 64); j++) {
+      const int tj = (j >= i0) ? __builtin_amdgcn_readlane(me, j - i0) : tgt[j];
+      pd = (j < i && tj == me) ? j : pd;
+    }
+    if (i < nt) prev[i] = pd;
+  }
+  if (umult) {
+    for (int i0 = 0; i0 < cw; i0 += 64) {
+      const int i = i0 + lane;
+      const int me = (i < cw) ? ctx[i] : -1;
+      bool first = true;
+      int mult = 0;
+      for (int j = 0; j < cw; j++) {
+        const int cj = (j >= i0 && j < i0 + 64) ? __builtin_amdgcn_readlane(me, j - i0) : ctx[j];
+        first = first && !(j < i && cj == me);
+        mult += (j >= i && cj == me) ? 1 : 0;
+      }
+      if (i < cw) umult[i] = first ? mult : 0;
+    }
+  }
+  W2B_WAVE_SYNC();
+  int start = 0, k = 0;
+  while (start < nt) {
+    const int lim = min(start + T, nt);
+    int end = lim;
+    for (int i0 = start + 1; i0 < lim; i0 += 64) {
+      const int i = i0 + lane;
+      const bool hit = (i < lim) && (prev[i] >= start);
+      const unsigned long long m = __ballot(hit);
+      if (m) { end = i0 + __ffsll((long long)m) - 1; break; }
+    }
+    if (lane == 0) cend[k] = end;
+    k++;
+    start = end;
+  }
+}
+
 // ------------------------------------------------------------------------------------ one centre word
-// Preconditions: L.ctx[0..cw), L.tgt[0..nt) published by a __syncthreads(); cw >= 1, nt >= 1.
+// Preconditions: L.ctx[0..cw), L.tgt[0..nt) and prep_lists() results published by a __syncthreads();
+// cw >= 1, nt >= 1.
 // Ends with a __syncthreads() (lists may be overwritten afterwards).
 template <int QM, int VEC, bool LOSS, int MM>
 __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &L, const QParam &qp,
@@ -165,37 +251,21 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
   const bool active = col0 < dim;
   const float ar2 = (2.f * alpha) * P.reg;                      // 2*alpha*reg (ref :490,:501)
 
-  // ---- duplicate bookkeeping (tiny, O(n^2) over <= 2*window / negative+1 entries)
-  for (int i = tid; i < nt; i += blockDim.x) {
-    const int me = L.tgt[i];
-    int pd = -1;
-    for (int j = 0; j < i; j++) pd = (L.tgt[j] == me) ? j : pd;
-    L.prev[i] = pd;
-  }
-  for (int i = tid; i < cw; i += blockDim.x) {
-    const int me = L.ctx[i];
-    bool first = true;
-    for (int j = 0; j < i; j++) first = first && (L.ctx[j] != me);
-    int mult = 0;
-    if (first) for (int j = i; j < cw; j++) mult += (L.ctx[j] == me);
-    L.umult[i] = mult;
-  }
-  __syncthreads();
-
-  auto chunk_end = [&](int start) {
-    int end = start + 1;
-    while (end < nt && end - start < W2B_T && L.prev[end] < start) end++;
-    return end;
-  };
-
   Col<VEC> x[W2B_T];
-  int start = 0, end = chunk_end(0);
+  int rows[W2B_T];           // row ids of the chunk, wave-uniform (SGPRs): one LDS read, then v_readlane
+  int start = 0, chunk = 0, end = L.cend[0];
+  auto chunk_rows = [&]() {
+    const int mine = L.tgt[min(start + lane, nt - 1)];
+#pragma unroll
+    for (int i = 0; i < W2B_T; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
+  };
+  chunk_rows();
   // issue the first chunk of target-row loads before the context phase so both gathers overlap
 #pragma unroll
   for (int i = 0; i < W2B_T; i++) {
 #pragma unroll
     for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
-    if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, L.tgt[start + i], dim, col0);
+    if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0);
   }
 
   // ---- phase A: context_avg = (1/cw) * sum_j quantize(u[ctx_j])   (ref :431-449)
@@ -251,11 +321,11 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     }
     float *red = L.red + par * (W2B_T * W2B_MAXW);
 #pragma unroll
-    for (int i = 0; i < W2B_T; i++) {
-      if (i < n) {
-        const float s = wave_sum(p[i]);
-        if (lane == 0) red[i * W2B_MAXW + wave] = s;
-      }
+    for (int i = 0; i < W2B_T; i++) p[i] = wave_sum(p[i]);     // unconditional: W2B_T independent chains interleave
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < W2B_T; i++)
+        if (i < n) red[i * W2B_MAXW + wave] = p[i];
     }
     __syncthreads();
     // lane i of every wavefront: f_i, then g_i (ref :473-475)
@@ -294,21 +364,25 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
         if (active) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) {
-            const float xv = x[i].e[e];
+            float xv = x[i].e[e];
+            // opaque copy: re-derive the quantized value here instead of keeping VEC extra registers per
+            // row alive since the dot product (halves the register footprint of a chunk)
+            if (QM != 0) asm volatile("" : "+v"(xv));
             err.e[e] += g * quant<QM>(xv, qp);
             x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
           }
-          store_col<VEC, MM>(P.v, L.tgt[start + i], dim, col0, x[i]);
+          store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i]);
         }
       }
     }
     start = end;
     if (start >= nt) break;
-    end = chunk_end(start);
+    end = L.cend[++chunk];
     par ^= 1;
+    chunk_rows();
 #pragma unroll
     for (int i = 0; i < W2B_T; i++)
-      if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, L.tgt[start + i], dim, col0);
+      if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0);
   }
 
   // ---- phase C: u[ctx_j] += context_avge - 2*alpha*reg*u[ctx_j]   (ref :494-503)
@@ -342,6 +416,80 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     if (lane == 0) loss_acc -= (double)(P.reg * s);             // ref :437-445 (summed over the window)
   }
   __syncthreads();
+}
+
+
+// ------------------------------------------------------------------------------------ worker helpers
+// exact n % d for a run-time divisor: magic = floor(2^64 / d) precomputed on the host; the quotient
+// estimate is at most 2 too small.  Replaces the ~150-instruction software 64-bit division.
+__device__ __forceinline__ unsigned long long fast_mod(unsigned long long n, unsigned long long d,
+                                                     unsigned long long magic) {
+  if (d <= 1) return 0;
+  const unsigned long long q = __umul64hi(n, magic);
+  unsigned long long r = n - q * d;
+  if (r >= d) r -= d;
+  if (r >= d) r -= d;
+  return r;
+}
+__device__ __forceinline__ unsigned long long lcg_jump(const W2bParams &P, unsigned long long x, int k) {
+  return P.jump_a[k] * x + P.jump_c[k];
+}
+
+// The sentence reader of ref :394-413, executed by wavefront 0 (64 tokens per trip).
+// All scalars are wave-uniform.
+__device__ __forceinline__ void read_sentence(const W2bParams &P, int *s_sen, unsigned long long &rng,
+                                              long long &cursor, long long &wc, int &ovr, int &eof,
+                                              int &len_out, const int lane) {
+  int len = 0;
+  bool stop = false;
+  const bool sub = (P.sample > 0.f);
+  if (ovr != -2) {                       // truncated first word of the shard (mid-word fseek, ref :377)
+    const int w = ovr;
+    ovr = -2;
+    if (w != -1) {
+      wc++;
+      if (w == 0) stop = true;
+      else {
+        bool kept = true;
+        if (sub) {
+          rng = rng * W2B_LCG_A + W2B_LCG_C;
+          kept = !(P.keep[w] < (float)(rng & 0xFFFF) / 65536.f);
+        }
+        if (kept) { if (lane == 0) s_sen[0] = w; len = 1; }
+      }
+    }
+  }
+  while (!stop) {
+    const long long i = cursor + lane;
+    const bool in = i < P.n_tokens;
+    const int tok = in ? P.corpus[i] : 0;
+    const bool isw = in && tok != 0;
+    const unsigned long long mw = __ballot(isw);
+    const unsigned long long lt = lane_lt_mask(lane);
+    bool kept = isw;
+    if (sub && isw) {
+      const unsigned long long x = lcg_jump(P, rng, __popcll(mw & lt) + 1);
+      kept = !(P.keep[tok] < (float)(x & 0xFFFF) / 65536.f);    // ref :403-406
+    }
+    const unsigned long long mk = __ballot(kept);
+    const int kpos = __popcll(mk & lt);
+    const bool lim = kept && (len + kpos + 1 >= W2B_MAX_SEN);    // ref :410
+    const unsigned long long mt = __ballot(!in || (in && tok == 0) || lim);
+    const unsigned long long min_ = __ballot(in);
+    const int e = mt ? (__ffsll((long long)mt) - 1) : 64;
+    const int ncons = e + ((e < 64 && ((min_ >> e) & 1ull)) ? 1 : 0);
+    const unsigned long long cmask = (ncons >= 64) ? ~0ull : ((1ull << ncons) - 1ull);
+    if (kept && lane < ncons) s_sen[len + kpos] = tok;
+    len += __popcll(mk & cmask);
+    wc += ncons;
+    cursor += ncons;
+    if (sub) rng = lcg_jump(P, rng, __popcll(mw & cmask));
+    if (e < 64) {
+      stop = true;
+      if (!((min_ >> e) & 1ull)) eof = 1;
+    }
+  }
+  len_out = len;
 }
 
 

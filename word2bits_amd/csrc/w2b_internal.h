@@ -18,6 +18,7 @@ struct W2bShared {
   double loss_tuples;   // loss sum of the tuple form (form ii)
   int workers_done;
   int pad1;
+  unsigned long long dbg[16];   // phase timers of workgroup 0 (builds with -DW2B_PHASE_TIMERS only)
 };
 
 // Per-worker locals of TrainModelThread (ref src/word2bits.cpp:364-375) that must survive between
@@ -45,6 +46,7 @@ struct W2bParams {
   W2bShared *shared;
   const unsigned long long *jump_a, *jump_c;   // LCG jump-ahead: x_{n+k} = jump_a[k]*x_n + jump_c[k]
   long long vocab_size, train_words, iter;
+  unsigned long long table_magic, window_magic;   // floor(2^64 / table_size), floor(2^64 / window)
   int dim, window, negative, bitlevel, num_threads;
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
   int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
@@ -60,6 +62,9 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
                              float alpha, int grid, int num_cus, int per_cu_override, bool loss,
                              hipStream_t s);
 hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s);
+// sentence-resident variant (w2b_kernels_workers2.hip): radius >= 0 when it can run for this shape
+int w2b_window_radius(int dim, int window, int negative);
+hipError_t w2b_launch_workers2(const W2bParams &p, long long max_positions, int radius, bool loss, hipStream_t s);
 hipError_t w2b_launch_init_net(float *u, float *v, long long n_per_table, const float *lut,
                                hipStream_t s);
 hipError_t w2b_launch_export(const float *u, const float *v, float *out, long long n, int bitlevel,

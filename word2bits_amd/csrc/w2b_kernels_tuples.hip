@@ -12,7 +12,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
                                                       const float alpha) {
   extern __shared__ int smem[];
   const WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
-  int *s_cnt = L.prev + round4(P.negative + 1);   // [0] cw, [1] nt
+  int *s_cnt = L.cend + round4(P.negative + 1);   // [0] cw, [1] nt
   const int tid = threadIdx.x, lane = tid & 63;
   QParam qp;
   qp.bitlevel = P.bitlevel;
@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
         cnt += __popcll(m);
       }
       if (lane == 0) { L.tgt[0] = word; s_cnt[0] = cw; s_cnt[1] = 1 + cnt; }
+      if (cw > 0) prep_lists<W2B_T>(L.tgt, L.prev, L.cend, 1 + cnt, L.ctx, L.umult, cw, lane);
     }
     __syncthreads();
     const int cw = s_cnt[0], nt = s_cnt[1];

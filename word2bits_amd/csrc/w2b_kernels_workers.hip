@@ -5,72 +5,11 @@
 namespace {
 // ------------------------------------------------------------------------------------ form (i): workers
 
-__device__ __forceinline__ unsigned long long lcg_jump(const W2bParams &P, unsigned long long x, int k) {
-  return P.jump_a[k] * x + P.jump_c[k];
-}
-
-// The sentence reader of ref :394-413, executed by wavefront 0 (64 tokens per trip).
-// All scalars are wave-uniform.
-__device__ __forceinline__ void read_sentence(const W2bParams &P, int *s_sen, unsigned long long &rng,
-                                              long long &cursor, long long &wc, int &ovr, int &eof,
-                                              int &len_out, const int lane) {
-  int len = 0;
-  bool stop = false;
-  const bool sub = (P.sample > 0.f);
-  if (ovr != -2) {                       // truncated first word of the shard (mid-word fseek, ref :377)
-    const int w = ovr;
-    ovr = -2;
-    if (w != -1) {
-      wc++;
-      if (w == 0) stop = true;
-      else {
-        bool kept = true;
-        if (sub) {
-          rng = rng * W2B_LCG_A + W2B_LCG_C;
-          kept = !(P.keep[w] < (float)(rng & 0xFFFF) / 65536.f);
-        }
-        if (kept) { if (lane == 0) s_sen[0] = w; len = 1; }
-      }
-    }
-  }
-  while (!stop) {
-    const long long i = cursor + lane;
-    const bool in = i < P.n_tokens;
-    const int tok = in ? P.corpus[i] : 0;
-    const bool isw = in && tok != 0;
-    const unsigned long long mw = __ballot(isw);
-    const unsigned long long lt = lane_lt_mask(lane);
-    bool kept = isw;
-    if (sub && isw) {
-      const unsigned long long x = lcg_jump(P, rng, __popcll(mw & lt) + 1);
-      kept = !(P.keep[tok] < (float)(x & 0xFFFF) / 65536.f);    // ref :403-406
-    }
-    const unsigned long long mk = __ballot(kept);
-    const int kpos = __popcll(mk & lt);
-    const bool lim = kept && (len + kpos + 1 >= W2B_MAX_SEN);    // ref :410
-    const unsigned long long mt = __ballot(!in || (in && tok == 0) || lim);
-    const unsigned long long min_ = __ballot(in);
-    const int e = mt ? (__ffsll((long long)mt) - 1) : 64;
-    const int ncons = e + ((e < 64 && ((min_ >> e) & 1ull)) ? 1 : 0);
-    const unsigned long long cmask = (ncons >= 64) ? ~0ull : ((1ull << ncons) - 1ull);
-    if (kept && lane < ncons) s_sen[len + kpos] = tok;
-    len += __popcll(mk & cmask);
-    wc += ncons;
-    cursor += ncons;
-    if (sub) rng = lcg_jump(P, rng, __popcll(mw & cmask));
-    if (e < 64) {
-      stop = true;
-      if (!((min_ >> e) & 1ull)) eof = 1;
-    }
-  }
-  len_out = len;
-}
-
 template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM>
 __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES : 1)) k_train_workers(const W2bParams P, const long long max_positions) {
   extern __shared__ int smem[];
   const WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
-  int *s_sen = L.prev + round4(P.negative + 1);
+  int *s_sen = L.cend + round4(P.negative + 1);
   WorkerLds *S = reinterpret_cast<WorkerLds *>(s_sen + round4(W2B_MAX_SEN) + 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wid = blockIdx.x;
@@ -153,6 +92,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
           nt = 1 + cnt;
           rng = lcg_jump(P, rng, K);
           alpha = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          prep_lists<W2B_T>(L.tgt, L.prev, L.cend, nt, L.ctx, L.umult, cw, lane);
         }
         sen_pos++;                                                    // ref :505-509
         if (sen_pos >= sen_len) sen_len = 0;

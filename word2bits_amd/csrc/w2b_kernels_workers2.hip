@@ -1,0 +1,811 @@
+// w2b_kernels_workers2.hip -- form (i), SENTENCE-RESIDENT variant of the worker kernel.
+//
+// Consecutive sentence positions share 2*window-1 of their context rows (ref src/word2bits.cpp:431-436
+// walks sen[p-window .. p+window]).  The plain worker kernel (w2b_kernels_workers.hip) reads and writes
+// every context row of every position from/to HBM: 2*cw of the 2*(cw+K+1) row transfers per centre
+// word.  Here a workgroup keeps the fp32 rows of the sliding window [p-R, p+R] RESIDENT IN LDS:
+//   * a row enters the window once (one read) and leaves it once (one read-modify-write), however
+//     many centre words use it in between;  phase A (ref :431-449) and phase C (ref :494-503) become
+//     LDS traffic;
+//   * a word that occurs at several window positions shares ONE slot (reference semantics: a row
+//     that occurs twice is updated twice, in order);
+//   * next to the value every slot keeps the fp16 sum of what this worker added to it.  When the row
+//     leaves the window and nobody else changed it meanwhile (wavefront checksum of the row bits), the
+//     exact fp32 value is stored -- a single worker stays bit-identical to the plain kernel; otherwise
+//     the worker's delta is added to the CURRENT row (merge), so concurrent Hogwild workers do not
+//     erase each other's updates;
+//   * rows are thread-private columns of LDS (a thread only ever touches its own 16 bytes of every
+//     slot): no barriers, no bank conflicts.
+// The radius R is window when the window fits in LDS next to a second workgroup, else window-1 with
+// the two outermost context rows held in registers for the step; otherwise the launcher falls back
+// to the plain kernel.
+#include "w2b_device.hpp"
+
+#include <hip/hip_fp16.h>
+#include <cstdio>
+#include <cstdlib>
+
+// target rows per chunk: all negative+1 = 25 rows of the headline shape in ONE chunk for bitlevel 0/1
+// (two workgroups per CU leave 256 VGPRs per thread); the 2-bit / generic quantizers need more
+// temporaries and use two chunks of 13
+#define W2B_T2MAX 25
+template <int QM> struct T2For { static constexpr int value = (QM <= 1) ? 25 : 13; };
+#define W2B_RCH 4   // window rows moved per trip when many enter/leave at once (sentence boundaries)
+
+namespace {
+
+struct Win2Lds {          // scalars owned by wavefront 0 (extends WorkerLds)
+  WorkerLds w;
+  int clo, chi;           // sentence positions currently resident (empty when chi < clo)
+  int n_ret, n_adm, uc_n, word;
+  int next_row;           // row of the position that enters the window at the NEXT step (-1: unknown / none)
+};
+
+struct Win2 {
+  float *win;             // [S][dim]   current fp32 value of the resident rows
+  __half *dlt;            // [S][dim]   what this worker added since the row entered (fp16)
+  unsigned *csum;         // [S][4]     per-wavefront xor checksum of the row bits at entry
+  float *red;             // [2][W2B_T2MAX][4]
+  int *slot_row, *slot_ref, *pos_slot;          // [S]
+  int *ret_slot, *ret_row, *adm_slot, *adm_row; // [S+2]
+  int *cslot;             // [maxc] slot of every context position; -1-k = k-th register-held row
+  int *uc_row;            // [2]   rows of the (at most two) context positions outside the radius
+  int *tgt, *prev, *cend; // [maxt]
+  int *sen;               // [1000]
+  unsigned long long *ja, *jc;   // [nj] LCG jump-ahead table (copy of P.jump_a / P.jump_c)
+  Win2Lds *S;
+};
+
+__host__ __device__ inline int w2_round4(int x) { return (x + 3) & ~3; }
+
+// LDS bytes of the sentence-resident kernel for radius R
+__host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negative, int R) {
+  const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
+  size_t b = (size_t)S * dim * 4 + (size_t)S * dim * 2;            // win + dlt
+  b = (b + 15) & ~(size_t)15;
+  b += (size_t)S * 4 * 4;                                          // csum
+  b += 2 * W2B_T2MAX * 4 * 4;                                      // red
+  b += (size_t)(3 * w2_round4(S) + 4 * w2_round4(S + 2) + maxc + 4 + 3 * maxt + w2_round4(W2B_MAX_SEN)) * 4;
+  b += sizeof(Win2Lds) + 16;
+  b += (size_t)2 * 8 * (negative + 2 > 66 ? negative + 2 : 66) + 16;   // LCG jump tables
+  return b;
+}
+
+__device__ __forceinline__ Win2 carve_win2(int *base, int dim, int window, int negative, int R) {
+  const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
+  Win2 L;
+  char *p = reinterpret_cast<char *>(base);
+  L.win = reinterpret_cast<float *>(p); p += (size_t)S * dim * 4;
+  L.dlt = reinterpret_cast<__half *>(p); p += (size_t)S * dim * 2;
+  p = reinterpret_cast<char *>((reinterpret_cast<size_t>(p) + 15) & ~(size_t)15);
+  L.csum = reinterpret_cast<unsigned *>(p); p += (size_t)S * 4 * 4;
+  L.red = reinterpret_cast<float *>(p); p += 2 * W2B_T2MAX * 4 * 4;
+  int *q = reinterpret_cast<int *>(p);
+  L.slot_row = q; q += w2_round4(S);
+  L.slot_ref = q; q += w2_round4(S);
+  L.pos_slot = q; q += w2_round4(S);
+  L.ret_slot = q; q += w2_round4(S + 2);
+  L.ret_row = q; q += w2_round4(S + 2);
+  L.adm_slot = q; q += w2_round4(S + 2);
+  L.adm_row = q; q += w2_round4(S + 2);
+  L.cslot = q; q += maxc;
+  L.uc_row = q; q += 4;
+  L.tgt = q; q += maxt;
+  L.prev = q; q += maxt;
+  L.cend = q; q += maxt;
+  L.sen = q; q += w2_round4(W2B_MAX_SEN);
+  L.S = reinterpret_cast<Win2Lds *>((reinterpret_cast<size_t>(q) + 15) & ~(size_t)15);
+  const int nj = negative + 2 > 66 ? negative + 2 : 66;
+  L.ja = reinterpret_cast<unsigned long long *>((reinterpret_cast<size_t>(L.S + 1) + 15) & ~(size_t)15);
+  L.jc = L.ja + nj;
+  return L;
+}
+
+__device__ __forceinline__ unsigned col_bits(const Col<4> &c) {
+  return __float_as_uint(c.e[0]) ^ (__float_as_uint(c.e[1]) * 3u) ^ (__float_as_uint(c.e[2]) * 5u) ^
+         (__float_as_uint(c.e[3]) * 7u);
+}
+
+// 16-byte LDS accesses of a thread's own column (win rows are 16-B aligned: dim % 4 == 0)
+__device__ __forceinline__ Col<4> lds_ld4(const float *p) {
+  const float4 t = *reinterpret_cast<const float4 *>(p);
+  Col<4> c;
+  c.e[0] = t.x; c.e[1] = t.y; c.e[2] = t.z; c.e[3] = t.w;
+  return c;
+}
+__device__ __forceinline__ void lds_st4(float *p, const Col<4> &c) {
+  *reinterpret_cast<float4 *>(p) = make_float4(c.e[0], c.e[1], c.e[2], c.e[3]);
+}
+__device__ __forceinline__ Col<4> lds_ldh4(const __half *p) {      // four fp16 deltas = one 8-byte access
+  const uint2 t = *reinterpret_cast<const uint2 *>(p);
+  const __half2 a = *reinterpret_cast<const __half2 *>(&t.x), b = *reinterpret_cast<const __half2 *>(&t.y);
+  Col<4> c;
+  c.e[0] = __low2float(a); c.e[1] = __high2float(a); c.e[2] = __low2float(b); c.e[3] = __high2float(b);
+  return c;
+}
+__device__ __forceinline__ void lds_sth4(__half *p, const Col<4> &c) {
+  const __half2 a = __floats2half2_rn(c.e[0], c.e[1]), b = __floats2half2_rn(c.e[2], c.e[3]);
+  uint2 t;
+  t.x = *reinterpret_cast<const unsigned *>(&a);
+  t.y = *reinterpret_cast<const unsigned *>(&b);
+  *reinterpret_cast<uint2 *>(p) = t;
+}
+
+// ---- rows leaving the window: store them (exact value when untouched by others, else merge the delta)
+template <int MM>
+__device__ __forceinline__ void window_retire(const W2bParams &P, const Win2 &L, int n_ret, bool active,
+                                              int col0, int lane, int wave) {
+  const int dim = P.dim;
+  for (int i0 = 0; i0 < n_ret; i0 += W2B_RCH) {
+    Col<4> rw[W2B_RCH], rd[W2B_RCH], g[W2B_RCH];
+#pragma unroll
+    for (int i = 0; i < W2B_RCH; i++)
+      if (i0 + i < n_ret) {
+        const int s = L.ret_slot[i0 + i];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { rw[i].e[e] = 0.f; rd[i].e[e] = 0.f; g[i].e[e] = 0.f; }
+        if (active) {
+          rw[i] = lds_ld4(L.win + s * dim + col0);
+          rd[i] = lds_ldh4(L.dlt + s * dim + col0);
+          g[i] = load_col<4, MM>(P.u, L.ret_row[i0 + i], dim, col0);
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < W2B_RCH; i++)
+      if (i0 + i < n_ret) {
+        const int s = L.ret_slot[i0 + i];
+        const unsigned now = wave_xor(active ? col_bits(g[i]) : 0u);
+        const bool untouched = (now == L.csum[s * 4 + wave]);     // wave-uniform
+        if (active) {
+          Col<4> o;
+#pragma unroll
+          for (int e = 0; e < 4; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
+          store_col<4, MM>(P.u, L.ret_row[i0 + i], dim, col0, o);
+        }
+      }
+  }
+}
+
+// ---- rows entering the window
+template <int MM>
+__device__ __forceinline__ void window_admit(const W2bParams &P, const Win2 &L, int n_adm, bool active,
+                                             int col0, int lane, int wave) {
+  const int dim = P.dim;
+  for (int i0 = 0; i0 < n_adm; i0 += W2B_RCH) {
+    Col<4> a[W2B_RCH];
+#pragma unroll
+    for (int i = 0; i < W2B_RCH; i++)
+      if (i0 + i < n_adm) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[i].e[e] = 0.f;
+        if (active) a[i] = load_col<4, MM>(P.u, L.adm_row[i0 + i], dim, col0);
+      }
+#pragma unroll
+    for (int i = 0; i < W2B_RCH; i++)
+      if (i0 + i < n_adm) {
+        const int s = L.adm_slot[i0 + i];
+        const unsigned cs = wave_xor(active ? col_bits(a[i]) : 0u);
+        if (lane == 0) L.csum[s * 4 + wave] = cs;
+        if (active) {
+          Col<4> z;
+#pragma unroll
+          for (int e = 0; e < 4; e++) z.e[e] = 0.f;
+          lds_st4(L.win + s * dim + col0, a[i]);
+          lds_sth4(L.dlt + s * dim + col0, z);
+        }
+      }
+  }
+}
+
+#ifdef W2B_PHASE_TIMERS
+#define W2B_TICK2(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); \
+    atomicAdd(&P.shared->dbg[k], n_ - t2_); t2_ = n_; } } while (0)
+#else
+#define W2B_TICK2(k) do { } while (0)
+#endif
+// ---- write-back of one leaving row: exact value if nobody else changed the row, else merge our delta
+template <int MM>
+__device__ __forceinline__ void retire_finish(const W2bParams &P, int row, unsigned csum_at_entry, const Col<4> &g,
+                                              const Col<4> &rw, const Col<4> &rd, bool active, int col0) {
+  const unsigned now = wave_xor(active ? col_bits(g) : 0u);
+  const bool untouched = (now == csum_at_entry);                          // wave-uniform
+  if (active) {
+    Col<4> o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o.e[e] = untouched ? rw.e[e] : g.e[e] + rd.e[e];
+    store_col<4, MM>(P.u, row, P.dim, col0, o);
+  }
+}
+
+// ---- steady state: at most W2B_RCH rows leave and enter per step: one memory round trip for both
+template <int MM>
+__device__ __forceinline__ void window_exchange(const W2bParams &P, const Win2 &L, int n_ret, int n_adm, bool active,
+                                                int col0, int lane, int wave) {
+  const int dim = P.dim;
+  Col<4> rw[W2B_RCH], rd[W2B_RCH], g[W2B_RCH], a[W2B_RCH];
+#pragma unroll
+  for (int i = 0; i < W2B_RCH; i++) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) { rw[i].e[e] = 0.f; rd[i].e[e] = 0.f; g[i].e[e] = 0.f; a[i].e[e] = 0.f; }
+    if (active && i < n_ret) {
+      const int s = L.ret_slot[i];
+      rw[i] = lds_ld4(L.win + s * dim + col0);
+      rd[i] = lds_ldh4(L.dlt + s * dim + col0);
+      g[i] = load_col<4, MM>(P.u, L.ret_row[i], dim, col0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < W2B_RCH; i++)
+    if (active && i < n_adm) a[i] = load_col<4, MM>(P.u, L.adm_row[i], dim, col0);
+#pragma unroll
+  for (int i = 0; i < W2B_RCH; i++)
+    if (i < n_ret) {
+      const int s = L.ret_slot[i];
+      const unsigned now = wave_xor(active ? col_bits(g[i]) : 0u);
+      const bool untouched = (now == L.csum[s * 4 + wave]);
+      if (active) {
+        Col<4> o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
+        store_col<4, MM>(P.u, L.ret_row[i], dim, col0, o);
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < W2B_RCH; i++)
+    if (i < n_adm) {
+      const int s = L.adm_slot[i];
+      const unsigned cs = wave_xor(active ? col_bits(a[i]) : 0u);
+      if (lane == 0) L.csum[s * 4 + wave] = cs;
+      if (active) {
+        Col<4> z;
+#pragma unroll
+        for (int e = 0; e < 4; e++) z.e[e] = 0.f;
+        lds_st4(L.win + s * dim + col0, a[i]);
+        lds_sth4(L.dlt + s * dim + col0, z);
+      }
+    }
+}
+
+// ---- one centre word on the resident window.  cslot[j] >= 0: LDS slot; -1-k: register-held row k.
+template <int QM, bool LOSS, int MM>
+__device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L, const QParam &qp, const int cw,
+                                              const int nt, const int uc_n, const float alpha, double &loss_acc) {
+  constexpr int VEC = 4;
+  constexpr int W2B_T2 = T2For<QM>::value;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int dim = P.dim, col0 = tid * VEC;
+  const bool active = col0 < dim;
+  const float ar2 = (2.f * alpha) * P.reg;
+
+#ifdef W2B_PHASE_TIMERS
+  unsigned long long t2_ = wall_clock64();
+#endif
+  Col<VEC> x[W2B_T2];
+  int rows[W2B_T2];
+  int start = 0, chunk = 0, end = L.cend[0];
+  auto chunk_rows = [&]() {
+    const int mine = L.tgt[min(start + lane, nt - 1)];
+#pragma unroll
+    for (int i = 0; i < W2B_T2; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
+  };
+  chunk_rows();
+#pragma unroll
+  for (int i = 0; i < W2B_T2; i++) {
+#pragma unroll
+    for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
+    if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0);
+  }
+  // the (at most two) context rows outside the radius live in registers for this step
+  Col<VEC> ur0, ur1;
+#pragma unroll
+  for (int e = 0; e < VEC; e++) { ur0.e[e] = 0.f; ur1.e[e] = 0.f; }
+  if (active && uc_n > 0) ur0 = load_col<VEC, MM>(P.u, L.uc_row[0], dim, col0);
+  if (active && uc_n > 1) ur1 = load_col<VEC, MM>(P.u, L.uc_row[1], dim, col0);
+
+  W2B_TICK2(6);
+  // ---- phase A from LDS (ref :431-449), window order
+  Col<VEC> avg;
+  float regsq = 0.f;
+#pragma unroll
+  for (int e = 0; e < VEC; e++) avg.e[e] = 0.f;
+  if (active) {
+    for (int j = 0; j < cw; j++) {
+      const int s = L.cslot[j];
+      Col<VEC> r;
+      if (s >= 0) {
+        r = lds_ld4(L.win + s * dim + col0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) r.e[e] = (s == -1) ? ur0.e[e] : ur1.e[e];
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        const float q = quant<QM>(r.e[e], qp);
+        avg.e[e] += q;
+        if (LOSS) regsq += q * q;
+      }
+    }
+    const float cwf = (float)cw;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) avg.e[e] = avg.e[e] / cwf;
+  }
+
+  W2B_TICK2(7);
+  // ---- phase B (ref :450-492): identical to process_word, W2B_T2 rows per chunk
+  Col<VEC> err;
+#pragma unroll
+  for (int e = 0; e < VEC; e++) err.e[e] = 0.f;
+  int par = 0;
+  for (;;) {
+    const int n = end - start;
+    float p[W2B_T2], p2[W2B_T2];
+#pragma unroll
+    for (int i = 0; i < W2B_T2; i++) {
+      float s = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; e++) {
+        const float q = quant<QM>(x[i].e[e], qp);
+        s += avg.e[e] * q;
+        if (LOSS) s2 += q * q;
+      }
+      p[i] = active ? s : 0.f;
+      p2[i] = active ? s2 : 0.f;
+    }
+    float *red = L.red + par * (W2B_T2 * 4);
+#pragma unroll
+    for (int i = 0; i < W2B_T2; i++) p[i] = wave_sum(p[i]);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < W2B_T2; i++)
+        if (i < n) red[i * 4 + wave] = p[i];
+    }
+    __syncthreads();
+    float gl = 0.f;
+    if (lane < n) {
+      float f = 0.f;
+      for (int w = 0; w < nwaves; w++) f += red[lane * 4 + w];
+      const float label = (start + lane == 0) ? 1.f : 0.f;
+      float g;
+      if (f > 6.f) g = (label - 1.f) * alpha;
+      else if (f < -6.f) g = label * alpha;
+      else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
+      gl = g;
+      if (LOSS && wave == 0) {
+        const float dp = (label != 0.f) ? f : -f;
+        float sg;
+        if (dp > 6.f) sg = 1.f;
+        else if (dp < -6.f) sg = 1e-9f;
+        else sg = 1.f / (1.f + expf(-dp));
+        loss_acc += (double)logf(sg);
+      }
+    }
+    if (LOSS && P.reg != 0.f) {
+#pragma unroll
+      for (int i = 0; i < W2B_T2; i++)
+        if (i < n) {
+          const float s2 = wave_sum(p2[i]);
+          if (lane == 0) loss_acc -= (double)(P.reg * s2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < W2B_T2; i++) {
+      if (i < n) {
+        const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
+        if (active) {
+#pragma unroll
+          for (int e = 0; e < VEC; e++) {
+            float xv = x[i].e[e];
+            // opaque copy: re-derive the quantized value here instead of keeping VEC extra registers per
+            // row alive since the dot product (halves the register footprint of a chunk)
+            if (QM != 0) asm volatile("" : "+v"(xv));
+            err.e[e] += g * quant<QM>(xv, qp);
+            x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
+          }
+          store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i]);
+        }
+      }
+    }
+    start = end;
+    if (start >= nt) break;
+    end = L.cend[++chunk];
+    par ^= 1;
+    chunk_rows();
+#pragma unroll
+    for (int i = 0; i < W2B_T2; i++)
+      if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0);
+  }
+
+  W2B_TICK2(8);
+  // ---- phase C on the resident rows (ref :494-503), window order; duplicates hit the same slot twice
+  if (active) {
+    for (int j = 0; j < cw; j++) {
+      const int s = L.cslot[j];
+      if (s >= 0) {
+        Col<VEC> w0 = lds_ld4(L.win + s * dim + col0), dl = lds_ldh4(L.dlt + s * dim + col0);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+          const float d = err.e[e] - ar2 * w0.e[e];
+          w0.e[e] = w0.e[e] + d;
+          dl.e[e] = dl.e[e] + d;
+        }
+        lds_st4(L.win + s * dim + col0, w0);
+        lds_sth4(L.dlt + s * dim + col0, dl);
+      } else if (s == -1) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) ur0.e[e] = ur0.e[e] + (err.e[e] - ar2 * ur0.e[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) ur1.e[e] = ur1.e[e] + (err.e[e] - ar2 * ur1.e[e]);
+      }
+    }
+    if (uc_n > 0) store_col<VEC, MM>(P.u, L.uc_row[0], dim, col0, ur0);
+    if (uc_n > 1) store_col<VEC, MM>(P.u, L.uc_row[1], dim, col0, ur1);
+  }
+  W2B_TICK2(9);
+  if (LOSS && P.reg != 0.f) {
+    const float s = wave_sum(regsq);
+    if (lane == 0) loss_acc -= (double)(P.reg * s);
+  }
+  __syncthreads();
+}
+
+// --------------------------------------------------------------------------------------------------
+template <int QM, bool LOSS, int MM>
+__global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, const long long max_positions,
+                                                           const int R) {
+  extern __shared__ int smem[];
+  const Win2 L = carve_win2(smem, P.dim, P.window, P.negative, R);
+  WorkerLds *S = &L.S->w;
+  int *s_sen = L.sen;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wid = blockIdx.x;
+  if (wid >= P.num_threads) return;
+  W2bWorker *G = P.workers + wid;
+  if (G->done) return;
+  QParam qp;
+  qp.bitlevel = P.bitlevel;
+  qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
+  qp.steps_f = (float)qp.steps_i;
+  const int NS = 2 * R + 1;
+  const int col0 = tid * 4;
+  const bool active = col0 < P.dim;
+  for (int i = tid; i < G->sen_len; i += blockDim.x) s_sen[i] = G->sen[i];
+  for (int i = tid; i < NS; i += blockDim.x) { L.slot_row[i] = -1; L.slot_ref[i] = 0; L.pos_slot[i] = 0; }
+  for (int i = tid; i < (P.negative + 2 > 66 ? P.negative + 2 : 66); i += blockDim.x) { L.ja[i] = P.jump_a[i]; L.jc[i] = P.jump_c[i]; }
+  if (tid == 0) {
+    S->rng = G->rng; S->cursor = G->cursor; S->wc = G->word_count; S->last_wc = G->last_word_count;
+    S->sen_len = G->sen_len; S->sen_pos = G->sen_pos; S->override_ = G->first_override;
+    S->eof = 0; S->done = 0; S->cw = 0; S->nt = 0; S->alpha = 0.f;
+    L.S->clo = 0; L.S->chi = -1; L.S->n_ret = 0; L.S->n_adm = 0; L.S->uc_n = 0;
+  }
+  __syncthreads();
+  double loss_acc = 0.0;
+  const int W = P.window, K = P.negative;
+#ifdef W2B_PHASE_TIMERS
+#define W2B_TICK(k) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long n_ = wall_clock64(); \
+    atomicAdd(&P.shared->dbg[k], n_ - tick_); tick_ = n_; } } while (0)
+  unsigned long long tick_ = wall_clock64();
+#else
+#define W2B_TICK(k) do { } while (0)
+#endif
+  // wavefront 0 issues the unigram-table gather and the alpha load of the NEXT step at the end of the
+  // current preparation; their latency then hides behind the data phase of the current step
+  Col<4> apre;                              // row prefetched for the next step's window entry
+#pragma unroll
+  for (int e = 0; e < 4; e++) apre.e[e] = 0.f;
+  int apre_row = -1;
+  int t_pref = 0;
+  bool pref_ok = false;
+  float alpha_pref = P.starting_alpha;
+  bool alpha_pref_ok = false;
+  for (long long it = 0; it <= max_positions; ++it) {
+    const bool last = (it == max_positions);           // extra pass: only empties the window
+    W2B_TICK(0);
+    if (wave == 0) {
+      unsigned long long rng = S->rng;
+      long long cursor = S->cursor, wc = S->wc, last_wc = S->last_wc;
+      int sen_len = S->sen_len, sen_pos = S->sen_pos, ovr = S->override_, eof = S->eof;
+      int done = 0, cw = 0, nt = 0, uc_n = 0;
+      float alpha = 0.f, alpha_own = 0.f;
+      bool new_sentence = false, alpha_set = false;
+      int lo = 0, hi = -1;                               // window wanted for this step (empty = flush)
+      int p = 0, b = 0, word = 0;
+      bool train = false;
+      if (!last) {
+        if (wc - last_wc > 10000) {                                    // ref :379-393
+          if (lane == 0) {
+            const unsigned long long d = (unsigned long long)(wc - last_wc);
+            const unsigned long long wca = atomicAdd(&P.shared->word_count_actual, d) + d;
+            const long long wca_all = (long long)wca * (P.total_threads / P.num_threads);
+            float a = P.starting_alpha * (1.f - (float)wca_all / (float)(P.iter * P.train_words + 1));
+            if ((double)a < (double)P.starting_alpha * 0.0001) a = (float)((double)P.starting_alpha * 0.0001);
+            __hip_atomic_store(&P.shared->alpha, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alpha_own = a;
+          }
+          alpha_own = __shfl(alpha_own, 0, 64);
+          alpha_set = true;                              // this worker's own write is the newest value it may see
+          last_wc = wc;
+        }
+        if (sen_len == 0) {                                            // ref :394-413
+          read_sentence(P, s_sen, rng, cursor, wc, ovr, eof, sen_len, lane);
+          sen_pos = 0;
+          new_sentence = true;
+          W2B_WAVE_SYNC();
+        }
+        if (eof || wc > P.train_words / P.total_threads) {            // ref :414-423
+          if (lane == 0) atomicAdd(&P.shared->word_count_actual, (unsigned long long)(wc - last_wc));
+          last_wc = wc;
+          done = 1;
+        } else {
+          train = true;
+          p = sen_pos;
+          word = (sen_len > 0) ? s_sen[p] : 0;                          // ref :424
+          rng = rng * W2B_LCG_A + W2B_LCG_C;                            // ref :428-429
+          b = (int)fast_mod(rng, (unsigned long long)W, P.window_magic);
+          if (sen_len > 0) { lo = max(0, p - R); hi = min(sen_len - 1, p + R); }
+        }
+      }
+      // ---------------- window bookkeeping: make the resident range [lo, hi]
+      int clo = L.S->clo, chi = L.S->chi, n_ret = 0, n_adm = 0;
+      if (new_sentence || !train) {
+        if (lane < NS) L.slot_ref[lane] = 0;              // every resident position belonged to the old sentence
+        clo = 0; chi = -1;
+        W2B_WAVE_SYNC();
+      } else {
+        for (int q = clo; q <= chi; q++) {                // positions that leave: [clo, lo) and (hi, chi]
+          if (q >= lo && q <= hi) { q = hi; continue; }
+          if (lane == 0) L.slot_ref[L.pos_slot[q % NS]]--;
+          W2B_WAVE_SYNC();
+        }
+      }
+      // Positions entering the window.  Pass 1 re-uses rows that are still resident (also rows of
+      // positions that just left: they are revived instead of being written back and re-read).  Pass 2
+      // gives the remaining words a slot; only then may a leaving row's slot be recycled, so a row that is
+      // wanted again in this very step is never reloaded before its write-back.
+      for (int pass = 0; pass < 2; pass++) {
+        for (int q = lo; q <= hi; q++) {
+          if (q >= clo && q <= chi) { q = chi; continue; }                 // already resident
+          if (pass == 1 && L.pos_slot[q % NS] >= 0) continue;             // resolved in pass 1
+          const int w = s_sen[q];
+          const bool match = (lane < NS) && (L.slot_row[lane] == w);
+          const unsigned long long mm = __ballot(match);
+          int s = -1;
+          if (mm) {                                                       // the word is resident: share its slot
+            s = __ffsll((long long)mm) - 1;
+            if (lane == 0) L.slot_ref[s]++;
+          } else if (pass == 1) {
+            const unsigned long long fr = __ballot((lane < NS) && (L.slot_row[lane] == -1));
+            if (fr) s = __ffsll((long long)fr) - 1;
+            else {                                                         // recycle the slot of a leaving row
+              const unsigned long long pend = __ballot((lane < NS) && (L.slot_ref[lane] == 0));
+              s = __ffsll((long long)pend) - 1;
+              if (lane == 0) { L.ret_slot[n_ret] = s; L.ret_row[n_ret] = L.slot_row[s]; }
+              n_ret++;
+            }
+            if (lane == 0) {
+              L.slot_row[s] = w; L.slot_ref[s] = 1;
+              L.adm_slot[n_adm] = s; L.adm_row[n_adm] = w;
+            }
+            n_adm++;
+          }
+          if (lane == 0) L.pos_slot[q % NS] = s;
+          W2B_WAVE_SYNC();
+        }
+      }
+      {                                                                  // whatever is unreferenced leaves
+        const bool leaving = (lane < NS) && (L.slot_row[lane] != -1) && (L.slot_ref[lane] == 0);
+        const unsigned long long ml = __ballot(leaving);
+        if (leaving) {
+          const int k = n_ret + __popcll(ml & lane_lt_mask(lane));
+          L.ret_slot[k] = lane; L.ret_row[k] = L.slot_row[lane];
+          L.slot_row[lane] = -1;
+        }
+        n_ret += __popcll(ml);
+        W2B_WAVE_SYNC();
+      }
+      if (train) {
+        const int hiA = 2 * W + 1 - b;
+        for (int a0 = b; a0 < hiA; a0 += 64) {                          // ref :431-436
+          const int a = a0 + lane;
+          const int c = p - W + a;
+          const bool ok = (a < hiA) && (a != W) && (c >= 0) && (c < sen_len);
+          const unsigned long long m = __ballot(ok);
+          int slot = 0;
+          if (ok) {
+            if (c >= lo && c <= hi) slot = L.pos_slot[c % NS];
+            else {                                     // outside the radius (|c - p| == window): resident anyway?
+              const int w = s_sen[c];
+              slot = (c < p) ? -1 : -2;                // provisional: register-held row (left / right)
+              for (int s2 = 0; s2 < NS; s2++) slot = (L.slot_row[s2] == w) ? s2 : slot;
+            }
+          }
+          if (ok) L.cslot[cw + __popcll(m & lane_lt_mask(lane))] = slot;
+          cw += __popcll(m);
+        }
+        W2B_WAVE_SYNC();
+        if (cw > 0 && R < W) {
+          // The radius is window-1: the two outermost context positions (only present when b == 0) are
+          // not resident.  They are the first / last entry of the context list; each one that is not
+          // resident through another position becomes a register-held row of this step.
+          const int first = L.cslot[0], lastc = L.cslot[cw - 1];
+          int wl = -1;
+          if (first == -1) { wl = s_sen[p - W]; if (lane == 0) L.uc_row[0] = wl; uc_n = 1; }
+          if (lastc == -2) {
+            const int wr = s_sen[p + W];
+            if (uc_n == 1 && wr == wl) { if (lane == 0) L.cslot[cw - 1] = -1; }       // same word on both ends
+            else {
+              if (lane == 0) { L.uc_row[uc_n] = wr; L.cslot[cw - 1] = -1 - uc_n; }
+              uc_n++;
+            }
+          }
+          W2B_WAVE_SYNC();
+        }
+        if (cw > 0) {                                                    // ref :450-460
+          int cnt = 0;
+          for (int d0 = 1; d0 <= K; d0 += 64) {
+            const int d = d0 + lane;
+            bool keep = false;
+            int t = 0;
+            if (d <= K) {
+              const unsigned long long x = (L.ja[d] * rng + L.jc[d]);
+              t = (pref_ok && d0 == 1) ? t_pref : P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
+              if (t == 0) t = (int)(x % (unsigned long long)(P.vocab_size - 1)) + 1;
+              keep = (t != word);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) L.tgt[1 + cnt + __popcll(m & lane_lt_mask(lane))] = t;
+            cnt += __popcll(m);
+          }
+          if (lane == 0) L.tgt[0] = word;
+          nt = 1 + cnt;
+          rng = (L.ja[K] * rng + L.jc[K]);
+          alpha = alpha_set ? alpha_own
+                            : (alpha_pref_ok ? alpha_pref
+                                             : __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT));
+          prep_lists<T2For<QM>::value>(L.tgt, L.prev, L.cend, nt, nullptr, nullptr, 0, lane);
+        }
+        const int nq = p + 1 + R;                                        // enters the window at the next step
+        if (lane == 0) L.S->next_row = (p + 1 < sen_len && nq < sen_len) ? s_sen[nq] : -1;
+        sen_pos++;                                                       // ref :505-509
+        if (sen_pos >= sen_len) sen_len = 0;
+        // ---- prefetch for the next step (valid unless the next step starts with a sentence read, whose
+        // sub-sampling draws come first in the LCG ledger)
+        pref_ok = (sen_len != 0);
+        if (pref_ok && lane < K) {                                       // lane l serves draw d = l + 1
+          const unsigned long long xb = rng * W2B_LCG_A + W2B_LCG_C;     // the next step's window draw
+          const unsigned long long x = (L.ja[lane + 1] * xb + L.jc[lane + 1]);
+          t_pref = P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
+        }
+        alpha_pref = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        alpha_pref_ok = true;
+      } else {
+        pref_ok = false;
+        if (lane == 0) L.S->next_row = -1;
+      }
+      if (lane == 0) {
+        S->rng = rng; S->cursor = cursor; S->wc = wc; S->last_wc = last_wc;
+        S->sen_len = sen_len; S->sen_pos = sen_pos; S->override_ = ovr; S->eof = eof;
+        S->done = done; S->cw = cw; S->nt = nt; S->alpha = alpha;
+        L.S->clo = lo; L.S->chi = hi; L.S->n_ret = n_ret; L.S->n_adm = n_adm; L.S->uc_n = uc_n;
+      }
+    }
+    W2B_TICK(1);                                        // wave-0 preparation (thread 0 is in wave 0)
+    __syncthreads();
+    W2B_TICK(2);
+    // ---------------- data phase
+    const int n_ret = L.S->n_ret, n_adm = L.S->n_adm;
+    bool deferred = false;                    // steady state: the leaving row is merged back AFTER the step
+    int d_row = -1;
+    unsigned d_csum = 0;
+    Col<4> d_g, d_rw, d_rd;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { d_g.e[e] = 0.f; d_rw.e[e] = 0.f; d_rd.e[e] = 0.f; }
+    if (n_ret <= 1 && n_adm <= 1) {
+      const int uc_n = L.S->uc_n;
+      if (n_ret == 1) {
+        const int s = L.ret_slot[0];
+        d_row = L.ret_row[0];
+        d_csum = L.csum[s * 4 + wave];
+        if (active) {
+          d_rw = lds_ld4(L.win + s * P.dim + col0);
+          d_rd = lds_ldh4(L.dlt + s * P.dim + col0);
+          d_g = load_col<4, MM>(P.u, d_row, P.dim, col0);               // consumed after the step: no stall
+        }
+        deferred = true;
+      }
+      if (n_adm == 1) {
+        const int s = L.adm_slot[0], row = L.adm_row[0];
+        Col<4> a = apre;                                                   // loaded during the previous step
+        if (row != apre_row) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) a.e[e] = 0.f;
+          if (active) a = load_col<4, MM>(P.u, row, P.dim, col0);
+        }
+        const unsigned cs = wave_xor(active ? col_bits(a) : 0u);
+        if (lane == 0) L.csum[s * 4 + wave] = cs;
+        if (active) {
+          Col<4> z;
+#pragma unroll
+          for (int e = 0; e < 4; e++) z.e[e] = 0.f;
+          lds_st4(L.win + s * P.dim + col0, a);
+          lds_sth4(L.dlt + s * P.dim + col0, z);
+        }
+      }
+      // a register-held outer row of this step that is the row leaving right now must see the merge
+      if (deferred && ((uc_n > 0 && L.uc_row[0] == d_row) || (uc_n > 1 && L.uc_row[1] == d_row))) {
+        retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
+        deferred = false;
+      }
+      // prefetch the row that enters at the next step (not the one whose write-back is still pending)
+      const int nr = L.S->next_row;
+      const bool is_uc = (uc_n > 0 && L.uc_row[0] == nr) || (uc_n > 1 && L.uc_row[1] == nr);   // stored at the end of this step
+      apre_row = (nr >= 0 && !(deferred && nr == d_row) && !is_uc) ? nr : -1;
+      if (apre_row >= 0 && active) apre = load_col<4, MM>(P.u, apre_row, P.dim, col0);
+    } else {
+      if (n_ret <= W2B_RCH && n_adm <= W2B_RCH) {
+        window_exchange<MM>(P, L, n_ret, n_adm, active, col0, lane, wave);
+      } else {
+        if (n_ret) window_retire<MM>(P, L, n_ret, active, col0, lane, wave);
+        if (n_adm) window_admit<MM>(P, L, n_adm, active, col0, lane, wave);
+      }
+      apre_row = -1;
+    }
+    W2B_TICK(4);
+    if (S->done || last) {
+      if (deferred) retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
+      break;
+    }
+    const int cw = S->cw, nt = S->nt;
+    if (cw > 0) process_word2<QM, LOSS, MM>(P, L, qp, cw, nt, L.S->uc_n, S->alpha, loss_acc);
+    else __syncthreads();
+    if (deferred) retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
+    W2B_TICK(5);
+  }
+  __syncthreads();
+  const int sl = S->sen_len;
+  for (int i = tid; i < sl; i += blockDim.x) G->sen[i] = s_sen[i];
+  double lsum = 0.0;
+  if (LOSS) {
+    if (wave == 0) lsum = wave_sum_d(loss_acc);
+    else if (lane == 0 && loss_acc != 0.0) atomicAdd(&G->loss, loss_acc);
+  }
+  if (tid == 0) {
+    G->rng = S->rng; G->cursor = S->cursor; G->word_count = S->wc; G->last_word_count = S->last_wc;
+    G->sen_len = S->sen_len; G->sen_pos = S->sen_pos; G->first_override = S->override_;
+    if (LOSS) atomicAdd(&G->loss, lsum);
+    if (S->done) { G->done = 1; atomicAdd(&P.shared->workers_done, 1); }
+  }
+}
+
+}  // namespace
+
+// Radius for which the sentence-resident kernel can run with two workgroups per CU (-1: use the plain kernel)
+int w2b_window_radius(int dim, int window, int negative) {
+  if (dim % 4 != 0 || dim > 1024) return -1;
+  const size_t budget = 80 * 1024;                 // two workgroups per 160 KiB CU
+  if (win2_lds_bytes(dim, window, negative, window) <= budget) return window;
+  if (window >= 2 && win2_lds_bytes(dim, window, negative, window - 1) <= budget) return window - 1;
+  return -1;
+}
+
+hipError_t w2b_launch_workers2(const W2bParams &p, long long max_positions, int R, bool loss, hipStream_t s) {
+  const int threads = 256;
+  const size_t lds = win2_lds_bytes(p.dim, p.window, p.negative, R);
+  static bool reported = false;
+  if (!reported && getenv("W2B_DEBUG")) {
+    reported = true;
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<1, false, 0>, threads, lds);
+    fprintf(stderr, "w2b debug: sentence-resident kernel R=%d lds=%zu B, resident workgroups/CU=%d\n", R, lds, nb);
+  }
+  return dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
+    constexpr int MM = decltype(mm)::value;
+    return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
+      constexpr int QM = decltype(qm)::value;
+      if (loss) hipLaunchKernelGGL((k_train_workers2<QM, true, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R);
+      else hipLaunchKernelGGL((k_train_workers2<QM, false, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R);
+      return hipGetLastError();
+    });
+  });
+}

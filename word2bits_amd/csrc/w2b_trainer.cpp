@@ -146,6 +146,8 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.shared = t->shared;
   p.jump_a = t->jump_a;
   p.jump_c = t->jump_c;
+  p.table_magic = t->table_size > 1 ? (unsigned long long)((((unsigned __int128)1) << 64) / (unsigned __int128)t->table_size) : 0;
+  p.window_magic = t->cfg.window > 1 ? (unsigned long long)((((unsigned __int128)1) << 64) / (unsigned __int128)t->cfg.window) : 0;
   p.vocab_size = t->cfg.vocab_size;
   p.train_words = t->cfg.train_words;
   p.iter = t->cfg.iter;
@@ -230,6 +232,14 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   (void)hipStreamSynchronize(t->stream);
+  if (getenv("W2B_DEBUG")) {
+    W2bShared sh;
+    if (hipMemcpy(&sh, t->shared, sizeof sh, hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(stderr, "w2b debug: phase ticks (100 MHz wall clock) of workgroup 0:");
+      for (int k = 0; k < 12; k++) fprintf(stderr, " [%d]=%llu", k, sh.dbg[k]);
+      fprintf(stderr, "\n");
+    }
+  }
   if (t->comm) ncclCommDestroy(t->comm);
   for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : t->ev_pool) (void)hipEventDestroy(e);
@@ -467,8 +477,11 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_train_step: corpus/shards not set");
   if (max_positions <= 0) return fail(W2B_EINVAL, "w2b_train_step: max_positions must be positive");
   const W2bParams p = make_params(t);
+  int radius = t->cfg.plain_worker_kernel ? -1 : w2b_window_radius(p.dim, p.window, p.negative);
+  if (const char *e = getenv("W2B_WORKER_KERNEL")) { if (atoi(e) == 1) radius = -1; }
   HIPCHK(timing_begin(t));
-  HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
+  if (radius >= 0) HIPCHK(w2b_launch_workers2(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream));
+  else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));
   return W2B_OK;
 }

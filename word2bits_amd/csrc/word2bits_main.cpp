@@ -33,6 +33,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   long long positions = 4096;          // sentence positions per worker per launch
   long long table_size = W2B_UNIGRAM_TABLE_SIZE;
   int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
+  int window_cache = 1;                // 0: plain worker kernel (no sentence-resident window in LDS)
 };
 
 // ArgPos, ref :579-589: exact-match search; a flag in last position has no value -> exit(1)
@@ -108,6 +109,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-positions", argc, argv)) > 0) o.positions = atoll(argv[i + 1]);
   if ((i = arg_pos("-table-size", argc, argv)) > 0) o.table_size = atoll(argv[i + 1]);
   if ((i = arg_pos("-relaxed", argc, argv)) > 0) o.relaxed = atoi(argv[i + 1]);
+  if ((i = arg_pos("-window-cache", argc, argv)) > 0) o.window_cache = atoi(argv[i + 1]);
 
   // ---- TrainModel, ref :518-577
   printf("Starting training using file %s\n", o.train_file.c_str());
@@ -174,6 +176,7 @@ int main(int argc, char **argv) {
     cfg.device = o.device + a->r->index;
     cfg.worker_offset = a->r->index * a->per_gpu;             // worker_offset: global id of local worker 0
     cfg.relaxed_coherence = o.relaxed;
+    cfg.plain_worker_kernel = !o.window_cache;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
     CK(w2b_init_net(a->r->t));                              // ref :528
