@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--form", choices=["tuples", "worker"], default="tuples")
+    ap.add_argument("--form", choices=["tuples", "worker"], default="worker")
     ap.add_argument("--vocab", type=int, default=400_000)
     ap.add_argument("--dim", type=int, default=800)
     ap.add_argument("--window", type=int, default=8)
@@ -48,8 +48,10 @@ def parse():
     ap.add_argument("--bitlevel", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=100_000_000)
     ap.add_argument("--batch", type=int, default=1 << 20, help="centre words per step (tuples form)")
-    ap.add_argument("--workers", type=int, default=0, help="Hogwild workers (worker form); 0 = 4 per CU")
-    ap.add_argument("--positions", type=int, default=1024, help="positions per worker per step")
+    ap.add_argument("--workers", type=int, default=0,
+                    help="Hogwild workers (worker form); 0 = exactly the workgroups resident on the GPU")
+    ap.add_argument("--positions", type=int, default=0,
+                    help="sentence positions per worker per step (0: --batch / workers)")
     ap.add_argument("--ids", choices=["zipf", "uniform"], default="zipf")
     ap.add_argument("--sync-every", type=int, default=16)
     ap.add_argument("--sync-mode", type=int, default=0)
@@ -64,8 +66,9 @@ def parse():
                     help="N=1 only: after the headline (coherent) run, time the same steps with relaxed row "
                          "coherence and report it as an extra object")
     ap.add_argument("--grid", type=int, default=0)
-    ap.add_argument("--window-cache", type=int, default=1,
-                    help="worker form: 1 = sentence-resident kernel (context window rows stay in LDS), 0 = plain")
+    ap.add_argument("--window-cache", type=int, default=-1,
+                    help="worker form: -1 = automatic, 1 = sentence-resident kernel (context window rows stay in "
+                         "LDS), 0 = plain kernel")
     ap.add_argument("--relaxed", type=int, default=0,
                     help="1: plain cached row accesses (not coherent between XCDs); default 0 = agent-scope (sc1)")
     return ap.parse_args()
@@ -232,7 +235,13 @@ def main():
 
     props = torch.cuda.get_device_properties(dev)
     ncu = props.multi_processor_count
-    workers = args.workers if args.workers > 0 else 4 * ncu
+    wcache = None if args.window_cache < 0 else bool(args.window_cache)
+    workers = args.workers
+    if workers <= 0:          # ask the library how many workgroups of the worker kernel are resident at once
+        probe = w2b.Trainer(2, D, W, K, args.bitlevel, num_threads=1, device=local_rank,
+                            relaxed_coherence=bool(args.relaxed), window_cache=wcache, compute_loss=False)
+        workers = probe.suggested_threads()
+        probe.close()
     from word2bits_amd import replicas
     nw_local = workers if args.form == "worker" else 1
     worker_offset, _ = replicas.worker_plan(nw_local * world, world, rank)   # global Hogwild worker ids
@@ -242,7 +251,7 @@ def main():
                          iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words * world,
                          compute_loss=False, device=local_rank, worker_offset=worker_offset,
                          total_threads=nw_local * world, relaxed_coherence=relaxed,
-                         window_cache=bool(args.window_cache))
+                         window_cache=wcache)
         tr.init_net()                                  # InitNet values (LCG seed 1), ref :343-361
         tr.set_vocab_counts(counts, 100_000_000)       # 1e8-entry unigram table, ref :112-128
         return tr
@@ -316,10 +325,11 @@ def main():
             tr.epoch_begin()
 
         prepare(t)
-        words_per_step = workers * args.positions
+        positions = args.positions if args.positions > 0 else max(1, args.batch // workers)
+        words_per_step = workers * positions
 
         def step(i, tr=None):
-            (tr or t).train_step(args.positions)
+            (tr or t).train_step(positions)
 
     torch.cuda.synchronize()
 
@@ -381,8 +391,9 @@ def main():
                                     (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
-                     "kernel": "k_train_%s" % ("tuples" if args.form == "tuples" else
-                                                 ("workers2" if args.window_cache else "workers")),
+                     "kernel": "k_train_tuples" if args.form == "tuples" else
+                               ("k_train_workers" if (args.window_cache == 0 or (args.window_cache < 0 and args.relaxed))
+                                else "k_train_workers2"),
                      "algorithmic_bytes_per_word": bpw, "avg_launch_ms": avg_launch_s * 1e3,
                      "launches": launches},
     }
@@ -401,6 +412,13 @@ def main():
     t.close()
     if world == 1 and args.also_relaxed and not args.relaxed:
         # same steps, same data, relaxed row coherence -- reported beside the headline
+        if args.form == "worker":          # relaxed rows run the plain worker kernel with its own residency
+            probe = w2b.Trainer(2, D, W, K, args.bitlevel, num_threads=1, device=local_rank, relaxed_coherence=True,
+                                window_cache=wcache, compute_loss=False)
+            nw_local = workers = probe.suggested_threads() if args.workers <= 0 else workers
+            probe.close()
+            positions = args.positions if args.positions > 0 else max(1, args.batch // workers)
+            words_per_step = workers * positions
         t2 = make_trainer(True)
         prepare(t2)
         for i in range(args.warmup):

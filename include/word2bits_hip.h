@@ -67,10 +67,11 @@ typedef struct w2b_config {
    * accesses -- faster when ids are heavily skewed, but a hot row is then private to an XCD's L2 (or
    * a CU's L1) until it is evicted or the launch ends; see DESIGN.md section 4. */
   int32_t relaxed_coherence;
-  /* form (i) normally runs the sentence-resident kernel: the fp32 rows of the sliding context window
-   * stay in LDS while a worker walks a sentence (a row is read once when it enters the window and
-   * merged back once when it leaves).  1: use the plain kernel that reads/writes every context row of
-   * every position (also used automatically when the window does not fit in LDS). */
+  /* form (i) has two kernels.  Sentence-resident: the fp32 rows of the sliding context window stay in LDS
+   * while a worker walks a sentence (a row is read once when it enters the window and merged back once
+   * when it leaves).  Plain: every context row of every position is read from / written to memory.
+   * 0 = automatic (sentence-resident for coherent rows when the window fits in LDS, plain otherwise),
+   * 1 = plain, 2 = sentence-resident whenever it fits. */
   int32_t plain_worker_kernel;
   int32_t reserved[3];   /* must be zero */
 } w2b_config;
@@ -128,6 +129,10 @@ int w2b_train_step(w2b_trainer *t, int64_t max_positions);
 /* blocks; *finished = 1 when all workers have ended their epoch (pthread_join, ref :536) */
 int w2b_epoch_status(w2b_trainer *t, int32_t *finished, int64_t *word_count_actual, float *alpha,
                      double *loss_sum);
+
+/* Number of Hogwild workers (-threads) that exactly fills this GPU for the configured shape: the workgroups
+ * of the worker kernel that are resident at once.  More workers run in rounds; fewer leave CUs idle. */
+int w2b_suggested_threads(w2b_trainer *t, int32_t *out);
 
 /* ---- form (ii): explicit tuples (benchmark / single-step parity form) ------------------------
  * n centre words; ctx_off[n+1] CSR into ctx[] (context rows of u, ref :431-447);

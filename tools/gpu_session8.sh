@@ -3,7 +3,7 @@ set +e
 export TMPDIR=/tmp
 echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --tb=short -x 2>&1 | grep -E "^E  |^tests/|passed|failed|Error" | cut -c1-260
 B="python bench.py --cpu-baseline none --also-relaxed 0 --tokens 30000000 --steps 8 --warmup 2"
-W2B_LIB=$PWD/word2bits_amd/libword2bits_hip_dbg.so W2B_DEBUG=1 timeout 600 $B --form worker --workers 256 --positions 1024 2>&1 | grep -E "w2b debug" | cut -c1-400
+W2B_LIB=$PWD/word2bits_amd/libword2bits_hip_dbg.so W2B_DEBUG=1 timeout 600 $B --form worker --workers 512 --positions 1024 2>&1 | grep -E "w2b debug" | cut -c1-400
 short() { python -c "
 import json,sys
 for l in sys.stdin:

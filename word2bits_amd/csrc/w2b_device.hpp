@@ -194,8 +194,8 @@ __device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int neg
 //   umult[j] = multiplicity of context row j at its first occurrence, 0 at later ones (plain kernel only)
 // Lane-parallel compares on register copies (v_readlane broadcasts) instead of O(n^2) LDS loops.
 template <int T>
-__device__ __forceinline__ void prep_lists(int *tgt, int *prev, int *cend, int nt, int *ctx, int *umult, int cw,
-                                           int lane) {
+__device__ __forceinline__ int prep_lists(int *tgt, int *prev, int *cend, int nt, int *ctx, int *umult, int cw,
+                                          int lane) {
   W2B_WAVE_SYNC();
   for (int i0 = 0; i0 < nt; i0 += 64) {
     const int i = i0 + lane;
@@ -236,6 +236,7 @@ __device__ __forceinline__ void prep_lists(int *tgt, int *prev, int *cend, int n
     k++;
     start = end;
   }
+  return k;     // number of chunks
 }
 
 // ------------------------------------------------------------------------------------ one centre word

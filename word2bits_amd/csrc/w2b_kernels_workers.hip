@@ -130,6 +130,23 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
 
 }  // namespace
 
+int w2b_workers_per_cu(const W2bParams &p, bool loss) {
+  int vec;
+  const int threads = w2b_block_threads(p.dim, &vec);
+  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, true);
+  int nb = 0;
+  (void)dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
+    constexpr int MM = decltype(mm)::value;
+    return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
+      constexpr int QM = decltype(qm)::value;
+      // (the LOSS / VEC / launch-bound variants share the register budget of their block size)
+      if (threads <= 256) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers<QM, 4, false, 256, MM>, threads, lds);
+      return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers<QM, 4, false, 1024, MM>, threads, lds);
+    });
+  });
+  return nb > 0 ? nb : 1;
+}
+
 hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s) {
   int vec;
   const int threads = w2b_block_threads(p.dim, &vec);

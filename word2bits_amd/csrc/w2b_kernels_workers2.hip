@@ -25,20 +25,28 @@
 #include <cstdio>
 #include <cstdlib>
 
-// target rows per chunk: all negative+1 = 25 rows of the headline shape in ONE chunk for bitlevel 0/1
-// (two workgroups per CU leave 256 VGPRs per thread); the 2-bit / generic quantizers need more
-// temporaries and use two chunks of 13
+// target rows per chunk (negative=24 -> 9 + 9 + 7).  Two 5-wavefront workgroups per CU put up to four
+// wavefronts on one SIMD (the dispatcher does not balance a second workgroup around the first one: at 168
+// VGPRs only ONE workgroup per CU was ever resident), so the kernel is held to 128 VGPRs.
 #define W2B_T2MAX 25
-template <int QM> struct T2For { static constexpr int value = (QM <= 1) ? 25 : 13; };
-#define W2B_RCH 4   // window rows moved per trip when many enter/leave at once (sentence boundaries)
+template <int QM> struct T2For { static constexpr int value = 9; };
+#define W2B_RCH 2   // window rows moved per trip when many enter/leave at once (sentence boundaries)
 
 namespace {
 
-struct Win2Lds {          // scalars owned by wavefront 0 (extends WorkerLds)
+struct Win2Lds {          // scalars owned by the producer wavefront (extends WorkerLds)
   WorkerLds w;
   int clo, chi;           // sentence positions currently resident (empty when chi < clo)
-  int n_ret, n_adm, uc_n, word;
+};
+
+// What the producer wavefront hands to the four data wavefronts for ONE step (double buffered in LDS)
+struct Step2 {
+  int stop;               // 1: this pass only empties the window (epoch finished, or end of the launch)
+  int cw, nt, uc_n, n_ret, n_adm;
   int next_row;           // row of the position that enters the window at the NEXT step (-1: unknown / none)
+  int nck;                // number of target chunks = number of workgroup barriers inside the data phase
+  float alpha;
+  int pad[3];
 };
 
 struct Win2 {
@@ -54,6 +62,7 @@ struct Win2 {
   int *sen;               // [1000]
   unsigned long long *ja, *jc;   // [nj] LCG jump-ahead table (copy of P.jump_a / P.jump_c)
   Win2Lds *S;
+  Step2 *St;              // per-step scalars (this struct exists twice: one per step buffer)
 };
 
 __host__ __device__ inline int w2_round4(int x) { return (x + 3) & ~3; }
@@ -65,13 +74,14 @@ __host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negati
   b = (b + 15) & ~(size_t)15;
   b += (size_t)S * 4 * 4;                                          // csum
   b += 2 * W2B_T2MAX * 4 * 4;                                      // red
-  b += (size_t)(3 * w2_round4(S) + 4 * w2_round4(S + 2) + maxc + 4 + 3 * maxt + w2_round4(W2B_MAX_SEN)) * 4;
+  b += (size_t)(3 * w2_round4(S) + maxt + w2_round4(W2B_MAX_SEN)) * 4;               // slot tables, prev, sen
+  b += 2 * ((size_t)(4 * w2_round4(S + 2) + maxc + 4 + 2 * maxt) * 4 + sizeof(Step2));  // step lists x 2
   b += sizeof(Win2Lds) + 16;
   b += (size_t)2 * 8 * (negative + 2 > 66 ? negative + 2 : 66) + 16;   // LCG jump tables
   return b;
 }
 
-__device__ __forceinline__ Win2 carve_win2(int *base, int dim, int window, int negative, int R) {
+__device__ __forceinline__ Win2 carve_win2(int *base, int dim, int window, int negative, int R, int buf) {
   const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
   Win2 L;
   char *p = reinterpret_cast<char *>(base);
@@ -84,6 +94,10 @@ __device__ __forceinline__ Win2 carve_win2(int *base, int dim, int window, int n
   L.slot_row = q; q += w2_round4(S);
   L.slot_ref = q; q += w2_round4(S);
   L.pos_slot = q; q += w2_round4(S);
+  L.prev = q; q += maxt;
+  L.sen = q; q += w2_round4(W2B_MAX_SEN);
+  const int per_buf = 4 * w2_round4(S + 2) + maxc + 4 + 2 * maxt + (int)(sizeof(Step2) / 4);
+  q += buf * per_buf;                                  // the per-step lists exist twice
   L.ret_slot = q; q += w2_round4(S + 2);
   L.ret_row = q; q += w2_round4(S + 2);
   L.adm_slot = q; q += w2_round4(S + 2);
@@ -91,9 +105,9 @@ __device__ __forceinline__ Win2 carve_win2(int *base, int dim, int window, int n
   L.cslot = q; q += maxc;
   L.uc_row = q; q += 4;
   L.tgt = q; q += maxt;
-  L.prev = q; q += maxt;
   L.cend = q; q += maxt;
-  L.sen = q; q += w2_round4(W2B_MAX_SEN);
+  L.St = reinterpret_cast<Step2 *>(q); q += sizeof(Step2) / 4;
+  q += (1 - buf) * per_buf;
   L.S = reinterpret_cast<Win2Lds *>((reinterpret_cast<size_t>(q) + 15) & ~(size_t)15);
   const int nj = negative + 2 > 66 ? negative + 2 : 66;
   L.ja = reinterpret_cast<unsigned long long *>((reinterpret_cast<size_t>(L.S + 1) + 15) & ~(size_t)15);
@@ -272,7 +286,7 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
                                               const int nt, const int uc_n, const float alpha, double &loss_acc) {
   constexpr int VEC = 4;
   constexpr int W2B_T2 = T2For<QM>::value;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = 4;   // data wavefronts 0..3
   const int dim = P.dim, col0 = tid * VEC;
   const bool active = col0 < dim;
   const float ar2 = (2.f * alpha) * P.reg;
@@ -446,18 +460,26 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
     const float s = wave_sum(regsq);
     if (lane == 0) loss_acc -= (double)(P.reg * s);
   }
-  __syncthreads();
 }
 
 // --------------------------------------------------------------------------------------------------
+// Five wavefronts per worker: wavefronts 0-3 own the embedding columns (data phase); wavefront 4 is the
+// PRODUCER: it walks the sentence, the LCG ledger, the window bookkeeping and the negative draws ONE STEP
+// AHEAD and hands the lists over through a double-buffered LDS record.  The data wavefronts never wait for
+// the scalar work of a step (it was 25-30 % of the step time when wavefront 0 did both).
+// Barrier discipline: every wavefront executes the same s_barrier sequence per step: nck barriers inside
+// the data phase (one per target chunk; the producer executes them after its own work) + one at the end.
 template <int QM, bool LOSS, int MM>
-__global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, const long long max_positions,
+__global__ void __launch_bounds__(320, 4) k_train_workers2(const W2bParams P, const long long max_positions,
                                                            const int R) {
   extern __shared__ int smem[];
-  const Win2 L = carve_win2(smem, P.dim, P.window, P.negative, R);
+  const Win2 L0 = carve_win2(smem, P.dim, P.window, P.negative, R, 0);
+  const Win2 L1 = carve_win2(smem, P.dim, P.window, P.negative, R, 1);
+  const Win2 &L = L0;                                   // everything that is not double buffered
   WorkerLds *S = &L.S->w;
   int *s_sen = L.sen;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = (wave == 4);
   const int wid = blockIdx.x;
   if (wid >= P.num_threads) return;
   W2bWorker *G = P.workers + wid;
@@ -468,7 +490,7 @@ __global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, co
   qp.steps_f = (float)qp.steps_i;
   const int NS = 2 * R + 1;
   const int col0 = tid * 4;
-  const bool active = col0 < P.dim;
+  const bool active = !producer && col0 < P.dim;
   for (int i = tid; i < G->sen_len; i += blockDim.x) s_sen[i] = G->sen[i];
   for (int i = tid; i < NS; i += blockDim.x) { L.slot_row[i] = -1; L.slot_ref[i] = 0; L.pos_slot[i] = 0; }
   for (int i = tid; i < (P.negative + 2 > 66 ? P.negative + 2 : 66); i += blockDim.x) { L.ja[i] = P.jump_a[i]; L.jc[i] = P.jump_c[i]; }
@@ -476,7 +498,7 @@ __global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, co
     S->rng = G->rng; S->cursor = G->cursor; S->wc = G->word_count; S->last_wc = G->last_word_count;
     S->sen_len = G->sen_len; S->sen_pos = G->sen_pos; S->override_ = G->first_override;
     S->eof = 0; S->done = 0; S->cw = 0; S->nt = 0; S->alpha = 0.f;
-    L.S->clo = 0; L.S->chi = -1; L.S->n_ret = 0; L.S->n_adm = 0; L.S->uc_n = 0;
+    L.S->clo = 0; L.S->chi = -1;
   }
   __syncthreads();
   double loss_acc = 0.0;
@@ -484,28 +506,31 @@ __global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, co
 #ifdef W2B_PHASE_TIMERS
 #define W2B_TICK(k) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long n_ = wall_clock64(); \
     atomicAdd(&P.shared->dbg[k], n_ - tick_); tick_ = n_; } } while (0)
+#define W2B_TICKP(k) do { if (blockIdx.x == 0 && tid == 256) { const unsigned long long n_ = wall_clock64(); \
+    atomicAdd(&P.shared->dbg[k], n_ - tick_); tick_ = n_; } } while (0)
   unsigned long long tick_ = wall_clock64();
 #else
 #define W2B_TICK(k) do { } while (0)
+#define W2B_TICKP(k) do { } while (0)
 #endif
-  // wavefront 0 issues the unigram-table gather and the alpha load of the NEXT step at the end of the
-  // current preparation; their latency then hides behind the data phase of the current step
-  Col<4> apre;                              // row prefetched for the next step's window entry
-#pragma unroll
-  for (int e = 0; e < 4; e++) apre.e[e] = 0.f;
-  int apre_row = -1;
+  // producer registers: the unigram-table gather and the alpha load of the NEXT step are issued at the end
+  // of a preparation, so that their latency is not on the producer's critical path either
   int t_pref = 0;
   bool pref_ok = false;
   float alpha_pref = P.starting_alpha;
   bool alpha_pref_ok = false;
-  for (long long it = 0; it <= max_positions; ++it) {
-    const bool last = (it == max_positions);           // extra pass: only empties the window
-    W2B_TICK(0);
-    if (wave == 0) {
+  // data-wavefront registers: the row that enters the window at the next step, loaded one step early
+  Col<4> apre;
+#pragma unroll
+  for (int e = 0; e < 4; e++) apre.e[e] = 0.f;
+  int apre_row = -1;
+
+  // ---- the preparation of one pass (producer wavefront only; all 64 lanes, wave-uniform control flow)
+  auto prepare = [&](const Win2 &O, const bool last) {
       unsigned long long rng = S->rng;
       long long cursor = S->cursor, wc = S->wc, last_wc = S->last_wc;
       int sen_len = S->sen_len, sen_pos = S->sen_pos, ovr = S->override_, eof = S->eof;
-      int done = 0, cw = 0, nt = 0, uc_n = 0;
+      int done = 0, cw = 0, nt = 0, uc_n = 0, nck = 0, next_row = -1;
       float alpha = 0.f, alpha_own = 0.f;
       bool new_sentence = false, alpha_set = false;
       int lo = 0, hi = -1;                               // window wanted for this step (empty = flush)
@@ -579,12 +604,12 @@ __global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, co
             else {                                                         // recycle the slot of a leaving row
               const unsigned long long pend = __ballot((lane < NS) && (L.slot_ref[lane] == 0));
               s = __ffsll((long long)pend) - 1;
-              if (lane == 0) { L.ret_slot[n_ret] = s; L.ret_row[n_ret] = L.slot_row[s]; }
+              if (lane == 0) { O.ret_slot[n_ret] = s; O.ret_row[n_ret] = L.slot_row[s]; }
               n_ret++;
             }
             if (lane == 0) {
               L.slot_row[s] = w; L.slot_ref[s] = 1;
-              L.adm_slot[n_adm] = s; L.adm_row[n_adm] = w;
+              O.adm_slot[n_adm] = s; O.adm_row[n_adm] = w;
             }
             n_adm++;
           }
@@ -597,7 +622,7 @@ __global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, co
         const unsigned long long ml = __ballot(leaving);
         if (leaving) {
           const int k = n_ret + __popcll(ml & lane_lt_mask(lane));
-          L.ret_slot[k] = lane; L.ret_row[k] = L.slot_row[lane];
+          O.ret_slot[k] = lane; O.ret_row[k] = L.slot_row[lane];
           L.slot_row[lane] = -1;
         }
         n_ret += __popcll(ml);
@@ -619,7 +644,7 @@ __global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, co
               for (int s2 = 0; s2 < NS; s2++) slot = (L.slot_row[s2] == w) ? s2 : slot;
             }
           }
-          if (ok) L.cslot[cw + __popcll(m & lane_lt_mask(lane))] = slot;
+          if (ok) O.cslot[cw + __popcll(m & lane_lt_mask(lane))] = slot;
           cw += __popcll(m);
         }
         W2B_WAVE_SYNC();
@@ -627,14 +652,14 @@ __global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, co
           // The radius is window-1: the two outermost context positions (only present when b == 0) are
           // not resident.  They are the first / last entry of the context list; each one that is not
           // resident through another position becomes a register-held row of this step.
-          const int first = L.cslot[0], lastc = L.cslot[cw - 1];
+          const int first = O.cslot[0], lastc = O.cslot[cw - 1];
           int wl = -1;
-          if (first == -1) { wl = s_sen[p - W]; if (lane == 0) L.uc_row[0] = wl; uc_n = 1; }
+          if (first == -1) { wl = s_sen[p - W]; if (lane == 0) O.uc_row[0] = wl; uc_n = 1; }
           if (lastc == -2) {
             const int wr = s_sen[p + W];
-            if (uc_n == 1 && wr == wl) { if (lane == 0) L.cslot[cw - 1] = -1; }       // same word on both ends
+            if (uc_n == 1 && wr == wl) { if (lane == 0) O.cslot[cw - 1] = -1; }       // same word on both ends
             else {
-              if (lane == 0) { L.uc_row[uc_n] = wr; L.cslot[cw - 1] = -1 - uc_n; }
+              if (lane == 0) { O.uc_row[uc_n] = wr; O.cslot[cw - 1] = -1 - uc_n; }
               uc_n++;
             }
           }
@@ -653,20 +678,20 @@ __global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, co
               keep = (t != word);
             }
             const unsigned long long m = __ballot(keep);
-            if (keep) L.tgt[1 + cnt + __popcll(m & lane_lt_mask(lane))] = t;
+            if (keep) O.tgt[1 + cnt + __popcll(m & lane_lt_mask(lane))] = t;
             cnt += __popcll(m);
           }
-          if (lane == 0) L.tgt[0] = word;
+          if (lane == 0) O.tgt[0] = word;
           nt = 1 + cnt;
           rng = (L.ja[K] * rng + L.jc[K]);
           alpha = alpha_set ? alpha_own
                             : (alpha_pref_ok ? alpha_pref
                                              : __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT));
-          prep_lists<T2For<QM>::value>(L.tgt, L.prev, L.cend, nt, nullptr, nullptr, 0, lane);
+          nck = prep_lists<T2For<QM>::value>(O.tgt, L.prev, O.cend, nt, nullptr, nullptr, 0, lane);
         }
         const int nq = p + 1 + R;                                        // enters the window at the next step
-        if (lane == 0) L.S->next_row = (p + 1 < sen_len && nq < sen_len) ? s_sen[nq] : -1;
+        next_row = (p + 1 < sen_len && nq < sen_len) ? s_sen[nq] : -1;
         sen_pos++;                                                       // ref :505-509
         if (sen_pos >= sen_len) sen_len = 0;
         // ---- prefetch for the next step (valid unless the next step starts with a sentence read, whose
@@ -681,88 +706,98 @@ __global__ void __launch_bounds__(256, 2) k_train_workers2(const W2bParams P, co
         alpha_pref_ok = true;
       } else {
         pref_ok = false;
-        if (lane == 0) L.S->next_row = -1;
       }
       if (lane == 0) {
         S->rng = rng; S->cursor = cursor; S->wc = wc; S->last_wc = last_wc;
         S->sen_len = sen_len; S->sen_pos = sen_pos; S->override_ = ovr; S->eof = eof;
-        S->done = done; S->cw = cw; S->nt = nt; S->alpha = alpha;
-        L.S->clo = lo; L.S->chi = hi; L.S->n_ret = n_ret; L.S->n_adm = n_adm; L.S->uc_n = uc_n;
+        L.S->clo = lo; L.S->chi = hi;
+        O.St->stop = (done || last) ? 1 : 0; O.St->cw = cw; O.St->nt = nt; O.St->uc_n = uc_n;
+        O.St->n_ret = n_ret; O.St->n_adm = n_adm; O.St->next_row = next_row; O.St->nck = (cw > 0) ? nck : 0;
+        O.St->alpha = alpha;
+        if (done) S->done = 1;
       }
-    }
-    W2B_TICK(1);                                        // wave-0 preparation (thread 0 is in wave 0)
-    __syncthreads();
-    W2B_TICK(2);
-    // ---------------- data phase
-    const int n_ret = L.S->n_ret, n_adm = L.S->n_adm;
-    bool deferred = false;                    // steady state: the leaving row is merged back AFTER the step
-    int d_row = -1;
-    unsigned d_csum = 0;
-    Col<4> d_g, d_rw, d_rd;
-#pragma unroll
-    for (int e = 0; e < 4; e++) { d_g.e[e] = 0.f; d_rw.e[e] = 0.f; d_rd.e[e] = 0.f; }
-    if (n_ret <= 1 && n_adm <= 1) {
-      const int uc_n = L.S->uc_n;
-      if (n_ret == 1) {
-        const int s = L.ret_slot[0];
-        d_row = L.ret_row[0];
-        d_csum = L.csum[s * 4 + wave];
-        if (active) {
-          d_rw = lds_ld4(L.win + s * P.dim + col0);
-          d_rd = lds_ldh4(L.dlt + s * P.dim + col0);
-          d_g = load_col<4, MM>(P.u, d_row, P.dim, col0);               // consumed after the step: no stall
-        }
-        deferred = true;
-      }
-      if (n_adm == 1) {
-        const int s = L.adm_slot[0], row = L.adm_row[0];
-        Col<4> a = apre;                                                   // loaded during the previous step
-        if (row != apre_row) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) a.e[e] = 0.f;
-          if (active) a = load_col<4, MM>(P.u, row, P.dim, col0);
-        }
-        const unsigned cs = wave_xor(active ? col_bits(a) : 0u);
-        if (lane == 0) L.csum[s * 4 + wave] = cs;
-        if (active) {
-          Col<4> z;
-#pragma unroll
-          for (int e = 0; e < 4; e++) z.e[e] = 0.f;
-          lds_st4(L.win + s * P.dim + col0, a);
-          lds_sth4(L.dlt + s * P.dim + col0, z);
-        }
-      }
-      // a register-held outer row of this step that is the row leaving right now must see the merge
-      if (deferred && ((uc_n > 0 && L.uc_row[0] == d_row) || (uc_n > 1 && L.uc_row[1] == d_row))) {
-        retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
-        deferred = false;
-      }
-      // prefetch the row that enters at the next step (not the one whose write-back is still pending)
-      const int nr = L.S->next_row;
-      const bool is_uc = (uc_n > 0 && L.uc_row[0] == nr) || (uc_n > 1 && L.uc_row[1] == nr);   // stored at the end of this step
-      apre_row = (nr >= 0 && !(deferred && nr == d_row) && !is_uc) ? nr : -1;
-      if (apre_row >= 0 && active) apre = load_col<4, MM>(P.u, apre_row, P.dim, col0);
-    } else {
-      if (n_ret <= W2B_RCH && n_adm <= W2B_RCH) {
-        window_exchange<MM>(P, L, n_ret, n_adm, active, col0, lane, wave);
-      } else {
-        if (n_ret) window_retire<MM>(P, L, n_ret, active, col0, lane, wave);
-        if (n_adm) window_admit<MM>(P, L, n_adm, active, col0, lane, wave);
-      }
-      apre_row = -1;
-    }
-    W2B_TICK(4);
-    if (S->done || last) {
-      if (deferred) retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
-      break;
-    }
-    const int cw = S->cw, nt = S->nt;
-    if (cw > 0) process_word2<QM, LOSS, MM>(P, L, qp, cw, nt, L.S->uc_n, S->alpha, loss_acc);
-    else __syncthreads();
-    if (deferred) retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
-    W2B_TICK(5);
-  }
+  };
+
+  if (producer) prepare(L0, max_positions == 0);
   __syncthreads();
+  for (long long it = 0;; ++it) {
+    const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
+    const bool stop = I.St->stop != 0;
+    const int nck = I.St->nck;
+    if (producer) {
+      W2B_TICKP(10);
+      if (!stop) prepare((it & 1) ? L0 : L1, it + 1 == max_positions);
+      W2B_TICKP(11);
+      for (int i = 0; i < nck; i++) __syncthreads();
+    } else {
+      W2B_TICK(0);
+      // ---------------- data phase
+      const int n_ret = I.St->n_ret, n_adm = I.St->n_adm;
+      bool deferred = false;                    // steady state: the leaving row is merged back AFTER the step
+      int d_row = -1;
+      unsigned d_csum = 0;
+      Col<4> d_g, d_rw, d_rd;
+#pragma unroll
+      for (int e = 0; e < 4; e++) { d_g.e[e] = 0.f; d_rw.e[e] = 0.f; d_rd.e[e] = 0.f; }
+      if (n_ret <= 1 && n_adm <= 1) {
+        const int uc_n = I.St->uc_n;
+        if (n_ret == 1) {
+          const int s = I.ret_slot[0];
+          d_row = I.ret_row[0];
+          d_csum = L.csum[s * 4 + wave];
+          if (active) {
+            d_rw = lds_ld4(L.win + s * P.dim + col0);
+            d_rd = lds_ldh4(L.dlt + s * P.dim + col0);
+            d_g = load_col<4, MM>(P.u, d_row, P.dim, col0);               // consumed after the step: no stall
+          }
+          deferred = true;
+        }
+        if (n_adm == 1) {
+          const int s = I.adm_slot[0], row = I.adm_row[0];
+          Col<4> a = apre;                                                   // loaded during the previous step
+          if (row != apre_row) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) a.e[e] = 0.f;
+            if (active) a = load_col<4, MM>(P.u, row, P.dim, col0);
+          }
+          const unsigned cs = wave_xor(active ? col_bits(a) : 0u);
+          if (lane == 0) L.csum[s * 4 + wave] = cs;
+          if (active) {
+            Col<4> z;
+#pragma unroll
+            for (int e = 0; e < 4; e++) z.e[e] = 0.f;
+            lds_st4(L.win + s * P.dim + col0, a);
+            lds_sth4(L.dlt + s * P.dim + col0, z);
+          }
+        }
+        // a register-held outer row of this step that is the row leaving right now must see the merge
+        if (deferred && ((uc_n > 0 && I.uc_row[0] == d_row) || (uc_n > 1 && I.uc_row[1] == d_row))) {
+          retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
+          deferred = false;
+        }
+        // prefetch the row that enters at the next step (never one whose store is still ahead of us)
+        const int nr = I.St->next_row;
+        const bool is_uc = (uc_n > 0 && I.uc_row[0] == nr) || (uc_n > 1 && I.uc_row[1] == nr);
+        apre_row = (nr >= 0 && !(deferred && nr == d_row) && !is_uc) ? nr : -1;
+        if (apre_row >= 0 && active) apre = load_col<4, MM>(P.u, apre_row, P.dim, col0);
+      } else {
+        if (n_ret <= W2B_RCH && n_adm <= W2B_RCH) {
+          window_exchange<MM>(P, I, n_ret, n_adm, active, col0, lane, wave);
+        } else {
+          if (n_ret) window_retire<MM>(P, I, n_ret, active, col0, lane, wave);
+          if (n_adm) window_admit<MM>(P, I, n_adm, active, col0, lane, wave);
+        }
+        apre_row = -1;
+      }
+      W2B_TICK(4);
+      if (!stop && I.St->cw > 0)
+        process_word2<QM, LOSS, MM>(P, I, qp, I.St->cw, I.St->nt, I.St->uc_n, I.St->alpha, loss_acc);
+      if (deferred) retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
+      W2B_TICK(5);
+    }
+    __syncthreads();                                     // lists of the next step are published; this step is done
+    if (stop) break;
+  }
   const int sl = S->sen_len;
   for (int i = tid; i < sl; i += blockDim.x) G->sen[i] = s_sen[i];
   double lsum = 0.0;
@@ -789,8 +824,24 @@ int w2b_window_radius(int dim, int window, int negative) {
   return -1;
 }
 
+// workgroups of the sentence-resident kernel that are resident per CU (occupancy query of the instantiation
+// that would run)
+int w2b_workers2_per_cu(const W2bParams &p, int R, bool loss) {
+  const size_t lds = win2_lds_bytes(p.dim, p.window, p.negative, R);
+  int nb = 0;
+  (void)dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
+    constexpr int MM = decltype(mm)::value;
+    return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
+      constexpr int QM = decltype(qm)::value;
+      if (loss) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, true, MM>, 320, lds);
+      return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, false, MM>, 320, lds);
+    });
+  });
+  return nb > 0 ? nb : 1;
+}
+
 hipError_t w2b_launch_workers2(const W2bParams &p, long long max_positions, int R, bool loss, hipStream_t s) {
-  const int threads = 256;
+  const int threads = 320;                 // 4 data wavefronts + 1 producer wavefront
   const size_t lds = win2_lds_bytes(p.dim, p.window, p.negative, R);
   static bool reported = false;
   if (!reported && getenv("W2B_DEBUG")) {

@@ -472,13 +472,34 @@ extern "C" int w2b_epoch_begin(w2b_trainer *t) {
   return W2B_OK;
 }
 
+// Which worker kernel runs: plain_worker_kernel 0 = automatic (sentence-resident kernel for coherent rows when
+// the window fits in LDS; plain kernel for relaxed rows, where caching in L2 already absorbs the re-reads and
+// four workgroups per CU win), 1 = plain, 2 = sentence-resident whenever it fits.
+static int worker_radius(const w2b_trainer *t) {
+  int mode = t->cfg.plain_worker_kernel;
+  if (const char *e = getenv("W2B_WORKER_KERNEL")) mode = atoi(e);
+  if (mode == 1) return -1;
+  if (mode == 0 && t->cfg.relaxed_coherence) return -1;
+  return w2b_window_radius(t->cfg.layer1_size, t->cfg.window, t->cfg.negative);
+}
+
+extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
+  NEED(t);
+  if (!out) return fail(W2B_EINVAL, "w2b_suggested_threads: null");
+  const W2bParams p = make_params(t);
+  const int radius = worker_radius(t);
+  const int per_cu = radius >= 0 ? w2b_workers2_per_cu(p, radius, t->cfg.compute_loss != 0)
+                                 : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
+  *out = per_cu * t->num_cus;
+  return W2B_OK;
+}
+
 extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   NEED(t);
   if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_train_step: corpus/shards not set");
   if (max_positions <= 0) return fail(W2B_EINVAL, "w2b_train_step: max_positions must be positive");
   const W2bParams p = make_params(t);
-  int radius = t->cfg.plain_worker_kernel ? -1 : w2b_window_radius(p.dim, p.window, p.negative);
-  if (const char *e = getenv("W2B_WORKER_KERNEL")) { if (atoi(e) == 1) radius = -1; }
+  const int radius = worker_radius(t);
   HIPCHK(timing_begin(t));
   if (radius >= 0) HIPCHK(w2b_launch_workers2(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream));
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));

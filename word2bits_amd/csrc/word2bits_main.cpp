@@ -33,7 +33,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   long long positions = 4096;          // sentence positions per worker per launch
   long long table_size = W2B_UNIGRAM_TABLE_SIZE;
   int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
-  int window_cache = 1;                // 0: plain worker kernel (no sentence-resident window in LDS)
+  int window_cache = -1;               // -1 automatic, 0 plain worker kernel, 1 sentence-resident kernel
 };
 
 // ArgPos, ref :579-589: exact-match search; a flag in last position has no value -> exit(1)
@@ -136,8 +136,20 @@ int main(int argc, char **argv) {
     fprintf(stderr, "word2bits: -gpus %d requested but %d visible\n", o.gpus, ndev);
     return 2;
   }
-  if (o.num_threads < 1) {                                   // GPU extension: -threads 0 = fill the device
-    o.num_threads = 1024 * o.gpus;
+  if (o.num_threads < 1) {                                   // GPU extension: -threads 0 = fill the device(s)
+    w2b_config probe_cfg;
+    memset(&probe_cfg, 0, sizeof probe_cfg);
+    probe_cfg.vocab_size = 2; probe_cfg.layer1_size = (int32_t)o.layer1_size; probe_cfg.window = o.window;
+    probe_cfg.negative = o.negative; probe_cfg.bitlevel = o.bitlevel; probe_cfg.num_threads = 1;
+    probe_cfg.alpha = o.alpha; probe_cfg.compute_loss = 1; probe_cfg.device = o.device;
+    probe_cfg.relaxed_coherence = o.relaxed;
+    probe_cfg.plain_worker_kernel = o.window_cache < 0 ? 0 : (o.window_cache ? 2 : 1);
+    w2b_trainer *probe = nullptr;
+    int32_t per_gpu = 1024;
+    CK(w2b_trainer_create(&probe_cfg, &probe));
+    CK(w2b_suggested_threads(probe, &per_gpu));               // workgroups resident at once on one GPU
+    w2b_trainer_destroy(probe);
+    o.num_threads = per_gpu * o.gpus;
     if (o.debug_mode > 0) printf("Hogwild workers (workgroups): %d\n", o.num_threads);
   }
   if (o.gpus > 1 && o.num_threads % o.gpus != 0) {
@@ -176,7 +188,7 @@ int main(int argc, char **argv) {
     cfg.device = o.device + a->r->index;
     cfg.worker_offset = a->r->index * a->per_gpu;             // worker_offset: global id of local worker 0
     cfg.relaxed_coherence = o.relaxed;
-    cfg.plain_worker_kernel = !o.window_cache;
+    cfg.plain_worker_kernel = o.window_cache < 0 ? 0 : (o.window_cache ? 2 : 1);
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
     CK(w2b_init_net(a->r->t));                              // ref :528

@@ -86,7 +86,7 @@ class Trainer:
 
     def __init__(self, vocab_size, layer1_size=100, window=5, negative=5, bitlevel=1, num_threads=12,
                  iter=5, alpha=0.05, sample=1e-3, reg=0.0, train_words=0, compute_loss=True, device=0,
-                 worker_offset=0, total_threads=0, relaxed_coherence=False, window_cache=True):
+                 worker_offset=0, total_threads=0, relaxed_coherence=False, window_cache=None):
         cfg = Config()
         cfg.vocab_size, cfg.train_words, cfg.iter = int(vocab_size), int(train_words), int(iter)
         cfg.layer1_size, cfg.window, cfg.negative = int(layer1_size), int(window), int(negative)
@@ -95,7 +95,8 @@ class Trainer:
         cfg.compute_loss, cfg.device = int(bool(compute_loss)), int(device)
         cfg.worker_offset, cfg.total_threads = int(worker_offset), int(total_threads)
         cfg.relaxed_coherence = int(bool(relaxed_coherence))
-        cfg.plain_worker_kernel = int(not window_cache)
+        # window_cache: None = automatic, True = sentence-resident kernel whenever it fits, False = plain
+        cfg.plain_worker_kernel = 0 if window_cache is None else (2 if window_cache else 1)
         self.cfg = cfg
         self._h = _lib.vp()
         check(lib().w2b_trainer_create(C.byref(cfg), C.byref(self._h)))
@@ -189,6 +190,11 @@ class Trainer:
             if fin:
                 return loss
 
+    def suggested_threads(self):
+        n = C.c_int32(0)
+        check(lib().w2b_suggested_threads(self._h, C.byref(n)))
+        return n.value
+
     # ---- form (ii): tuples
     def train_tuples(self, center, ctx_off, ctx, neg, alpha, serial=False):
         center = np.ascontiguousarray(center, np.int32)
@@ -243,7 +249,7 @@ def comm_unique_id():
 
 def train_model(train_file, output_file, bitlevel=1, size=100, window=5, negative=5, threads=12, iter=5,
                 min_count=5, alpha=0.05, sample=1e-3, reg=0.0, binary=0, table_size=100000000,
-                positions_per_launch=4096, device=0, verbose=False, relaxed_coherence=False, window_cache=True):
+                positions_per_launch=4096, device=0, verbose=False, relaxed_coherence=False, window_cache=None):
     """TrainModel (ref :518-577) on one GPU: vocab, InitNet, unigram table, `iter` epochs, save.
     Returns the list of epoch losses."""
     corpus = Corpus(train_file, min_count)
