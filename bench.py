@@ -329,6 +329,11 @@ def main():
         words_per_step = workers * positions
 
         def step(i, tr=None):
+            # a shard lasts steps_per_epoch steps; after that the workers start their next epoch
+            # (pthread_create of the next iteration, ref :532-535) -- any --steps value is valid
+            steps_per_epoch = max(1, (per_rank_tokens // workers - 1100) // positions)
+            if i > 0 and i % steps_per_epoch == 0:
+                (tr or t).epoch_begin()
             (tr or t).train_step(positions)
 
     torch.cuda.synchronize()
@@ -365,9 +370,6 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    if args.form == "worker":
-        fin, _, _, _ = t.epoch_status(want_loss=False)
-        assert not fin, "workers ran out of corpus inside the timed region: lower --steps/--positions"
 
     total_words = words_per_step * args.steps * world
     value = total_words / dt
