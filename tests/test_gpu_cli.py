@@ -70,3 +70,15 @@ def test_cli_hogwild_many_workers(gpu, tmp_path):
     words, M = read_vectors(out, 1)
     assert len(words) == META["b1_d8"]["vocab_size"] and np.isfinite(M).all()
     assert txt.count("Starting epoch:") == 2 and txt.count("Epoch Loss:") == 2
+
+
+def test_cli_threads_zero_fills_the_gpu(gpu, tmp_path):
+    """-threads 0 (GPU extension): as many Hogwild workers as workgroups fit on the device."""
+    out = str(tmp_path / "o.vec")
+    flags = dict(META["b1_d8"]["flags"])
+    txt = run_cli(out, flags, threads=0)
+    import re
+    m = re.search(r"Hogwild workers \(workgroups\): (\d+)", txt)
+    assert m and int(m.group(1)) >= 256
+    words, M = read_vectors(out, 1)
+    assert np.isfinite(M).all() and len(words) == META["b1_d8"]["vocab_size"]

@@ -242,3 +242,14 @@ def test_model_tensor_view_and_single_rank_sync_noop(gpu):
     u3, v3 = t.get_model()
     assert np.array_equal(u3, u2) and np.array_equal(v3, v)
     t.close()
+
+
+def test_suggested_threads_fills_the_device(gpu):
+    """w2b_suggested_threads = resident workgroups of the worker kernel that would run (per-CU occupancy
+    x CUs): 2 per CU for the sentence-resident kernel at D=800, 4 per CU for the plain one."""
+    ncu = 64          # any CDNA part has a multiple of 64 CUs' worth... keep the check device independent
+    a = w2b.Trainer(2, 800, 8, 24, 1, num_threads=1, compute_loss=False)                          # coherent: resident
+    b = w2b.Trainer(2, 800, 8, 24, 1, num_threads=1, compute_loss=False, relaxed_coherence=True)  # relaxed: plain
+    na, nb = a.suggested_threads(), b.suggested_threads()
+    assert na >= 2 * ncu and nb >= 2 * ncu and nb >= na      # the plain kernel needs less LDS: more workers fit
+    a.close(); b.close()

@@ -80,6 +80,7 @@ template <int MM> struct Aux {
   static constexpr int store = (MM == 1) ? 0 : 16;
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int VEC, int MM>
 __device__ __forceinline__ Col<VEC> load_col(const float *tab, long long row, int dim, int col0) {
   Col<VEC> c;
@@ -89,6 +90,9 @@ __device__ __forceinline__ Col<VEC> load_col(const float *tab, long long row, in
     u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, col0 * 4, 0, Aux<MM>::load);
     c.e[0] = __uint_as_float(t.x); c.e[1 % VEC] = __uint_as_float(t.y);
     c.e[2 % VEC] = __uint_as_float(t.z); c.e[3 % VEC] = __uint_as_float(t.w);
+  } else if (VEC == 2) {
+    u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, col0 * 4, 0, Aux<MM>::load);
+    c.e[0] = __uint_as_float(t.x); c.e[1 % VEC] = __uint_as_float(t.y);
   } else {
     c.e[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, col0 * 4, 0, Aux<MM>::load));
   }
@@ -103,6 +107,10 @@ __device__ __forceinline__ void store_col(float *tab, long long row, int dim, in
     t.x = __float_as_uint(c.e[0]); t.y = __float_as_uint(c.e[1 % VEC]);
     t.z = __float_as_uint(c.e[2 % VEC]); t.w = __float_as_uint(c.e[3 % VEC]);
     __builtin_amdgcn_raw_buffer_store_b128(t, r, col0 * 4, 0, Aux<MM>::store);
+  } else if (VEC == 2) {
+    u32x2 t;
+    t.x = __float_as_uint(c.e[0]); t.y = __float_as_uint(c.e[1 % VEC]);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, col0 * 4, 0, Aux<MM>::store);
   } else {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c.e[0]), r, col0 * 4, 0, Aux<MM>::store);
   }
@@ -310,13 +318,15 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     float p[W2B_T], p2[W2B_T];
 #pragma unroll
     for (int i = 0; i < W2B_T; i++) {
-      float s = 0.f, s2 = 0.f;
+      float t[VEC], s2 = 0.f;
 #pragma unroll
       for (int e = 0; e < VEC; e++) {
         const float q = quant<QM>(x[i].e[e], qp);
-        s += avg.e[e] * q;                                      // ref :466 (re-associated)
+        t[e] = avg.e[e] * q;                                    // ref :466 (re-associated as a binary tree)
         if (LOSS) s2 += q * q;
       }
+      // pairwise: the same tree over the elements as the 8-byte-column kernel (w2b_kernels_workers2.hip)
+      const float s = (VEC == 4) ? (t[0] + t[1 % VEC]) + (t[2 % VEC] + t[3 % VEC]) : ((VEC == 2) ? t[0] + t[1 % VEC] : t[0]);
       p[i] = active ? s : 0.f;
       p2[i] = active ? s2 : 0.f;
     }

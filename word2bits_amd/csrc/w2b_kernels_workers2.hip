@@ -29,7 +29,8 @@
 // wavefronts on one SIMD (the dispatcher does not balance a second workgroup around the first one: at 168
 // VGPRs only ONE workgroup per CU was ever resident), so the kernel is held to 128 VGPRs.
 #define W2B_T2MAX 25
-template <int QM> struct T2For { static constexpr int value = 9; };
+#define W2B_NDWMAX 8   // data wavefronts per worker (stride of the per-wavefront LDS tables)
+template <int VEC> struct T2For { static constexpr int value = (VEC == 2) ? 13 : 9; };
 #define W2B_RCH 2   // window rows moved per trip when many enter/leave at once (sentence boundaries)
 
 namespace {
@@ -72,8 +73,8 @@ __host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negati
   const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
   size_t b = (size_t)S * dim * 4 + (size_t)S * dim * 2;            // win + dlt
   b = (b + 15) & ~(size_t)15;
-  b += (size_t)S * 4 * 4;                                          // csum
-  b += 2 * W2B_T2MAX * 4 * 4;                                      // red
+  b += (size_t)S * W2B_NDWMAX * 4;                                 // csum
+  b += 2 * W2B_T2MAX * W2B_NDWMAX * 4;                             // red
   b += (size_t)(3 * w2_round4(S) + maxt + w2_round4(W2B_MAX_SEN)) * 4;               // slot tables, prev, sen
   b += 2 * ((size_t)(4 * w2_round4(S + 2) + maxc + 4 + 2 * maxt) * 4 + sizeof(Step2));  // step lists x 2
   b += sizeof(Win2Lds) + 16;
@@ -88,8 +89,8 @@ __device__ __forceinline__ Win2 carve_win2(int *base, int dim, int window, int n
   L.win = reinterpret_cast<float *>(p); p += (size_t)S * dim * 4;
   L.dlt = reinterpret_cast<__half *>(p); p += (size_t)S * dim * 2;
   p = reinterpret_cast<char *>((reinterpret_cast<size_t>(p) + 15) & ~(size_t)15);
-  L.csum = reinterpret_cast<unsigned *>(p); p += (size_t)S * 4 * 4;
-  L.red = reinterpret_cast<float *>(p); p += 2 * W2B_T2MAX * 4 * 4;
+  L.csum = reinterpret_cast<unsigned *>(p); p += (size_t)S * W2B_NDWMAX * 4;
+  L.red = reinterpret_cast<float *>(p); p += 2 * W2B_T2MAX * W2B_NDWMAX * 4;
   int *q = reinterpret_cast<int *>(p);
   L.slot_row = q; q += w2_round4(S);
   L.slot_ref = q; q += w2_round4(S);
@@ -115,53 +116,76 @@ __device__ __forceinline__ Win2 carve_win2(int *base, int dim, int window, int n
   return L;
 }
 
-__device__ __forceinline__ unsigned col_bits(const Col<4> &c) {
-  return __float_as_uint(c.e[0]) ^ (__float_as_uint(c.e[1]) * 3u) ^ (__float_as_uint(c.e[2]) * 5u) ^
-         (__float_as_uint(c.e[3]) * 7u);
+template <int VEC>
+__device__ __forceinline__ unsigned col_bits(const Col<VEC> &c) {
+  unsigned h = 0;
+#pragma unroll
+  for (int e = 0; e < VEC; e++) h ^= __float_as_uint(c.e[e]) * (2u * e + 3u);
+  return h;
 }
 
-// 16-byte LDS accesses of a thread's own column (win rows are 16-B aligned: dim % 4 == 0)
-__device__ __forceinline__ Col<4> lds_ld4(const float *p) {
+// LDS accesses of a thread's own column of a window row: VEC floats (8 or 16 bytes) and VEC fp16 deltas
+template <int VEC> __device__ __forceinline__ Col<VEC> lds_ld(const float *p);
+template <> __device__ __forceinline__ Col<4> lds_ld<4>(const float *p) {
   const float4 t = *reinterpret_cast<const float4 *>(p);
   Col<4> c;
   c.e[0] = t.x; c.e[1] = t.y; c.e[2] = t.z; c.e[3] = t.w;
   return c;
 }
-__device__ __forceinline__ void lds_st4(float *p, const Col<4> &c) {
+template <> __device__ __forceinline__ Col<2> lds_ld<2>(const float *p) {
+  const float2 t = *reinterpret_cast<const float2 *>(p);
+  Col<2> c;
+  c.e[0] = t.x; c.e[1] = t.y;
+  return c;
+}
+__device__ __forceinline__ void lds_st(float *p, const Col<4> &c) {
   *reinterpret_cast<float4 *>(p) = make_float4(c.e[0], c.e[1], c.e[2], c.e[3]);
 }
-__device__ __forceinline__ Col<4> lds_ldh4(const __half *p) {      // four fp16 deltas = one 8-byte access
+__device__ __forceinline__ void lds_st(float *p, const Col<2> &c) {
+  *reinterpret_cast<float2 *>(p) = make_float2(c.e[0], c.e[1]);
+}
+template <int VEC> __device__ __forceinline__ Col<VEC> lds_ldh(const __half *p);
+template <> __device__ __forceinline__ Col<4> lds_ldh<4>(const __half *p) {
   const uint2 t = *reinterpret_cast<const uint2 *>(p);
   const __half2 a = *reinterpret_cast<const __half2 *>(&t.x), b = *reinterpret_cast<const __half2 *>(&t.y);
   Col<4> c;
   c.e[0] = __low2float(a); c.e[1] = __high2float(a); c.e[2] = __low2float(b); c.e[3] = __high2float(b);
   return c;
 }
-__device__ __forceinline__ void lds_sth4(__half *p, const Col<4> &c) {
+template <> __device__ __forceinline__ Col<2> lds_ldh<2>(const __half *p) {
+  const __half2 a = *reinterpret_cast<const __half2 *>(p);
+  Col<2> c;
+  c.e[0] = __low2float(a); c.e[1] = __high2float(a);
+  return c;
+}
+__device__ __forceinline__ void lds_sth(__half *p, const Col<4> &c) {
   const __half2 a = __floats2half2_rn(c.e[0], c.e[1]), b = __floats2half2_rn(c.e[2], c.e[3]);
   uint2 t;
   t.x = *reinterpret_cast<const unsigned *>(&a);
   t.y = *reinterpret_cast<const unsigned *>(&b);
   *reinterpret_cast<uint2 *>(p) = t;
 }
+__device__ __forceinline__ void lds_sth(__half *p, const Col<2> &c) {
+  *reinterpret_cast<__half2 *>(p) = __floats2half2_rn(c.e[0], c.e[1]);
+}
 
 // ---- rows leaving the window: store them (exact value when untouched by others, else merge the delta)
-template <int MM>
+template <int VEC, int MM>
 __device__ __forceinline__ void window_retire(const W2bParams &P, const Win2 &L, int n_ret, bool active,
                                               int col0, int lane, int wave) {
   const int dim = P.dim;
   for (int i0 = 0; i0 < n_ret; i0 += W2B_RCH) {
-    Col<4> rw[W2B_RCH], rd[W2B_RCH], g[W2B_RCH];
+    Col<VEC> rw[W2B_RCH], rd[W2B_RCH], g[W2B_RCH];
 #pragma unroll
     for (int i = 0; i < W2B_RCH; i++)
       if (i0 + i < n_ret) {
         const int s = L.ret_slot[i0 + i];
 #pragma unroll
-        for (int e = 0; e < 4; e++) { rw[i].e[e] = 0.f; rd[i].e[e] = 0.f; g[i].e[e] = 0.f; }
+        for (int e = 0; e < VEC; e++) { rw[i].e[e] = 0.f; rd[i].e[e] = 0.f; g[i].e[e] = 0.f; }
         if (active) {
-          rw[i] = lds_ld4(L.win + s * dim + col0);
-          rd[i] = lds_ldh4(L.dlt + s * dim + col0);
-          g[i] = load_col<4, MM>(P.u, L.ret_row[i0 + i], dim, col0);
+          rw[i] = lds_ld<VEC>(L.win + s * dim + col0);
+          rd[i] = lds_ldh<VEC>(L.dlt + s * dim + col0);
+          g[i] = load_col<VEC, MM>(P.u, L.ret_row[i0 + i], dim, col0);
         }
       }
 #pragma unroll
@@ -169,43 +193,43 @@ __device__ __forceinline__ void window_retire(const W2bParams &P, const Win2 &L,
       if (i0 + i < n_ret) {
         const int s = L.ret_slot[i0 + i];
         const unsigned now = wave_xor(active ? col_bits(g[i]) : 0u);
-        const bool untouched = (now == L.csum[s * 4 + wave]);     // wave-uniform
+        const bool untouched = (now == L.csum[s * W2B_NDWMAX + wave]);     // wave-uniform
         if (active) {
-          Col<4> o;
+          Col<VEC> o;
 #pragma unroll
-          for (int e = 0; e < 4; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
-          store_col<4, MM>(P.u, L.ret_row[i0 + i], dim, col0, o);
+          for (int e = 0; e < VEC; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
+          store_col<VEC, MM>(P.u, L.ret_row[i0 + i], dim, col0, o);
         }
       }
   }
 }
 
 // ---- rows entering the window
-template <int MM>
+template <int VEC, int MM>
 __device__ __forceinline__ void window_admit(const W2bParams &P, const Win2 &L, int n_adm, bool active,
                                              int col0, int lane, int wave) {
   const int dim = P.dim;
   for (int i0 = 0; i0 < n_adm; i0 += W2B_RCH) {
-    Col<4> a[W2B_RCH];
+    Col<VEC> a[W2B_RCH];
 #pragma unroll
     for (int i = 0; i < W2B_RCH; i++)
       if (i0 + i < n_adm) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) a[i].e[e] = 0.f;
-        if (active) a[i] = load_col<4, MM>(P.u, L.adm_row[i0 + i], dim, col0);
+        for (int e = 0; e < VEC; e++) a[i].e[e] = 0.f;
+        if (active) a[i] = load_col<VEC, MM>(P.u, L.adm_row[i0 + i], dim, col0);
       }
 #pragma unroll
     for (int i = 0; i < W2B_RCH; i++)
       if (i0 + i < n_adm) {
         const int s = L.adm_slot[i0 + i];
         const unsigned cs = wave_xor(active ? col_bits(a[i]) : 0u);
-        if (lane == 0) L.csum[s * 4 + wave] = cs;
+        if (lane == 0) L.csum[s * W2B_NDWMAX + wave] = cs;
         if (active) {
-          Col<4> z;
+          Col<VEC> z;
 #pragma unroll
-          for (int e = 0; e < 4; e++) z.e[e] = 0.f;
-          lds_st4(L.win + s * dim + col0, a[i]);
-          lds_sth4(L.dlt + s * dim + col0, z);
+          for (int e = 0; e < VEC; e++) z.e[e] = 0.f;
+          lds_st(L.win + s * dim + col0, a[i]);
+          lds_sth(L.dlt + s * dim + col0, z);
         }
       }
   }
@@ -218,50 +242,50 @@ __device__ __forceinline__ void window_admit(const W2bParams &P, const Win2 &L, 
 #define W2B_TICK2(k) do { } while (0)
 #endif
 // ---- write-back of one leaving row: exact value if nobody else changed the row, else merge our delta
-template <int MM>
-__device__ __forceinline__ void retire_finish(const W2bParams &P, int row, unsigned csum_at_entry, const Col<4> &g,
-                                              const Col<4> &rw, const Col<4> &rd, bool active, int col0) {
+template <int VEC, int MM>
+__device__ __forceinline__ void retire_finish(const W2bParams &P, int row, unsigned csum_at_entry, const Col<VEC> &g,
+                                              const Col<VEC> &rw, const Col<VEC> &rd, bool active, int col0) {
   const unsigned now = wave_xor(active ? col_bits(g) : 0u);
   const bool untouched = (now == csum_at_entry);                          // wave-uniform
   if (active) {
-    Col<4> o;
+    Col<VEC> o;
 #pragma unroll
-    for (int e = 0; e < 4; e++) o.e[e] = untouched ? rw.e[e] : g.e[e] + rd.e[e];
-    store_col<4, MM>(P.u, row, P.dim, col0, o);
+    for (int e = 0; e < VEC; e++) o.e[e] = untouched ? rw.e[e] : g.e[e] + rd.e[e];
+    store_col<VEC, MM>(P.u, row, P.dim, col0, o);
   }
 }
 
 // ---- steady state: at most W2B_RCH rows leave and enter per step: one memory round trip for both
-template <int MM>
+template <int VEC, int MM>
 __device__ __forceinline__ void window_exchange(const W2bParams &P, const Win2 &L, int n_ret, int n_adm, bool active,
                                                 int col0, int lane, int wave) {
   const int dim = P.dim;
-  Col<4> rw[W2B_RCH], rd[W2B_RCH], g[W2B_RCH], a[W2B_RCH];
+  Col<VEC> rw[W2B_RCH], rd[W2B_RCH], g[W2B_RCH], a[W2B_RCH];
 #pragma unroll
   for (int i = 0; i < W2B_RCH; i++) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) { rw[i].e[e] = 0.f; rd[i].e[e] = 0.f; g[i].e[e] = 0.f; a[i].e[e] = 0.f; }
+    for (int e = 0; e < VEC; e++) { rw[i].e[e] = 0.f; rd[i].e[e] = 0.f; g[i].e[e] = 0.f; a[i].e[e] = 0.f; }
     if (active && i < n_ret) {
       const int s = L.ret_slot[i];
-      rw[i] = lds_ld4(L.win + s * dim + col0);
-      rd[i] = lds_ldh4(L.dlt + s * dim + col0);
-      g[i] = load_col<4, MM>(P.u, L.ret_row[i], dim, col0);
+      rw[i] = lds_ld<VEC>(L.win + s * dim + col0);
+      rd[i] = lds_ldh<VEC>(L.dlt + s * dim + col0);
+      g[i] = load_col<VEC, MM>(P.u, L.ret_row[i], dim, col0);
     }
   }
 #pragma unroll
   for (int i = 0; i < W2B_RCH; i++)
-    if (active && i < n_adm) a[i] = load_col<4, MM>(P.u, L.adm_row[i], dim, col0);
+    if (active && i < n_adm) a[i] = load_col<VEC, MM>(P.u, L.adm_row[i], dim, col0);
 #pragma unroll
   for (int i = 0; i < W2B_RCH; i++)
     if (i < n_ret) {
       const int s = L.ret_slot[i];
       const unsigned now = wave_xor(active ? col_bits(g[i]) : 0u);
-      const bool untouched = (now == L.csum[s * 4 + wave]);
+      const bool untouched = (now == L.csum[s * W2B_NDWMAX + wave]);
       if (active) {
-        Col<4> o;
+        Col<VEC> o;
 #pragma unroll
-        for (int e = 0; e < 4; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
-        store_col<4, MM>(P.u, L.ret_row[i], dim, col0, o);
+        for (int e = 0; e < VEC; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
+        store_col<VEC, MM>(P.u, L.ret_row[i], dim, col0, o);
       }
     }
 #pragma unroll
@@ -269,24 +293,24 @@ __device__ __forceinline__ void window_exchange(const W2bParams &P, const Win2 &
     if (i < n_adm) {
       const int s = L.adm_slot[i];
       const unsigned cs = wave_xor(active ? col_bits(a[i]) : 0u);
-      if (lane == 0) L.csum[s * 4 + wave] = cs;
+      if (lane == 0) L.csum[s * W2B_NDWMAX + wave] = cs;
       if (active) {
-        Col<4> z;
+        Col<VEC> z;
 #pragma unroll
-        for (int e = 0; e < 4; e++) z.e[e] = 0.f;
-        lds_st4(L.win + s * dim + col0, a[i]);
-        lds_sth4(L.dlt + s * dim + col0, z);
+        for (int e = 0; e < VEC; e++) z.e[e] = 0.f;
+        lds_st(L.win + s * dim + col0, a[i]);
+        lds_sth(L.dlt + s * dim + col0, z);
       }
     }
 }
 
 // ---- one centre word on the resident window.  cslot[j] >= 0: LDS slot; -1-k: register-held row k.
-template <int QM, bool LOSS, int MM>
-__device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L, const QParam &qp, const int cw,
+template <int QM, int VEC, bool LOSS, int MM>
+__device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L, const QParam &qp, const int ndw,
+                                              const int cw,
                                               const int nt, const int uc_n, const float alpha, double &loss_acc) {
-  constexpr int VEC = 4;
-  constexpr int W2B_T2 = T2For<QM>::value;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = 4;   // data wavefronts 0..3
+  constexpr int W2B_T2 = T2For<VEC>::value;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = ndw;   // data wavefronts 0..ndw-1
   const int dim = P.dim, col0 = tid * VEC;
   const bool active = col0 < dim;
   const float ar2 = (2.f * alpha) * P.reg;
@@ -327,7 +351,7 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
       const int s = L.cslot[j];
       Col<VEC> r;
       if (s >= 0) {
-        r = lds_ld4(L.win + s * dim + col0);
+        r = lds_ld<VEC>(L.win + s * dim + col0);
       } else {
 #pragma unroll
         for (int e = 0; e < VEC; e++) r.e[e] = (s == -1) ? ur0.e[e] : ur1.e[e];
@@ -355,29 +379,33 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
     float p[W2B_T2], p2[W2B_T2];
 #pragma unroll
     for (int i = 0; i < W2B_T2; i++) {
-      float s = 0.f, s2 = 0.f;
+      float t[VEC], s2 = 0.f;
 #pragma unroll
       for (int e = 0; e < VEC; e++) {
         const float q = quant<QM>(x[i].e[e], qp);
-        s += avg.e[e] * q;
+        t[e] = avg.e[e] * q;
         if (LOSS) s2 += q * q;
       }
+      const float s = (VEC == 4) ? (t[0] + t[1 % VEC]) + (t[2 % VEC] + t[3 % VEC]) : t[0] + t[1 % VEC];
       p[i] = active ? s : 0.f;
       p2[i] = active ? s2 : 0.f;
     }
-    float *red = L.red + par * (W2B_T2 * 4);
+    float *red = L.red + par * (W2B_T2 * W2B_NDWMAX);
 #pragma unroll
     for (int i = 0; i < W2B_T2; i++) p[i] = wave_sum(p[i]);
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < W2B_T2; i++)
-        if (i < n) red[i * 4 + wave] = p[i];
+        if (i < n) red[i * W2B_NDWMAX + wave] = p[i];
     }
     __syncthreads();
     float gl = 0.f;
     if (lane < n) {
       float f = 0.f;
-      for (int w = 0; w < nwaves; w++) f += red[lane * 4 + w];
+      // pairs of 8-byte-column wavefronts first: the same binary tree over the elements as the plain kernel's
+      // 16-byte-column wavefronts, so that a single worker reproduces the plain kernel bit for bit
+      for (int w = 0; w < nwaves; w += 2)
+        f += red[lane * W2B_NDWMAX + w] + ((w + 1 < nwaves) ? red[lane * W2B_NDWMAX + w + 1] : 0.f);
       const float label = (start + lane == 0) ? 1.f : 0.f;
       float g;
       if (f > 6.f) g = (label - 1.f) * alpha;
@@ -435,15 +463,15 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
     for (int j = 0; j < cw; j++) {
       const int s = L.cslot[j];
       if (s >= 0) {
-        Col<VEC> w0 = lds_ld4(L.win + s * dim + col0), dl = lds_ldh4(L.dlt + s * dim + col0);
+        Col<VEC> w0 = lds_ld<VEC>(L.win + s * dim + col0), dl = lds_ldh<VEC>(L.dlt + s * dim + col0);
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
           const float d = err.e[e] - ar2 * w0.e[e];
           w0.e[e] = w0.e[e] + d;
           dl.e[e] = dl.e[e] + d;
         }
-        lds_st4(L.win + s * dim + col0, w0);
-        lds_sth4(L.dlt + s * dim + col0, dl);
+        lds_st(L.win + s * dim + col0, w0);
+        lds_sth(L.dlt + s * dim + col0, dl);
       } else if (s == -1) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) ur0.e[e] = ur0.e[e] + (err.e[e] - ar2 * ur0.e[e]);
@@ -469,9 +497,9 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
 // the scalar work of a step (it was 25-30 % of the step time when wavefront 0 did both).
 // Barrier discipline: every wavefront executes the same s_barrier sequence per step: nck barriers inside
 // the data phase (one per target chunk; the producer executes them after its own work) + one at the end.
-template <int QM, bool LOSS, int MM>
-__global__ void __launch_bounds__(320, 4) k_train_workers2(const W2bParams P, const long long max_positions,
-                                                           const int R) {
+template <int QM, int VEC, bool LOSS, int MM>
+__global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, const long long max_positions,
+                                                           const int R, const int NDW) {
   extern __shared__ int smem[];
   const Win2 L0 = carve_win2(smem, P.dim, P.window, P.negative, R, 0);
   const Win2 L1 = carve_win2(smem, P.dim, P.window, P.negative, R, 1);
@@ -479,7 +507,7 @@ __global__ void __launch_bounds__(320, 4) k_train_workers2(const W2bParams P, co
   WorkerLds *S = &L.S->w;
   int *s_sen = L.sen;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool producer = (wave == 4);
+  const bool producer = (wave == NDW);
   const int wid = blockIdx.x;
   if (wid >= P.num_threads) return;
   W2bWorker *G = P.workers + wid;
@@ -489,7 +517,7 @@ __global__ void __launch_bounds__(320, 4) k_train_workers2(const W2bParams P, co
   qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
   qp.steps_f = (float)qp.steps_i;
   const int NS = 2 * R + 1;
-  const int col0 = tid * 4;
+  const int col0 = tid * VEC;
   const bool active = !producer && col0 < P.dim;
   for (int i = tid; i < G->sen_len; i += blockDim.x) s_sen[i] = G->sen[i];
   for (int i = tid; i < NS; i += blockDim.x) { L.slot_row[i] = -1; L.slot_ref[i] = 0; L.pos_slot[i] = 0; }
@@ -506,7 +534,7 @@ __global__ void __launch_bounds__(320, 4) k_train_workers2(const W2bParams P, co
 #ifdef W2B_PHASE_TIMERS
 #define W2B_TICK(k) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long n_ = wall_clock64(); \
     atomicAdd(&P.shared->dbg[k], n_ - tick_); tick_ = n_; } } while (0)
-#define W2B_TICKP(k) do { if (blockIdx.x == 0 && tid == 256) { const unsigned long long n_ = wall_clock64(); \
+#define W2B_TICKP(k) do { if (blockIdx.x == 0 && tid == NDW * 64) { const unsigned long long n_ = wall_clock64(); \
     atomicAdd(&P.shared->dbg[k], n_ - tick_); tick_ = n_; } } while (0)
   unsigned long long tick_ = wall_clock64();
 #else
@@ -520,9 +548,9 @@ __global__ void __launch_bounds__(320, 4) k_train_workers2(const W2bParams P, co
   float alpha_pref = P.starting_alpha;
   bool alpha_pref_ok = false;
   // data-wavefront registers: the row that enters the window at the next step, loaded one step early
-  Col<4> apre;
+  Col<VEC> apre;
 #pragma unroll
-  for (int e = 0; e < 4; e++) apre.e[e] = 0.f;
+  for (int e = 0; e < VEC; e++) apre.e[e] = 0.f;
   int apre_row = -1;
 
   // ---- the preparation of one pass (producer wavefront only; all 64 lanes, wave-uniform control flow)
@@ -688,7 +716,7 @@ __global__ void __launch_bounds__(320, 4) k_train_workers2(const W2bParams P, co
                             : (alpha_pref_ok ? alpha_pref
                                              : __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT));
-          nck = prep_lists<T2For<QM>::value>(O.tgt, L.prev, O.cend, nt, nullptr, nullptr, 0, lane);
+          nck = prep_lists<T2For<VEC>::value>(O.tgt, L.prev, O.cend, nt, nullptr, nullptr, 0, lane);
         }
         const int nq = p + 1 + R;                                        // enters the window at the next step
         next_row = (p + 1 < sen_len && nq < sen_len) ? s_sen[nq] : -1;
@@ -736,63 +764,63 @@ __global__ void __launch_bounds__(320, 4) k_train_workers2(const W2bParams P, co
       bool deferred = false;                    // steady state: the leaving row is merged back AFTER the step
       int d_row = -1;
       unsigned d_csum = 0;
-      Col<4> d_g, d_rw, d_rd;
+      Col<VEC> d_g, d_rw, d_rd;
 #pragma unroll
-      for (int e = 0; e < 4; e++) { d_g.e[e] = 0.f; d_rw.e[e] = 0.f; d_rd.e[e] = 0.f; }
+      for (int e = 0; e < VEC; e++) { d_g.e[e] = 0.f; d_rw.e[e] = 0.f; d_rd.e[e] = 0.f; }
       if (n_ret <= 1 && n_adm <= 1) {
         const int uc_n = I.St->uc_n;
         if (n_ret == 1) {
           const int s = I.ret_slot[0];
           d_row = I.ret_row[0];
-          d_csum = L.csum[s * 4 + wave];
+          d_csum = L.csum[s * W2B_NDWMAX + wave];
           if (active) {
-            d_rw = lds_ld4(L.win + s * P.dim + col0);
-            d_rd = lds_ldh4(L.dlt + s * P.dim + col0);
-            d_g = load_col<4, MM>(P.u, d_row, P.dim, col0);               // consumed after the step: no stall
+            d_rw = lds_ld<VEC>(L.win + s * P.dim + col0);
+            d_rd = lds_ldh<VEC>(L.dlt + s * P.dim + col0);
+            d_g = load_col<VEC, MM>(P.u, d_row, P.dim, col0);               // consumed after the step: no stall
           }
           deferred = true;
         }
         if (n_adm == 1) {
           const int s = I.adm_slot[0], row = I.adm_row[0];
-          Col<4> a = apre;                                                   // loaded during the previous step
+          Col<VEC> a = apre;                                                   // loaded during the previous step
           if (row != apre_row) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) a.e[e] = 0.f;
-            if (active) a = load_col<4, MM>(P.u, row, P.dim, col0);
+            for (int e = 0; e < VEC; e++) a.e[e] = 0.f;
+            if (active) a = load_col<VEC, MM>(P.u, row, P.dim, col0);
           }
           const unsigned cs = wave_xor(active ? col_bits(a) : 0u);
-          if (lane == 0) L.csum[s * 4 + wave] = cs;
+          if (lane == 0) L.csum[s * W2B_NDWMAX + wave] = cs;
           if (active) {
-            Col<4> z;
+            Col<VEC> z;
 #pragma unroll
-            for (int e = 0; e < 4; e++) z.e[e] = 0.f;
-            lds_st4(L.win + s * P.dim + col0, a);
-            lds_sth4(L.dlt + s * P.dim + col0, z);
+            for (int e = 0; e < VEC; e++) z.e[e] = 0.f;
+            lds_st(L.win + s * P.dim + col0, a);
+            lds_sth(L.dlt + s * P.dim + col0, z);
           }
         }
         // a register-held outer row of this step that is the row leaving right now must see the merge
         if (deferred && ((uc_n > 0 && I.uc_row[0] == d_row) || (uc_n > 1 && I.uc_row[1] == d_row))) {
-          retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
+          retire_finish<VEC, MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
           deferred = false;
         }
         // prefetch the row that enters at the next step (never one whose store is still ahead of us)
         const int nr = I.St->next_row;
         const bool is_uc = (uc_n > 0 && I.uc_row[0] == nr) || (uc_n > 1 && I.uc_row[1] == nr);
         apre_row = (nr >= 0 && !(deferred && nr == d_row) && !is_uc) ? nr : -1;
-        if (apre_row >= 0 && active) apre = load_col<4, MM>(P.u, apre_row, P.dim, col0);
+        if (apre_row >= 0 && active) apre = load_col<VEC, MM>(P.u, apre_row, P.dim, col0);
       } else {
         if (n_ret <= W2B_RCH && n_adm <= W2B_RCH) {
-          window_exchange<MM>(P, I, n_ret, n_adm, active, col0, lane, wave);
+          window_exchange<VEC, MM>(P, I, n_ret, n_adm, active, col0, lane, wave);
         } else {
-          if (n_ret) window_retire<MM>(P, I, n_ret, active, col0, lane, wave);
-          if (n_adm) window_admit<MM>(P, I, n_adm, active, col0, lane, wave);
+          if (n_ret) window_retire<VEC, MM>(P, I, n_ret, active, col0, lane, wave);
+          if (n_adm) window_admit<VEC, MM>(P, I, n_adm, active, col0, lane, wave);
         }
         apre_row = -1;
       }
       W2B_TICK(4);
       if (!stop && I.St->cw > 0)
-        process_word2<QM, LOSS, MM>(P, I, qp, I.St->cw, I.St->nt, I.St->uc_n, I.St->alpha, loss_acc);
-      if (deferred) retire_finish<MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
+        process_word2<QM, VEC, LOSS, MM>(P, I, qp, NDW, I.St->cw, I.St->nt, I.St->uc_n, I.St->alpha, loss_acc);
+      if (deferred) retire_finish<VEC, MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
       W2B_TICK(5);
     }
     __syncthreads();                                     // lists of the next step are published; this step is done
@@ -815,9 +843,11 @@ __global__ void __launch_bounds__(320, 4) k_train_workers2(const W2bParams P, co
 
 }  // namespace
 
+static int win2_threads(int dim) { return (((dim / 2) + 63) / 64 + 1) * 64; }
+
 // Radius for which the sentence-resident kernel can run with two workgroups per CU (-1: use the plain kernel)
 int w2b_window_radius(int dim, int window, int negative) {
-  if (dim % 4 != 0 || dim > 1024) return -1;
+  if (dim % 2 != 0 || dim > 2 * 64 * 7) return -1;     // 8-byte columns, at most 7 data wavefronts (+1 producer)
   const size_t budget = 80 * 1024;                 // two workgroups per 160 KiB CU
   if (win2_lds_bytes(dim, window, negative, window) <= budget) return window;
   if (window >= 2 && win2_lds_bytes(dim, window, negative, window - 1) <= budget) return window - 1;
@@ -833,29 +863,30 @@ int w2b_workers2_per_cu(const W2bParams &p, int R, bool loss) {
     constexpr int MM = decltype(mm)::value;
     return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
       constexpr int QM = decltype(qm)::value;
-      if (loss) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, true, MM>, 320, lds);
-      return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, false, MM>, 320, lds);
+      if (loss) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, 2, true, MM>, win2_threads(p.dim), lds);
+      return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, 2, false, MM>, win2_threads(p.dim), lds);
     });
   });
   return nb > 0 ? nb : 1;
 }
 
 hipError_t w2b_launch_workers2(const W2bParams &p, long long max_positions, int R, bool loss, hipStream_t s) {
-  const int threads = 320;                 // 4 data wavefronts + 1 producer wavefront
+  const int threads = win2_threads(p.dim);   // data wavefronts (one thread per 8-byte column) + 1 producer wavefront
+  const int NDW = threads / 64 - 1;
   const size_t lds = win2_lds_bytes(p.dim, p.window, p.negative, R);
   static bool reported = false;
   if (!reported && getenv("W2B_DEBUG")) {
     reported = true;
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<1, false, 0>, threads, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<1, 2, false, 0>, threads, lds);
     fprintf(stderr, "w2b debug: sentence-resident kernel R=%d lds=%zu B, resident workgroups/CU=%d\n", R, lds, nb);
   }
   return dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
     constexpr int MM = decltype(mm)::value;
     return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
       constexpr int QM = decltype(qm)::value;
-      if (loss) hipLaunchKernelGGL((k_train_workers2<QM, true, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R);
-      else hipLaunchKernelGGL((k_train_workers2<QM, false, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R);
+      if (loss) hipLaunchKernelGGL((k_train_workers2<QM, 2, true, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
+      else hipLaunchKernelGGL((k_train_workers2<QM, 2, false, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
       return hipGetLastError();
     });
   });
