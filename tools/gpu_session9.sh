@@ -1,11 +1,7 @@
 #!/bin/bash
 set +e
 export TMPDIR=/tmp
-B="python bench.py --cpu-baseline none --also-relaxed 0 --tokens 30000000 --steps 6 --warmup 2 --form worker --positions 1024"
-short() { python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('%-40s %8.2f Mw/s  frac %.3f  launch %.2f ms' % (sys.argv[1], d['value']/1e6, d['roofline']['frac'], d['roofline']['avg_launch_ms']))
-" "$1"; }
-for w in 128 256 384 512 768; do timeout 300 $B --workers $w 2>/dev/null | short "wc=1 workers=$w"; done
+export W2B_LIB=$PWD/word2bits_amd/libword2bits_hip_dbg.so W2B_DEBUG=1
+B="python bench.py --cpu-baseline none --also-relaxed 0 --tokens 30000000 --steps 8 --warmup 2"
+timeout 600 $B 2>&1 | grep -E "w2b debug" | cut -c1-400
+timeout 600 $B --workers 256 2>&1 | grep -E "w2b debug: phase" | cut -c1-400
