@@ -201,8 +201,8 @@ __device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int neg
 //   cend[k]  = end of the k-th chunk of at most T targets, cut early at a repeated row
 //   umult[j] = multiplicity of context row j at its first occurrence, 0 at later ones (plain kernel only)
 // Lane-parallel compares on register copies (v_readlane broadcasts) instead of O(n^2) LDS loops.
-template <int T>
-__device__ __forceinline__ int prep_lists(int *tgt, int *prev, int *cend, int nt, int *ctx, int *umult, int cw,
+template <int T, typename IP>
+__device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP ctx, IP umult, int cw,
                                           int lane) {
   W2B_WAVE_SYNC();
   for (int i0 = 0; i0 < nt; i0 += 64) {

@@ -50,20 +50,26 @@ struct Step2 {
   int pad[3];
 };
 
+// Explicit LDS address space on every pointer of the kernel's LDS record: dereferences compile to ds_*
+// instructions.  (With generic pointers the two step buffers were selected through a struct reference and
+// address-space inference gave up: 250 flat_load/flat_store per step, each tied to vmcnt AND lgkmcnt, so
+// every window access also waited for the target rows in flight.)
+#define W2B_LDS __attribute__((address_space(3)))
+
 struct Win2 {
-  float *win;             // [S][dim]   current fp32 value of the resident rows
-  __half *dlt;            // [S][dim]   what this worker added since the row entered (fp16)
-  unsigned *csum;         // [S][4]     per-wavefront xor checksum of the row bits at entry
-  float *red;             // [2][W2B_T2MAX][4]
-  int *slot_row, *slot_ref, *pos_slot;          // [S]
-  int *ret_slot, *ret_row, *adm_slot, *adm_row; // [S+2]
-  int *cslot;             // [maxc] slot of every context position; -1-k = k-th register-held row
-  int *uc_row;            // [2]   rows of the (at most two) context positions outside the radius
-  int *tgt, *prev, *cend; // [maxt]
-  int *sen;               // [1000]
-  unsigned long long *ja, *jc;   // [nj] LCG jump-ahead table (copy of P.jump_a / P.jump_c)
-  Win2Lds *S;
-  Step2 *St;              // per-step scalars (this struct exists twice: one per step buffer)
+  W2B_LDS float *win;             // [S][dim]   current fp32 value of the resident rows
+  W2B_LDS __half *dlt;            // [S][dim]   what this worker added since the row entered (fp16)
+  W2B_LDS unsigned *csum;         // [S][4]     per-wavefront xor checksum of the row bits at entry
+  W2B_LDS float *red;             // [2][W2B_T2MAX][4]
+  W2B_LDS int *slot_row, *slot_ref, *pos_slot;          // [S]
+  W2B_LDS int *ret_slot, *ret_row, *adm_slot, *adm_row; // [S+2]
+  W2B_LDS int *cslot;             // [maxc] slot of every context position; -1-k = k-th register-held row
+  W2B_LDS int *uc_row;            // [2]   rows of the (at most two) context positions outside the radius
+  W2B_LDS int *tgt, *prev, *cend; // [maxt]
+  W2B_LDS int *sen;               // [1000]
+  W2B_LDS unsigned long long *ja, *jc;   // [nj] LCG jump-ahead table (copy of P.jump_a / P.jump_c)
+  W2B_LDS Win2Lds *S;
+  W2B_LDS Step2 *St;              // per-step scalars (this struct exists twice: one per step buffer)
 };
 
 __host__ __device__ inline int w2_round4(int x) { return (x + 3) & ~3; }
@@ -82,16 +88,16 @@ __host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negati
   return b;
 }
 
-__device__ __forceinline__ Win2 carve_win2(int *base, int dim, int window, int negative, int R, int buf) {
+__device__ __forceinline__ Win2 carve_win2(W2B_LDS int *base, int dim, int window, int negative, int R, int buf) {
   const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
   Win2 L;
-  char *p = reinterpret_cast<char *>(base);
-  L.win = reinterpret_cast<float *>(p); p += (size_t)S * dim * 4;
-  L.dlt = reinterpret_cast<__half *>(p); p += (size_t)S * dim * 2;
-  p = reinterpret_cast<char *>((reinterpret_cast<size_t>(p) + 15) & ~(size_t)15);
-  L.csum = reinterpret_cast<unsigned *>(p); p += (size_t)S * W2B_NDWMAX * 4;
-  L.red = reinterpret_cast<float *>(p); p += 2 * W2B_T2MAX * W2B_NDWMAX * 4;
-  int *q = reinterpret_cast<int *>(p);
+  W2B_LDS char *p = (W2B_LDS char *)base;
+  L.win = (W2B_LDS float *)p; p += (size_t)S * dim * 4;
+  L.dlt = (W2B_LDS __half *)p; p += (size_t)S * dim * 2;
+  p = (W2B_LDS char *)(((unsigned)(size_t)p + 15u) & ~15u);
+  L.csum = (W2B_LDS unsigned *)p; p += (size_t)S * W2B_NDWMAX * 4;
+  L.red = (W2B_LDS float *)p; p += 2 * W2B_T2MAX * W2B_NDWMAX * 4;
+  W2B_LDS int *q = (W2B_LDS int *)p;
   L.slot_row = q; q += w2_round4(S);
   L.slot_ref = q; q += w2_round4(S);
   L.pos_slot = q; q += w2_round4(S);
@@ -107,11 +113,11 @@ __device__ __forceinline__ Win2 carve_win2(int *base, int dim, int window, int n
   L.uc_row = q; q += 4;
   L.tgt = q; q += maxt;
   L.cend = q; q += maxt;
-  L.St = reinterpret_cast<Step2 *>(q); q += sizeof(Step2) / 4;
+  L.St = (W2B_LDS Step2 *)q; q += sizeof(Step2) / 4;
   q += (1 - buf) * per_buf;
-  L.S = reinterpret_cast<Win2Lds *>((reinterpret_cast<size_t>(q) + 15) & ~(size_t)15);
+  L.S = (W2B_LDS Win2Lds *)(((unsigned)(size_t)q + 15u) & ~15u);
   const int nj = negative + 2 > 66 ? negative + 2 : 66;
-  L.ja = reinterpret_cast<unsigned long long *>((reinterpret_cast<size_t>(L.S + 1) + 15) & ~(size_t)15);
+  L.ja = (W2B_LDS unsigned long long *)(((unsigned)(size_t)(L.S + 1) + 15u) & ~15u);
   L.jc = L.ja + nj;
   return L;
 }
@@ -124,49 +130,59 @@ __device__ __forceinline__ unsigned col_bits(const Col<VEC> &c) {
   return h;
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 // LDS accesses of a thread's own column of a window row: VEC floats (8 or 16 bytes) and VEC fp16 deltas
-template <int VEC> __device__ __forceinline__ Col<VEC> lds_ld(const float *p);
-template <> __device__ __forceinline__ Col<4> lds_ld<4>(const float *p) {
-  const float4 t = *reinterpret_cast<const float4 *>(p);
+template <int VEC> __device__ __forceinline__ Col<VEC> lds_ld(const W2B_LDS float *p);
+template <> __device__ __forceinline__ Col<4> lds_ld<4>(const W2B_LDS float *p) {
+  const f32x4_t t = *(const W2B_LDS f32x4_t *)p;
   Col<4> c;
   c.e[0] = t.x; c.e[1] = t.y; c.e[2] = t.z; c.e[3] = t.w;
   return c;
 }
-template <> __device__ __forceinline__ Col<2> lds_ld<2>(const float *p) {
-  const float2 t = *reinterpret_cast<const float2 *>(p);
+template <> __device__ __forceinline__ Col<2> lds_ld<2>(const W2B_LDS float *p) {
+  const f32x2_t t = *(const W2B_LDS f32x2_t *)p;
   Col<2> c;
   c.e[0] = t.x; c.e[1] = t.y;
   return c;
 }
-__device__ __forceinline__ void lds_st(float *p, const Col<4> &c) {
-  *reinterpret_cast<float4 *>(p) = make_float4(c.e[0], c.e[1], c.e[2], c.e[3]);
+__device__ __forceinline__ void lds_st(W2B_LDS float *p, const Col<4> &c) {
+  f32x4_t t;
+  t.x = c.e[0]; t.y = c.e[1]; t.z = c.e[2]; t.w = c.e[3];
+  *(W2B_LDS f32x4_t *)p = t;
 }
-__device__ __forceinline__ void lds_st(float *p, const Col<2> &c) {
-  *reinterpret_cast<float2 *>(p) = make_float2(c.e[0], c.e[1]);
+__device__ __forceinline__ void lds_st(W2B_LDS float *p, const Col<2> &c) {
+  f32x2_t t;
+  t.x = c.e[0]; t.y = c.e[1];
+  *(W2B_LDS f32x2_t *)p = t;
 }
-template <int VEC> __device__ __forceinline__ Col<VEC> lds_ldh(const __half *p);
-template <> __device__ __forceinline__ Col<4> lds_ldh<4>(const __half *p) {
-  const uint2 t = *reinterpret_cast<const uint2 *>(p);
-  const __half2 a = *reinterpret_cast<const __half2 *>(&t.x), b = *reinterpret_cast<const __half2 *>(&t.y);
+template <int VEC> __device__ __forceinline__ Col<VEC> lds_ldh(const W2B_LDS __half *p);
+template <> __device__ __forceinline__ Col<4> lds_ldh<4>(const W2B_LDS __half *p) {
+  const u32x2_t t = *(const W2B_LDS u32x2_t *)p;
+  const unsigned tx = t.x, ty = t.y;
+  const __half2 a = *reinterpret_cast<const __half2 *>(&tx), b = *reinterpret_cast<const __half2 *>(&ty);
   Col<4> c;
   c.e[0] = __low2float(a); c.e[1] = __high2float(a); c.e[2] = __low2float(b); c.e[3] = __high2float(b);
   return c;
 }
-template <> __device__ __forceinline__ Col<2> lds_ldh<2>(const __half *p) {
-  const __half2 a = *reinterpret_cast<const __half2 *>(p);
+template <> __device__ __forceinline__ Col<2> lds_ldh<2>(const W2B_LDS __half *p) {
+  const unsigned raw = *(const W2B_LDS unsigned *)p;
+  const __half2 a = *reinterpret_cast<const __half2 *>(&raw);
   Col<2> c;
   c.e[0] = __low2float(a); c.e[1] = __high2float(a);
   return c;
 }
-__device__ __forceinline__ void lds_sth(__half *p, const Col<4> &c) {
+__device__ __forceinline__ void lds_sth(W2B_LDS __half *p, const Col<4> &c) {
   const __half2 a = __floats2half2_rn(c.e[0], c.e[1]), b = __floats2half2_rn(c.e[2], c.e[3]);
-  uint2 t;
+  u32x2_t t;
   t.x = *reinterpret_cast<const unsigned *>(&a);
   t.y = *reinterpret_cast<const unsigned *>(&b);
-  *reinterpret_cast<uint2 *>(p) = t;
+  *(W2B_LDS u32x2_t *)p = t;
 }
-__device__ __forceinline__ void lds_sth(__half *p, const Col<2> &c) {
-  *reinterpret_cast<__half2 *>(p) = __floats2half2_rn(c.e[0], c.e[1]);
+__device__ __forceinline__ void lds_sth(W2B_LDS __half *p, const Col<2> &c) {
+  const __half2 a = __floats2half2_rn(c.e[0], c.e[1]);
+  *(W2B_LDS unsigned *)p = *reinterpret_cast<const unsigned *>(&a);
 }
 
 // ---- rows leaving the window: store them (exact value when untouched by others, else merge the delta)
@@ -390,7 +406,7 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
       p[i] = active ? s : 0.f;
       p2[i] = active ? s2 : 0.f;
     }
-    float *red = L.red + par * (W2B_T2 * W2B_NDWMAX);
+    W2B_LDS float *red = L.red + par * (W2B_T2 * W2B_NDWMAX);
 #pragma unroll
     for (int i = 0; i < W2B_T2; i++) p[i] = wave_sum(p[i]);
     if (lane == 0) {
@@ -501,11 +517,12 @@ template <int QM, int VEC, bool LOSS, int MM>
 __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, const long long max_positions,
                                                            const int R, const int NDW) {
   extern __shared__ int smem[];
-  const Win2 L0 = carve_win2(smem, P.dim, P.window, P.negative, R, 0);
-  const Win2 L1 = carve_win2(smem, P.dim, P.window, P.negative, R, 1);
+  W2B_LDS int *const smem_lds = (W2B_LDS int *)smem;
+  const Win2 L0 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, 0);
+  const Win2 L1 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, 1);
   const Win2 &L = L0;                                   // everything that is not double buffered
-  WorkerLds *S = &L.S->w;
-  int *s_sen = L.sen;
+  W2B_LDS WorkerLds *S = &L.S->w;
+  W2B_LDS int *s_sen = L.sen;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool producer = (wave == NDW);
   const int wid = blockIdx.x;
@@ -580,7 +597,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
           last_wc = wc;
         }
         if (sen_len == 0) {                                            // ref :394-413
-          read_sentence(P, s_sen, rng, cursor, wc, ovr, eof, sen_len, lane);
+          read_sentence(P, (int *)s_sen, rng, cursor, wc, ovr, eof, sen_len, lane);
           sen_pos = 0;
           new_sentence = true;
           W2B_WAVE_SYNC();
@@ -716,7 +733,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
                             : (alpha_pref_ok ? alpha_pref
                                              : __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT));
-          nck = prep_lists<T2For<VEC>::value>(O.tgt, L.prev, O.cend, nt, nullptr, nullptr, 0, lane);
+          nck = prep_lists<T2For<VEC>::value, W2B_LDS int *>(O.tgt, L.prev, O.cend, nt, (W2B_LDS int *)nullptr, (W2B_LDS int *)nullptr, 0, lane);
         }
         const int nq = p + 1 + R;                                        // enters the window at the next step
         next_row = (p + 1 < sen_len && nq < sen_len) ? s_sen[nq] : -1;
