@@ -203,7 +203,7 @@ __device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int neg
 // Lane-parallel compares on register copies (v_readlane broadcasts) instead of O(n^2) LDS loops.
 template <int T, typename IP>
 __device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP ctx, IP umult, int cw,
-                                          int lane) {
+                                          int lane, bool with_dep = false) {
   W2B_WAVE_SYNC();
   for (int i0 = 0; i0 < nt; i0 += 64) {
     const int i = i0 + lane;
@@ -240,7 +240,14 @@ __device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP c
       const unsigned long long m = __ballot(hit);
       if (m) { end = i0 + __ffsll((long long)m) - 1; break; }
     }
-    if (lane == 0) cend[k] = end;
+    int dep = 0;                   // with_dep: bit 16 = the chunk holds a row that an earlier chunk also holds
+    if (with_dep) {
+      for (int i0 = start; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        dep |= (__ballot((i < end) && (prev[i] >= 0)) != 0ull) ? 1 : 0;
+      }
+    }
+    if (lane == 0) cend[k] = end | (dep << 16);
     k++;
     start = end;
   }

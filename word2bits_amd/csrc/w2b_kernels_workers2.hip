@@ -30,7 +30,7 @@
 // VGPRs only ONE workgroup per CU was ever resident), so the kernel is held to 128 VGPRs.
 #define W2B_T2MAX 25
 #define W2B_NDWMAX 8   // data wavefronts per worker (stride of the per-wavefront LDS tables)
-template <int VEC> struct T2For { static constexpr int value = (VEC == 2) ? 13 : 9; };
+template <int VEC> struct T2For { static constexpr int value = 13; };
 #define W2B_RCH 2   // window rows moved per trip when many enter/leave at once (sentence boundaries)
 
 namespace {
@@ -334,21 +334,23 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
 #ifdef W2B_PHASE_TIMERS
   unsigned long long t2_ = wall_clock64();
 #endif
-  Col<VEC> x[W2B_T2];
-  int rows[W2B_T2];
-  int start = 0, chunk = 0, end = L.cend[0];
-  auto chunk_rows = [&]() {
-    const int mine = L.tgt[min(start + lane, nt - 1)];
+  // Two register buffers of target rows: while chunk k is reduced and updated, the rows of chunk k+1 are
+  // already in flight (unless chunk k+1 repeats a row of an earlier chunk: then it is loaded after the stores)
+  Col<VEC> xa[W2B_T2], xb[W2B_T2];
+  int ra[W2B_T2], rb[W2B_T2];
+  auto load_chunk = [&](Col<VEC> (&X)[W2B_T2], int (&Rw)[W2B_T2], const int s, const int e) {
+    const int mine = L.tgt[min(s + lane, nt - 1)];
 #pragma unroll
-    for (int i = 0; i < W2B_T2; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
+    for (int i = 0; i < W2B_T2; i++) Rw[i] = __builtin_amdgcn_readlane(mine, i);
+#pragma unroll
+    for (int i = 0; i < W2B_T2; i++) {
+#pragma unroll
+      for (int ee = 0; ee < VEC; ee++) X[i].e[ee] = 0.f;
+      if (active && s + i < e) X[i] = load_col<VEC, MM>(P.v, Rw[i], dim, col0);
+    }
   };
-  chunk_rows();
-#pragma unroll
-  for (int i = 0; i < W2B_T2; i++) {
-#pragma unroll
-    for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
-    if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0);
-  }
+  int start = 0, chunk = 0, end = L.cend[0] & 0xffff;
+  load_chunk(xa, ra, start, end);
   // the (at most two) context rows outside the radius live in registers for this step
   Col<VEC> ur0, ur1;
 #pragma unroll
@@ -390,7 +392,7 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
 #pragma unroll
   for (int e = 0; e < VEC; e++) err.e[e] = 0.f;
   int par = 0;
-  for (;;) {
+  auto process_chunk = [&](Col<VEC> (&x)[W2B_T2], int (&rows)[W2B_T2], const int start, const int end) {
     const int n = end - start;
     float p[W2B_T2], p2[W2B_T2];
 #pragma unroll
@@ -463,14 +465,29 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
         }
       }
     }
-    start = end;
-    if (start >= nt) break;
-    end = L.cend[++chunk];
     par ^= 1;
-    chunk_rows();
-#pragma unroll
-    for (int i = 0; i < W2B_T2; i++)
-      if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0);
+  };
+  for (;;) {
+    {   // buffer A holds chunk `chunk`
+      const bool more = end < nt;
+      const int raw = more ? L.cend[chunk + 1] : 0;
+      const int nend = raw & 0xffff, dep = raw >> 16;
+      if (more && !dep) load_chunk(xb, rb, end, nend);
+      process_chunk(xa, ra, start, end);
+      if (!more) break;
+      if (dep) load_chunk(xb, rb, end, nend);
+      start = end; end = nend; chunk++;
+    }
+    {   // buffer B holds chunk `chunk`
+      const bool more = end < nt;
+      const int raw = more ? L.cend[chunk + 1] : 0;
+      const int nend = raw & 0xffff, dep = raw >> 16;
+      if (more && !dep) load_chunk(xa, ra, end, nend);
+      process_chunk(xb, rb, start, end);
+      if (!more) break;
+      if (dep) load_chunk(xa, ra, end, nend);
+      start = end; end = nend; chunk++;
+    }
   }
 
   W2B_TICK2(8);
@@ -733,7 +750,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
                             : (alpha_pref_ok ? alpha_pref
                                              : __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT));
-          nck = prep_lists<T2For<VEC>::value, W2B_LDS int *>(O.tgt, L.prev, O.cend, nt, (W2B_LDS int *)nullptr, (W2B_LDS int *)nullptr, 0, lane);
+          nck = prep_lists<T2For<VEC>::value, W2B_LDS int *>(O.tgt, L.prev, O.cend, nt, (W2B_LDS int *)nullptr, (W2B_LDS int *)nullptr, 0, lane, true);
         }
         const int nq = p + 1 + R;                                        // enters the window at the next step
         next_row = (p + 1 < sen_len && nq < sen_len) ? s_sen[nq] : -1;
