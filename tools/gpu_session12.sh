@@ -13,3 +13,6 @@ timeout 600 $B 2>/dev/null | short "worker default (coherent, resident)"
 timeout 600 $B --relaxed 1 --window-cache 1 2>/dev/null | short "worker resident relaxed"
 timeout 600 $B --ids uniform 2>/dev/null | short "worker resident coherent uniform"
 timeout 600 $B --dim 200 --vocab 60238 2>/dev/null | short "cfg1 shape coherent"
+timeout 600 $B --form tuples 2>/dev/null | short "tuples coherent"
+timeout 600 $B --form tuples --relaxed 1 2>/dev/null | short "tuples relaxed"
+timeout 600 $B --relaxed 1 2>/dev/null | short "worker plain relaxed (auto)"

@@ -26,8 +26,11 @@
 #include <type_traits>
 
 #ifndef W2B_T
-#define W2B_T 9    // target rows kept in registers per chunk (negative=24 -> 25 targets = 9 + 9 + 7)
+#define W2B_T 13   // most target rows kept in registers per chunk (LDS sizing); see TFor below
 #endif
+// target rows per chunk of the plain kernels: 13 (negative=24 -> 25 targets = 13 + 12) without the loss
+// bookkeeping, 9 (9 + 9 + 7) with it -- the widest chunk that stays within 128 VGPRs without spilling
+template <bool LOSS> struct TFor { static constexpr int value = LOSS ? 9 : W2B_T; };
 #ifndef W2B_CA
 #define W2B_CA 8   // context rows loaded per sub-chunk
 #endif
@@ -81,38 +84,60 @@ template <int MM> struct Aux {
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// `tab_bytes` != 0: the whole table is addressable with 32-bit offsets (< 4 GiB): ONE buffer resource per table
+// (loop invariant, built once) and the row start goes into the instruction's scalar offset -- one s_mul per row
+// instead of a 4-SGPR descriptor per row (the kernels were close to issue-bound with as many SALU as VALU
+// instructions).  Lanes beyond the row are masked by the callers (`active`).  tab_bytes == 0 (tables >= 4 GiB,
+// e.g. V=3.7M x D=1000): per-row resource whose size is the row length.
 template <int VEC, int MM>
-__device__ __forceinline__ Col<VEC> load_col(const float *tab, long long row, int dim, int col0) {
+__device__ __forceinline__ Col<VEC> load_col(const float *tab, long long row, int dim, int col0, unsigned tab_bytes) {
   Col<VEC> c;
-  const float *rowp = tab + __builtin_amdgcn_readfirstlane((int)row) * (long long)dim;
-  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, dim * 4, 0x27000);
+  const int urow = __builtin_amdgcn_readfirstlane((int)row);
+  __amdgpu_buffer_rsrc_t r;
+  int soff;
+  if (tab_bytes) {
+    r = __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, (int)tab_bytes, 0x27000);
+    soff = urow * dim * 4;
+  } else {
+    r = __builtin_amdgcn_make_buffer_rsrc((void *)(tab + urow * (long long)dim), 0, dim * 4, 0x27000);
+    soff = 0;
+  }
   if (VEC == 4) {
-    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, col0 * 4, 0, Aux<MM>::load);
+    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, col0 * 4, soff, Aux<MM>::load);
     c.e[0] = __uint_as_float(t.x); c.e[1 % VEC] = __uint_as_float(t.y);
     c.e[2 % VEC] = __uint_as_float(t.z); c.e[3 % VEC] = __uint_as_float(t.w);
   } else if (VEC == 2) {
-    u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, col0 * 4, 0, Aux<MM>::load);
+    u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, col0 * 4, soff, Aux<MM>::load);
     c.e[0] = __uint_as_float(t.x); c.e[1 % VEC] = __uint_as_float(t.y);
   } else {
-    c.e[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, col0 * 4, 0, Aux<MM>::load));
+    c.e[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, col0 * 4, soff, Aux<MM>::load));
   }
   return c;
 }
 template <int VEC, int MM>
-__device__ __forceinline__ void store_col(float *tab, long long row, int dim, int col0, const Col<VEC> &c) {
-  float *rowp = tab + __builtin_amdgcn_readfirstlane((int)row) * (long long)dim;
-  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, dim * 4, 0x27000);
+__device__ __forceinline__ void store_col(float *tab, long long row, int dim, int col0, const Col<VEC> &c,
+                                          unsigned tab_bytes) {
+  const int urow = __builtin_amdgcn_readfirstlane((int)row);
+  __amdgpu_buffer_rsrc_t r;
+  int soff;
+  if (tab_bytes) {
+    r = __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, (int)tab_bytes, 0x27000);
+    soff = urow * dim * 4;
+  } else {
+    r = __builtin_amdgcn_make_buffer_rsrc((void *)(tab + urow * (long long)dim), 0, dim * 4, 0x27000);
+    soff = 0;
+  }
   if (VEC == 4) {
     u32x4 t;
     t.x = __float_as_uint(c.e[0]); t.y = __float_as_uint(c.e[1 % VEC]);
     t.z = __float_as_uint(c.e[2 % VEC]); t.w = __float_as_uint(c.e[3 % VEC]);
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, col0 * 4, 0, Aux<MM>::store);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, col0 * 4, soff, Aux<MM>::store);
   } else if (VEC == 2) {
     u32x2 t;
     t.x = __float_as_uint(c.e[0]); t.y = __float_as_uint(c.e[1 % VEC]);
-    __builtin_amdgcn_raw_buffer_store_b64(t, r, col0 * 4, 0, Aux<MM>::store);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, col0 * 4, soff, Aux<MM>::store);
   } else {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c.e[0]), r, col0 * 4, 0, Aux<MM>::store);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c.e[0]), r, col0 * 4, soff, Aux<MM>::store);
   }
 }
 
@@ -266,22 +291,23 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
   const int dim = P.dim, col0 = tid * VEC;
   const bool active = col0 < dim;
   const float ar2 = (2.f * alpha) * P.reg;                      // 2*alpha*reg (ref :490,:501)
+  constexpr int TC = TFor<LOSS>::value;                         // rows per chunk
 
-  Col<VEC> x[W2B_T];
-  int rows[W2B_T];           // row ids of the chunk, wave-uniform (SGPRs): one LDS read, then v_readlane
+  Col<VEC> x[TC];
+  int rows[TC];           // row ids of the chunk, wave-uniform (SGPRs): one LDS read, then v_readlane
   int start = 0, chunk = 0, end = L.cend[0];
   auto chunk_rows = [&]() {
     const int mine = L.tgt[min(start + lane, nt - 1)];
 #pragma unroll
-    for (int i = 0; i < W2B_T; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
+    for (int i = 0; i < TC; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
   };
   chunk_rows();
   // issue the first chunk of target-row loads before the context phase so both gathers overlap
 #pragma unroll
-  for (int i = 0; i < W2B_T; i++) {
+  for (int i = 0; i < TC; i++) {
 #pragma unroll
     for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
-    if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0);
+    if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0, P.tab_bytes);
   }
 
   // ---- phase A: context_avg = (1/cw) * sum_j quantize(u[ctx_j])   (ref :431-449)
@@ -293,7 +319,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     Col<VEC> r[W2B_CA];
 #pragma unroll
     for (int jj = 0; jj < W2B_CA; jj++)
-      if (active && j0 + jj < cw) r[jj] = load_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0);
+      if (active && j0 + jj < cw) r[jj] = load_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0, P.tab_bytes);
 #pragma unroll
     for (int jj = 0; jj < W2B_CA; jj++)
       if (active && j0 + jj < cw) {
@@ -322,9 +348,9 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
   int par = 0;
   for (;;) {
     const int n = end - start;
-    float p[W2B_T], p2[W2B_T];
+    float p[TC], p2[TC];
 #pragma unroll
-    for (int i = 0; i < W2B_T; i++) {
+    for (int i = 0; i < TC; i++) {
       float t[VEC], s2 = 0.f;
 #pragma unroll
       for (int e = 0; e < VEC; e++) {
@@ -337,12 +363,12 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
       p[i] = active ? s : 0.f;
       p2[i] = active ? s2 : 0.f;
     }
-    float *red = L.red + par * (W2B_T * W2B_MAXW);
+    float *red = L.red + par * (TC * W2B_MAXW);
 #pragma unroll
-    for (int i = 0; i < W2B_T; i++) p[i] = wave_sum(p[i]);     // unconditional: W2B_T independent chains interleave
+    for (int i = 0; i < TC; i++) p[i] = wave_sum(p[i]);     // unconditional: W2B_T independent chains interleave
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < W2B_T; i++)
+      for (int i = 0; i < TC; i++)
         if (i < n) red[i * W2B_MAXW + wave] = p[i];
     }
     __syncthreads();
@@ -368,7 +394,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     }
     if (LOSS && P.reg != 0.f) {                                 // reg * sum q^2 of every target row
 #pragma unroll
-      for (int i = 0; i < W2B_T; i++)
+      for (int i = 0; i < TC; i++)
         if (i < n) {
           const float s2 = wave_sum(p2[i]);
           if (lane == 0) loss_acc -= (double)(P.reg * s2);
@@ -376,7 +402,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     }
     // error accumulation + row update, in target order (ref :486-491)
 #pragma unroll
-    for (int i = 0; i < W2B_T; i++) {
+    for (int i = 0; i < TC; i++) {
       if (i < n) {
         const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
         if (active) {
@@ -389,7 +415,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
             err.e[e] += g * quant<QM>(xv, qp);
             x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
           }
-          store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i]);
+          store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i], P.tab_bytes);
         }
       }
     }
@@ -399,8 +425,8 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     par ^= 1;
     chunk_rows();
 #pragma unroll
-    for (int i = 0; i < W2B_T; i++)
-      if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0);
+    for (int i = 0; i < TC; i++)
+      if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0, P.tab_bytes);
   }
 
   // ---- phase C: u[ctx_j] += context_avge - 2*alpha*reg*u[ctx_j]   (ref :494-503)
@@ -413,7 +439,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
 #pragma unroll
           for (int e = 0; e < VEC; e++) r[jj].e[e] = L.stash[((j0 + jj) * blockDim.x + tid) * VEC + e];
         } else {
-          r[jj] = load_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0);
+          r[jj] = load_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0, P.tab_bytes);
         }
       }
 #pragma unroll
@@ -425,7 +451,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
 #pragma unroll
             for (int e = 0; e < VEC; e++) r[jj].e[e] = r[jj].e[e] + (err.e[e] - ar2 * r[jj].e[e]);
           }
-          store_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0, r[jj]);
+          store_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0, r[jj], P.tab_bytes);
         }
       }
   }

@@ -46,6 +46,7 @@ struct W2bParams {
   W2bShared *shared;
   const unsigned long long *jump_a, *jump_c;   // LCG jump-ahead: x_{n+k} = jump_a[k]*x_n + jump_c[k]
   long long vocab_size, train_words, iter;
+  unsigned tab_bytes;             // bytes of one table when < 4 GiB (32-bit addressing of rows), else 0
   unsigned long long table_magic, window_magic;   // floor(2^64 / table_size), floor(2^64 / window)
   int dim, window, negative, bitlevel, num_threads;
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)

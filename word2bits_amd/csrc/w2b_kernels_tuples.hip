@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
         cnt += __popcll(m);
       }
       if (lane == 0) { L.tgt[0] = word; s_cnt[0] = cw; s_cnt[1] = 1 + cnt; }
-      if (cw > 0) prep_lists<W2B_T, int *>(L.tgt, L.prev, L.cend, 1 + cnt, L.ctx, L.umult, cw, lane);
+      if (cw > 0) prep_lists<TFor<LOSS>::value, int *>(L.tgt, L.prev, L.cend, 1 + cnt, L.ctx, L.umult, cw, lane);
     }
     __syncthreads();
     const int cw = s_cnt[0], nt = s_cnt[1];

@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
           nt = 1 + cnt;
           rng = lcg_jump(P, rng, K);
           alpha = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          prep_lists<W2B_T, int *>(L.tgt, L.prev, L.cend, nt, L.ctx, L.umult, cw, lane);
+          prep_lists<TFor<LOSS>::value, int *>(L.tgt, L.prev, L.cend, nt, L.ctx, L.umult, cw, lane);
         }
         sen_pos++;                                                    // ref :505-509
         if (sen_pos >= sen_len) sen_len = 0;

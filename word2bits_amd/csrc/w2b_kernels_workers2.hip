@@ -201,7 +201,7 @@ __device__ __forceinline__ void window_retire(const W2bParams &P, const Win2 &L,
         if (active) {
           rw[i] = lds_ld<VEC>(L.win + s * dim + col0);
           rd[i] = lds_ldh<VEC>(L.dlt + s * dim + col0);
-          g[i] = load_col<VEC, MM>(P.u, L.ret_row[i0 + i], dim, col0);
+          g[i] = load_col<VEC, MM>(P.u, L.ret_row[i0 + i], dim, col0, P.tab_bytes);
         }
       }
 #pragma unroll
@@ -214,7 +214,7 @@ __device__ __forceinline__ void window_retire(const W2bParams &P, const Win2 &L,
           Col<VEC> o;
 #pragma unroll
           for (int e = 0; e < VEC; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
-          store_col<VEC, MM>(P.u, L.ret_row[i0 + i], dim, col0, o);
+          store_col<VEC, MM>(P.u, L.ret_row[i0 + i], dim, col0, o, P.tab_bytes);
         }
       }
   }
@@ -232,7 +232,7 @@ __device__ __forceinline__ void window_admit(const W2bParams &P, const Win2 &L, 
       if (i0 + i < n_adm) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) a[i].e[e] = 0.f;
-        if (active) a[i] = load_col<VEC, MM>(P.u, L.adm_row[i0 + i], dim, col0);
+        if (active) a[i] = load_col<VEC, MM>(P.u, L.adm_row[i0 + i], dim, col0, P.tab_bytes);
       }
 #pragma unroll
     for (int i = 0; i < W2B_RCH; i++)
@@ -267,7 +267,7 @@ __device__ __forceinline__ void retire_finish(const W2bParams &P, int row, unsig
     Col<VEC> o;
 #pragma unroll
     for (int e = 0; e < VEC; e++) o.e[e] = untouched ? rw.e[e] : g.e[e] + rd.e[e];
-    store_col<VEC, MM>(P.u, row, P.dim, col0, o);
+    store_col<VEC, MM>(P.u, row, P.dim, col0, o, P.tab_bytes);
   }
 }
 
@@ -285,12 +285,12 @@ __device__ __forceinline__ void window_exchange(const W2bParams &P, const Win2 &
       const int s = L.ret_slot[i];
       rw[i] = lds_ld<VEC>(L.win + s * dim + col0);
       rd[i] = lds_ldh<VEC>(L.dlt + s * dim + col0);
-      g[i] = load_col<VEC, MM>(P.u, L.ret_row[i], dim, col0);
+      g[i] = load_col<VEC, MM>(P.u, L.ret_row[i], dim, col0, P.tab_bytes);
     }
   }
 #pragma unroll
   for (int i = 0; i < W2B_RCH; i++)
-    if (active && i < n_adm) a[i] = load_col<VEC, MM>(P.u, L.adm_row[i], dim, col0);
+    if (active && i < n_adm) a[i] = load_col<VEC, MM>(P.u, L.adm_row[i], dim, col0, P.tab_bytes);
 #pragma unroll
   for (int i = 0; i < W2B_RCH; i++)
     if (i < n_ret) {
@@ -301,7 +301,7 @@ __device__ __forceinline__ void window_exchange(const W2bParams &P, const Win2 &
         Col<VEC> o;
 #pragma unroll
         for (int e = 0; e < VEC; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
-        store_col<VEC, MM>(P.u, L.ret_row[i], dim, col0, o);
+        store_col<VEC, MM>(P.u, L.ret_row[i], dim, col0, o, P.tab_bytes);
       }
     }
 #pragma unroll
@@ -346,7 +346,7 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
     for (int i = 0; i < W2B_T2; i++) {
 #pragma unroll
       for (int ee = 0; ee < VEC; ee++) X[i].e[ee] = 0.f;
-      if (active && s + i < e) X[i] = load_col<VEC, MM>(P.v, Rw[i], dim, col0);
+      if (active && s + i < e) X[i] = load_col<VEC, MM>(P.v, Rw[i], dim, col0, P.tab_bytes);
     }
   };
   int start = 0, chunk = 0, end = L.cend[0] & 0xffff;
@@ -355,8 +355,8 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
   Col<VEC> ur0, ur1;
 #pragma unroll
   for (int e = 0; e < VEC; e++) { ur0.e[e] = 0.f; ur1.e[e] = 0.f; }
-  if (active && uc_n > 0) ur0 = load_col<VEC, MM>(P.u, L.uc_row[0], dim, col0);
-  if (active && uc_n > 1) ur1 = load_col<VEC, MM>(P.u, L.uc_row[1], dim, col0);
+  if (active && uc_n > 0) ur0 = load_col<VEC, MM>(P.u, L.uc_row[0], dim, col0, P.tab_bytes);
+  if (active && uc_n > 1) ur1 = load_col<VEC, MM>(P.u, L.uc_row[1], dim, col0, P.tab_bytes);
 
   W2B_TICK2(6);
   // ---- phase A from LDS (ref :431-449), window order
@@ -461,7 +461,7 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
             err.e[e] += g * quant<QM>(xv, qp);
             x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
           }
-          store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i]);
+          store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i], P.tab_bytes);
         }
       }
     }
@@ -513,8 +513,8 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
         for (int e = 0; e < VEC; e++) ur1.e[e] = ur1.e[e] + (err.e[e] - ar2 * ur1.e[e]);
       }
     }
-    if (uc_n > 0) store_col<VEC, MM>(P.u, L.uc_row[0], dim, col0, ur0);
-    if (uc_n > 1) store_col<VEC, MM>(P.u, L.uc_row[1], dim, col0, ur1);
+    if (uc_n > 0) store_col<VEC, MM>(P.u, L.uc_row[0], dim, col0, ur0, P.tab_bytes);
+    if (uc_n > 1) store_col<VEC, MM>(P.u, L.uc_row[1], dim, col0, ur1, P.tab_bytes);
   }
   W2B_TICK2(9);
   if (LOSS && P.reg != 0.f) {
@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
           if (active) {
             d_rw = lds_ld<VEC>(L.win + s * P.dim + col0);
             d_rd = lds_ldh<VEC>(L.dlt + s * P.dim + col0);
-            d_g = load_col<VEC, MM>(P.u, d_row, P.dim, col0);               // consumed after the step: no stall
+            d_g = load_col<VEC, MM>(P.u, d_row, P.dim, col0, P.tab_bytes);               // consumed after the step: no stall
           }
           deferred = true;
         }
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
           if (row != apre_row) {
 #pragma unroll
             for (int e = 0; e < VEC; e++) a.e[e] = 0.f;
-            if (active) a = load_col<VEC, MM>(P.u, row, P.dim, col0);
+            if (active) a = load_col<VEC, MM>(P.u, row, P.dim, col0, P.tab_bytes);
           }
           const unsigned cs = wave_xor(active ? col_bits(a) : 0u);
           if (lane == 0) L.csum[s * W2B_NDWMAX + wave] = cs;
@@ -841,7 +841,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
         const int nr = I.St->next_row;
         const bool is_uc = (uc_n > 0 && I.uc_row[0] == nr) || (uc_n > 1 && I.uc_row[1] == nr);
         apre_row = (nr >= 0 && !(deferred && nr == d_row) && !is_uc) ? nr : -1;
-        if (apre_row >= 0 && active) apre = load_col<VEC, MM>(P.u, apre_row, P.dim, col0);
+        if (apre_row >= 0 && active) apre = load_col<VEC, MM>(P.u, apre_row, P.dim, col0, P.tab_bytes);
       } else {
         if (n_ret <= W2B_RCH && n_adm <= W2B_RCH) {
           window_exchange<VEC, MM>(P, I, n_ret, n_adm, active, col0, lane, wave);

@@ -148,6 +148,10 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.jump_c = t->jump_c;
   p.table_magic = t->table_size > 1 ? (unsigned long long)((((unsigned __int128)1) << 64) / (unsigned __int128)t->table_size) : 0;
   p.window_magic = t->cfg.window > 1 ? (unsigned long long)((((unsigned __int128)1) << 64) / (unsigned __int128)t->cfg.window) : 0;
+  {
+    const unsigned long long bytes = (unsigned long long)t->table_elems * sizeof(float);
+    p.tab_bytes = bytes < 0x7fffffffull ? (unsigned)bytes : 0u;   // signed 32-bit scalar offsets
+  }
   p.vocab_size = t->cfg.vocab_size;
   p.train_words = t->cfg.train_words;
   p.iter = t->cfg.iter;
