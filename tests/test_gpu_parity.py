@@ -90,6 +90,9 @@ def quantized(x, bitlevel):
     (30, 2, 1, 3, 0.0),        # degenerate bitlevel 3 (+-0)
     (1200, 2, 3, 2, 0.0),      # > 1024 floats: 5-wave workgroup
     (36, 40, 70, 1, 0.0),      # window > 32 and negative > 63: multi-trip list building
+    (8, 1, 0, 0, 0.0),         # -negative 0: the centre word is the only target (ref :450 runs d = 0 only)
+    (2, 1, 1, 1, 0.0),         # two-float rows
+    (1, 3, 2, 2, 0.0),         # one-float rows
 ])
 def test_single_step_parity_collision_free(gpu, D, window, negative, bitlevel, reg):
     n = 24

@@ -41,6 +41,7 @@ def setup(V, ids, D, window, negative, bitlevel, sample, iters, num_threads=1, f
     (1, 1e-3, 200, 8, 24),
     (0, 1e-3, 200, 8, 24),
     (2, 0.0, 100, 3, 7),
+    (1, 1e-3, 32, 1, 0),       # -window 1 -negative 0
 ])
 @pytest.mark.parametrize("window_cache", [True, False])
 def test_single_worker_short_horizon_tight(gpu, bitlevel, sample, D, window, negative, window_cache):

@@ -4,6 +4,7 @@ OUT=gpurun_out/s13
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --tb=short 2>&1 | grep -E "^E  |^tests/|passed|failed|Error" | cut -c1-260
 echo "== bench default"; timeout 1200 python bench.py > $OUT/bench_default.log 2>$OUT/bench_default.err; tail -1 $OUT/bench_default.log | cut -c1-400
 form=worker; K=k_train_workers2
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_stats_$form -o r01 -- python $R/bench.py --form $form --steps 8 --warmup 2 --cpu-baseline none --also-relaxed 0 > $R/$OUT/rocprof_stats_$form.log 2>&1)
