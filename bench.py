@@ -230,8 +230,11 @@ def main():
     cdf = zipf_cdf(torch, V, dev, args.ids == "uniform")
     stream = draw_ids(torch, cdf, per_rank_tokens, gen)
     stream[999::1000] = 0                        # "</s>" every 1000 tokens
-    counts = torch.bincount(stream.long(), minlength=V).clamp_(min=1).cpu().numpy().astype(np.int64)
-    train_words = int(counts.sum())
+    counts_t = torch.bincount(stream.long(), minlength=V)
+    if world > 1:                                 # one vocabulary for all replicas: global word counts
+        dist.all_reduce(counts_t)
+    counts = counts_t.clamp_(min=1).cpu().numpy().astype(np.int64)
+    train_words = int(counts.sum()) // world      # per-rank share; the trainer gets the global number below
 
     props = torch.cuda.get_device_properties(dev)
     ncu = props.multi_processor_count

@@ -5,7 +5,8 @@
 // compute_accuracy evaluator runs unchanged on the result.  What differs is where the work
 // happens: the corpus is tokenised once on the host (word2bits_corpus.h) and every epoch is a
 // sequence of GPU launches in which each of the -threads Hogwild workers is one workgroup.
-// GPU-only additions use new flag names: -gpus, -positions, -device, -table-size, -relaxed.
+// GPU-only additions use new flag names: -gpus, -sync-every, -positions, -device, -table-size, -relaxed,
+// -window-cache.
 #include <pthread.h>
 #include <unistd.h>
 
@@ -29,7 +30,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   float alpha = 0.05f, sample = 1e-3f, reg = 0.f;
   // GPU-only
   int gpus = 1, device = 0;
-  long long sync_every = 0;            // positions per worker between replica syncs (0: once per launch)
+  long long sync_every = 8;            // -gpus > 1: launches between two replica exchanges
   long long positions = 4096;          // sentence positions per worker per launch
   long long table_size = W2B_UNIGRAM_TABLE_SIZE;
   int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
@@ -216,6 +217,7 @@ int main(int argc, char **argv) {
     for (auto &r : reps) CK(w2b_epoch_begin(r.t));             // pthread_create, ref :535
     double last_loss = 0, epoch_loss = 0;
     bool finished = false;
+    long long launches = 0;
     while (!finished) {
       for (auto &r : reps) CK(w2b_train_step(r.t, o.positions));
       finished = true;
@@ -233,7 +235,9 @@ int main(int argc, char **argv) {
         alpha = a;
         epoch_loss += l;
       }
-      if (o.gpus > 1) {                                       // replicas: periodic all-reduce over xGMI
+      launches++;
+      if (o.gpus > 1 && (finished || launches % (o.sync_every > 0 ? o.sync_every : 1) == 0)) {
+        // replicas: periodic delta-sum all-reduce of [u||v] over RCCL (and always at the end of an epoch)
         std::vector<pthread_t> th(o.gpus);
         auto sync = [](void *p) -> void * { CK(w2b_sync_replicas((w2b_trainer *)p, 0)); CK(w2b_synchronize((w2b_trainer *)p)); return nullptr; };
         for (int g = 0; g < o.gpus; g++) pthread_create(&th[g], nullptr, sync, reps[g].t);
