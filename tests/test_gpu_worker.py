@@ -151,7 +151,11 @@ def test_shard_override_and_multi_worker_bookkeeping(gpu, window_cache):
 def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, window, negative, bitlevel):
     """The LDS-resident window is an optimisation, not a different algorithm: with one worker nobody else
     touches a resident row, so the exact fp32 value is written back and the whole model must come out
-    BIT-IDENTICAL to the plain kernel (same launches, same dot-product reduction tree)."""
+    BIT-IDENTICAL to the plain kernel (same launches, same dot-product reduction tree).  The register-resident
+    hot target rows are switched off here: they reorder the targets of a chunk (hot rows first), which changes
+    the rounding of the error sum -- their parity is covered by the oracle tests above."""
+    import os
+    os.environ["W2B_HOT_ROWS"] = "0"
     V, n = 300, 6000
     rng = np.random.default_rng(9)
     ids = token_stream(rng, V, n, line=23)          # short sentences: many window fills/flushes
@@ -170,6 +174,7 @@ def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, wind
         u, v = t.get_model()
         out.append((u, v, loss, t.epoch_status()[1]))
         t.close()
+    os.environ.pop("W2B_HOT_ROWS", None)
     for k in (1, 2):
         assert out[0][3] == out[k][3]
         assert np.array_equal(out[0][0].view(np.uint32), out[k][0].view(np.uint32))

@@ -228,7 +228,7 @@ __device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int neg
 // Lane-parallel compares on register copies (v_readlane broadcasts) instead of O(n^2) LDS loops.
 template <int T, typename IP>
 __device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP ctx, IP umult, int cw,
-                                          int lane, bool with_dep = false) {
+                                          int lane, bool with_dep = false, bool hot_first = false) {
   W2B_WAVE_SYNC();
   for (int i0 = 0; i0 < nt; i0 += 64) {
     const int i = i0 + lane;
@@ -271,6 +271,24 @@ __device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP c
         const int i = i0 + lane;
         dep |= (__ballot((i < end) && (prev[i] >= 0)) != 0ull) ? 1 : 0;
       }
+    }
+    if (hot_first && end - start <= 64) {
+      // Hot-row placement (sentence-resident kernel): inside a chunk the register-resident rows 1 and 2 of v
+      // move to slots 0 / 1, so the data wavefronts test for them at two compile-time slots only.  Bit 30 of
+      // an entry carries its label (the centre word may move away from list index 0).  A chunk never holds
+      // a row twice, so at most one entry each.
+      const int i = start + lane;
+      const bool in = i < end;
+      int ent = in ? tgt[i] : 0;
+      if (in && i == 0) ent |= 1 << 30;
+      const int row = ent & 0x3fffffff;
+      const bool is1 = in && row == 1, is2 = in && row == 2;
+      const int has1 = __ballot(is1) != 0ull, has2 = __ballot(is2) != 0ull;
+      const unsigned long long mcold = __ballot(in && !is1 && !is2);
+      const int pos = is1 ? 0 : (is2 ? has1 : has1 + has2 + __popcll(mcold & lane_lt_mask(lane)));
+      W2B_WAVE_SYNC();
+      if (in) tgt[start + pos] = ent;
+      W2B_WAVE_SYNC();
     }
     if (lane == 0) cend[k] = end | (dep << 16);
     k++;

@@ -51,6 +51,7 @@ struct W2bParams {
   int dim, window, negative, bitlevel, num_threads;
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
   int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
+  int hot_rows;                   // sentence-resident kernel: keep rows 1 and 2 of v in registers (0 = off)
   float starting_alpha, sample, reg;
 };
 

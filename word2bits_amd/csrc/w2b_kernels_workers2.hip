@@ -79,7 +79,7 @@ __host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negati
   const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
   size_t b = (size_t)S * dim * 4 + (size_t)S * dim * 2;            // win + dlt
   b = (b + 15) & ~(size_t)15;
-  b += (size_t)S * W2B_NDWMAX * 4;                                 // csum
+  b += (size_t)(S + 2) * W2B_NDWMAX * 4;                           // csum (window slots + 2 hot target rows)
   b += 2 * W2B_T2MAX * W2B_NDWMAX * 4;                             // red
   b += (size_t)(3 * w2_round4(S) + maxt + w2_round4(W2B_MAX_SEN)) * 4;               // slot tables, prev, sen
   b += 2 * ((size_t)(4 * w2_round4(S + 2) + maxc + 4 + 2 * maxt) * 4 + sizeof(Step2));  // step lists x 2
@@ -95,7 +95,7 @@ __device__ __forceinline__ Win2 carve_win2(W2B_LDS int *base, int dim, int windo
   L.win = (W2B_LDS float *)p; p += (size_t)S * dim * 4;
   L.dlt = (W2B_LDS __half *)p; p += (size_t)S * dim * 2;
   p = (W2B_LDS char *)(((unsigned)(size_t)p + 15u) & ~15u);
-  L.csum = (W2B_LDS unsigned *)p; p += (size_t)S * W2B_NDWMAX * 4;
+  L.csum = (W2B_LDS unsigned *)p; p += (size_t)(S + 2) * W2B_NDWMAX * 4;
   L.red = (W2B_LDS float *)p; p += 2 * W2B_T2MAX * W2B_NDWMAX * 4;
   W2B_LDS int *q = (W2B_LDS int *)p;
   L.slot_row = q; q += w2_round4(S);
@@ -251,6 +251,40 @@ __device__ __forceinline__ void window_admit(const W2bParams &P, const Win2 &L, 
   }
 }
 
+// The hottest target rows (rows 1 and 2 of v: the vocabulary is sorted by frequency) live in REGISTERS of the
+// worker, value + accumulated delta, and are merged with memory every W2B_HOT_PERIOD steps with the same
+// exact-or-merge rule as the window rows.  Coherent accesses to one embedding row serialise at its memory
+// line (about 7 M read-modify-writes per second); on Zipf-distributed ids the most frequent word alone is a
+// target of 0.3 centre words in every position, which capped the whole GPU at 23 M words/s.  The producer
+// places these rows at slots 0 / 1 of a chunk (prep_lists, hot_first), so only those two slots test for them.
+#define W2B_HOT_PERIOD 32
+template <int VEC> struct HotV { Col<VEC> v0, v1, d0, d1; int on; };
+
+template <int VEC, int MM>
+__device__ __forceinline__ void hot_merge(const W2bParams &P, const Win2 &L, HotV<VEC> &H, int NS, bool active,
+                                          int col0, int lane, int wave) {
+  if (!H.on) return;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    if (k + 1 >= P.vocab_size) break;
+    Col<VEC> &val = k ? H.v1 : H.v0;
+    Col<VEC> &del = k ? H.d1 : H.d0;
+    Col<VEC> g;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) g.e[e] = 0.f;
+    if (active) g = load_col<VEC, MM>(P.v, k + 1, P.dim, col0, P.tab_bytes);
+    const unsigned now = wave_xor(active ? col_bits(g) : 0u);
+    const bool untouched = (now == L.csum[(NS + k) * W2B_NDWMAX + wave]);
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < VEC; e++) { val.e[e] = untouched ? val.e[e] : g.e[e] + del.e[e]; del.e[e] = 0.f; }
+      store_col<VEC, MM>(P.v, k + 1, P.dim, col0, val, P.tab_bytes);
+    }
+    const unsigned cs = wave_xor(active ? col_bits(val) : 0u);
+    if (lane == 0) L.csum[(NS + k) * W2B_NDWMAX + wave] = cs;
+  }
+}
+
 #ifdef W2B_PHASE_TIMERS
 #define W2B_TICK2(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); \
     atomicAdd(&P.shared->dbg[k], n_ - t2_); t2_ = n_; } } while (0)
@@ -324,7 +358,8 @@ __device__ __forceinline__ void window_exchange(const W2bParams &P, const Win2 &
 template <int QM, int VEC, bool LOSS, int MM>
 __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L, const QParam &qp, const int ndw,
                                               const int cw,
-                                              const int nt, const int uc_n, const float alpha, double &loss_acc) {
+                                              const int nt, const int uc_n, const float alpha, double &loss_acc,
+                                              HotV<VEC> &H) {
   constexpr int W2B_T2 = T2For<VEC>::value;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = ndw;   // data wavefronts 0..ndw-1
   const int dim = P.dim, col0 = tid * VEC;
@@ -339,14 +374,19 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
   Col<VEC> xa[W2B_T2], xb[W2B_T2];
   int ra[W2B_T2], rb[W2B_T2];
   auto load_chunk = [&](Col<VEC> (&X)[W2B_T2], int (&Rw)[W2B_T2], const int s, const int e) {
-    const int mine = L.tgt[min(s + lane, nt - 1)];
+    const int mine = L.tgt[min(s + lane, nt - 1)] & 0x3fffffff;    // bit 30 = label, see prep_lists
 #pragma unroll
     for (int i = 0; i < W2B_T2; i++) Rw[i] = __builtin_amdgcn_readlane(mine, i);
 #pragma unroll
     for (int i = 0; i < W2B_T2; i++) {
 #pragma unroll
       for (int ee = 0; ee < VEC; ee++) X[i].e[ee] = 0.f;
-      if (active && s + i < e) X[i] = load_col<VEC, MM>(P.v, Rw[i], dim, col0, P.tab_bytes);
+      if (active && s + i < e) {
+        // the register-resident hot rows can only sit at slot 0 (row 1 or 2) or slot 1 (row 2)
+        if (i == 0 && H.on && Rw[i] == 1) X[i] = H.v0;
+        else if (i <= 1 && H.on && Rw[i] == 2) X[i] = H.v1;
+        else X[i] = load_col<VEC, MM>(P.v, Rw[i], dim, col0, P.tab_bytes);
+      }
     }
   };
   int start = 0, chunk = 0, end = L.cend[0] & 0xffff;
@@ -424,7 +464,8 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
       // 16-byte-column wavefronts, so that a single worker reproduces the plain kernel bit for bit
       for (int w = 0; w < nwaves; w += 2)
         f += red[lane * W2B_NDWMAX + w] + ((w + 1 < nwaves) ? red[lane * W2B_NDWMAX + w + 1] : 0.f);
-      const float label = (start + lane == 0) ? 1.f : 0.f;
+      // the centre word: entry bit 30 when the producer reorders chunks (hot rows first), else list index 0
+      const float label = (H.on ? ((L.tgt[start + lane] >> 30) & 1) : (start + lane == 0)) ? 1.f : 0.f;
       float g;
       if (f > 6.f) g = (label - 1.f) * alpha;
       else if (f < -6.f) g = label * alpha;
@@ -452,6 +493,7 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
       if (i < n) {
         const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
         if (active) {
+          float dd[VEC];
 #pragma unroll
           for (int e = 0; e < VEC; e++) {
             float xv = x[i].e[e];
@@ -459,9 +501,20 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
             // row alive since the dot product (halves the register footprint of a chunk)
             if (QM != 0) asm volatile("" : "+v"(xv));
             err.e[e] += g * quant<QM>(xv, qp);
-            x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
+            dd[e] = g * avg.e[e] - ar2 * xv;
+            x[i].e[e] = xv + dd[e];
           }
-          store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i], P.tab_bytes);
+          if (i == 0 && H.on && rows[i] == 1) {
+            H.v0 = x[i];
+#pragma unroll
+            for (int e = 0; e < VEC; e++) H.d0.e[e] += dd[e];
+          } else if (i <= 1 && H.on && rows[i] == 2) {
+            H.v1 = x[i];
+#pragma unroll
+            for (int e = 0; e < VEC; e++) H.d1.e[e] += dd[e];
+          } else {
+            store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i], P.tab_bytes);
+          }
         }
       }
     }
@@ -586,6 +639,17 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
 #pragma unroll
   for (int e = 0; e < VEC; e++) apre.e[e] = 0.f;
   int apre_row = -1;
+  // data-wavefront registers: the two hottest target rows (value + delta)
+  HotV<VEC> H;
+  H.on = P.hot_rows;
+#pragma unroll
+  for (int e = 0; e < VEC; e++) { H.v0.e[e] = 0.f; H.v1.e[e] = 0.f; H.d0.e[e] = 0.f; H.d1.e[e] = 0.f; }
+  if (!producer && H.on) {
+    if (active) H.v0 = load_col<VEC, MM>(P.v, 1, P.dim, col0, P.tab_bytes);
+    if (active && P.vocab_size > 2) H.v1 = load_col<VEC, MM>(P.v, 2, P.dim, col0, P.tab_bytes);
+    const unsigned c0 = wave_xor(active ? col_bits(H.v0) : 0u), c1 = wave_xor(active ? col_bits(H.v1) : 0u);
+    if (lane == 0) { L.csum[(NS + 0) * W2B_NDWMAX + wave] = c0; L.csum[(NS + 1) * W2B_NDWMAX + wave] = c1; }
+  }
 
   // ---- the preparation of one pass (producer wavefront only; all 64 lanes, wave-uniform control flow)
   auto prepare = [&](const Win2 &O, const bool last) {
@@ -750,7 +814,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
                             : (alpha_pref_ok ? alpha_pref
                                              : __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT));
-          nck = prep_lists<T2For<VEC>::value, W2B_LDS int *>(O.tgt, L.prev, O.cend, nt, (W2B_LDS int *)nullptr, (W2B_LDS int *)nullptr, 0, lane, true);
+          nck = prep_lists<T2For<VEC>::value, W2B_LDS int *>(O.tgt, L.prev, O.cend, nt, (W2B_LDS int *)nullptr, (W2B_LDS int *)nullptr, 0, lane, true, P.hot_rows != 0);
         }
         const int nq = p + 1 + R;                                        // enters the window at the next step
         next_row = (p + 1 < sen_len && nq < sen_len) ? s_sen[nq] : -1;
@@ -853,7 +917,8 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
       }
       W2B_TICK(4);
       if (!stop && I.St->cw > 0)
-        process_word2<QM, VEC, LOSS, MM>(P, I, qp, NDW, I.St->cw, I.St->nt, I.St->uc_n, I.St->alpha, loss_acc);
+        process_word2<QM, VEC, LOSS, MM>(P, I, qp, NDW, I.St->cw, I.St->nt, I.St->uc_n, I.St->alpha, loss_acc, H);
+      if (stop || (it % W2B_HOT_PERIOD) == W2B_HOT_PERIOD - 1) hot_merge<VEC, MM>(P, L, H, NS, active, col0, lane, wave);
       if (deferred) retire_finish<VEC, MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
       W2B_TICK(5);
     }

@@ -163,6 +163,8 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.total_threads = t->cfg.total_threads > 0 ? t->cfg.total_threads : t->cfg.num_threads;
   p.mem_mode = t->cfg.relaxed_coherence;   // 0 coherent (sc1), 1 relaxed (plain); >1 experimental builds only
   if (const char *e = getenv("W2B_MEM_MODE")) p.mem_mode = atoi(e);
+  p.hot_rows = 1;
+  if (const char *e = getenv("W2B_HOT_ROWS")) p.hot_rows = atoi(e) != 0;
   p.starting_alpha = t->cfg.alpha;
   p.sample = t->cfg.sample;
   p.reg = t->cfg.reg;
