@@ -535,3 +535,43 @@ int w2bo_run(const char *train_file, const char *output_file, int bitlevel, int 
   w2bo_vocab_free(vb);
   return 0;
 }
+
+/* ------------------------------------------------------------------ evaluator numerics */
+
+/* src/compute-accuracy.c:106-110.  The evaluator carries its own copy of quantize (:26-61),
+ * identical to the trainer's; len accumulates in float, sqrt() is the double one applied to
+ * a float and stored back to float. */
+void w2bo_eval_normalize(float *M, long long words, long long size, int bitlevel, int fma) {
+  for (long long b = 0; b < words; b++) {
+    float *row = M + b * size;
+    for (long long a = 0; a < size; a++) row[a] = w2bo_quantize(row[a], bitlevel);
+    float len = 0;
+    for (long long a = 0; a < size; a++) len = fma ? fmaf(row[a], row[a], len) : len + row[a] * row[a];
+    len = (float)sqrt((double)len);
+    for (long long a = 0; a < size; a++) row[a] /= len;
+  }
+}
+
+/* src/compute-accuracy.c:146-177 (N = 1): bestd starts at 0, a candidate replaces it only when
+ * strictly greater, candidates are visited in row order, the three question rows are skipped. */
+void w2bo_eval_top1(const float *M, long long words, long long size, long long nq, const int *b1,
+                    const int *b2, const int *b3, int fma, int *best, float *bestd) {
+  float *vec = (float *)malloc(sizeof(float) * (size > 0 ? size : 1));
+  for (long long q = 0; q < nq; q++) {
+    for (long long a = 0; a < size; a++)
+      vec[a] = (M[a + b2[q] * size] - M[a + b1[q] * size]) + M[a + b3[q] * size];
+    float bd = 0;
+    int bi = -1;
+    for (long long c = 0; c < words; c++) {
+      if (c == b1[q] || c == b2[q] || c == b3[q]) continue;
+      const float *row = M + c * size;
+      float dist = 0;
+      if (fma) for (long long a = 0; a < size; a++) dist = fmaf(vec[a], row[a], dist);
+      else for (long long a = 0; a < size; a++) dist += vec[a] * row[a];
+      if (dist > bd) { bd = dist; bi = (int)c; }
+    }
+    best[q] = bi;
+    bestd[q] = bd;
+  }
+  free(vec);
+}

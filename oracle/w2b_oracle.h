@@ -112,6 +112,18 @@ int w2bo_run(const char *train_file, const char *output_file, int bitlevel, int 
              int negative, int num_threads, int iter, int min_count, float alpha, float sample,
              float reg, int binary, double *epoch_losses /*[iter] or NULL*/);
 
+/* ------------------------------------------------------------------ evaluator (src/compute-accuracy.c)
+ * Numerics of the analogy evaluator, restated; file parsing and the stdout transcript are
+ * restated in oracle/eval_oracle.py on top of these two.  `fma` != 0 evaluates every
+ * `acc += a * b` as one fused multiply-add (what the reference's Makefile:6 build does on an
+ * FMA host), fma == 0 as two roundings (the -ffp-contract=off build).  Both are pinned to the
+ * corresponding build of the unmodified evaluator (tests/golden/eval_*). */
+/* :106-110 : quantize again with the evaluator's bitlevel, then divide each row by its length */
+void w2bo_eval_normalize(float *M, long long words, long long size, int bitlevel, int fma);
+/* :146-177 with N = 1: best[q] = first c (not b1,b2,b3) with the largest dist > 0, or -1 */
+void w2bo_eval_top1(const float *M, long long words, long long size, long long nq, const int *b1,
+                    const int *b2, const int *b3, int fma, int *best, float *bestd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,88 @@
+"""not gpu: the evaluator oracle (oracle/eval_oracle.py + w2bo_eval_* in oracle/w2b_oracle.c) against the
+committed stdout of BOTH builds of the unmodified reference evaluator (tests/golden/eval_golden.json, made by
+tests/golden/make_eval_golden.py), and -- where /root/reference's binaries exist -- against live runs on fresh
+random inputs.  Also the no-GPU behaviour of the product evaluator."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import word2bits_amd as w2b
+from word2bits_amd import _lib
+from w2b_testlib import GOLDEN, ROOT, eval_oracle, ref_binary, write_vectors_file
+
+ALL = json.load(open(os.path.join(GOLDEN, "eval_golden.json")))
+RUNS = [g for g in ALL if "vectors" in g]
+
+
+def test_golden_set_is_discriminating():
+    """the fixture must separate the two arithmetic modes and contain right and wrong answers"""
+    by = {}
+    for g in RUNS:
+        by.setdefault((g["vectors"], g["bitlevel"], g["threshold"], g["questions"]), {})[g["build"]] = g["stdout"]
+    assert sum(len(set(v.values())) == 2 for v in by.values()) >= 2
+    assert any("ACCURACY TOP1: 4" in g["stdout"] for g in RUNS) and any("-nan" in g["stdout"] for g in RUNS)
+
+
+@pytest.mark.parametrize("build", ["compute_accuracy", "compute_accuracy_nofma"])
+def test_oracle_reproduces_reference_transcripts(build):
+    E = eval_oracle()
+    models = {}
+    n = 0
+    for g in RUNS:
+        if g["build"] != build:
+            continue
+        key = (g["vectors"], g["bitlevel"], g["threshold"])
+        if key not in models:
+            models[key] = E.EvalModel(os.path.join(GOLDEN, g["vectors"]), g["bitlevel"], g["threshold"],
+                                      fma=(build == "compute_accuracy"))
+        got = E.transcript(models[key], open(os.path.join(GOLDEN, g["questions"]), "rb").read())
+        assert got.decode("latin1") == g["stdout"], (g["vectors"], g["bitlevel"], g["threshold"], g["questions"])
+        n += 1
+    assert n == 24
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_oracle_matches_live_reference_on_fresh_inputs(seed, tmp_path):
+    exe = {b: ref_binary(b) for b in ("compute_accuracy", "compute_accuracy_nofma")}
+    if not all(exe.values()):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    E = eval_oracle()
+    rng = np.random.default_rng(seed)
+    V, D = 180, (16, 21)[seed - 1]
+    names = [b"</s>"] + [("w%d" % i).encode() for i in range(1, V)]
+    M = (rng.integers(0, 2, (V, D)) * 2 - 1).astype(np.float32) / np.float32(3) if seed == 1 \
+        else rng.standard_normal((V, D)).astype(np.float32)
+    vec = write_vectors_file(str(tmp_path / "v.bin"), names, M)
+    lines = []
+    for s in range(7):
+        lines.append(": s%d" % s)
+        for _ in range(30):
+            lines.append(" ".join("w%d" % i for i in rng.integers(1, V + 8, 4)))
+    q = ("\n".join(lines) + "\n").encode()
+    for build, fma in (("compute_accuracy", True), ("compute_accuracy_nofma", False)):
+        want = subprocess.run([exe[build], vec, "0", "0"], input=q, capture_output=True).stdout
+        got = E.transcript(E.EvalModel(vec, 0, 0, fma=fma), q)
+        assert got == want
+
+
+def test_product_evaluator_has_no_cpu_fallback():
+    if w2b.lib().w2b_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(w2b.W2bError) as e:
+        w2b.Evaluator(os.path.join(GOLDEN, "eval_1bit.bin"))
+    assert e.value.code == _lib.W2B_ENOGPU
+    with pytest.raises(w2b.W2bError) as e:
+        w2b.Evaluator(os.path.join(GOLDEN, "no_such_file.bin"))
+    assert e.value.code == _lib.W2B_EIO
+
+
+def test_cli_usage_and_missing_file_match_reference():
+    cli = os.path.join(ROOT, "compute_accuracy")
+    want = {g["cli"]: g for g in ALL if g.get("cli") and g["build"] == "compute_accuracy"}
+    r = subprocess.run([cli], capture_output=True)
+    assert (r.stdout.decode(), r.returncode) == (want["usage"]["stdout"], want["usage"]["returncode"])
+    r = subprocess.run([cli, os.path.join(GOLDEN, "no_such_file.bin")], capture_output=True, stdin=subprocess.DEVNULL)
+    assert (r.stdout.decode(), r.returncode) == (want["notfound"]["stdout"], want["notfound"]["returncode"])

@@ -1,0 +1,139 @@
+"""-m gpu: the MI355X analogy evaluator (include/word2bits_eval.h) through the C ABI against the evaluator oracle
+and against the committed stdout of both builds of the unmodified reference (tests/golden/eval_golden.json).
+Integer/index work and float scores alike are compared BIT-EXACTLY: the kernel keeps the reference's summation
+order and rounding (fused or not), so even massive ties resolve to the reference's answer."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import word2bits_amd as w2b
+from w2b_testlib import GOLDEN, ROOT, eval_oracle, write_vectors_file
+
+pytestmark = pytest.mark.gpu
+ALL = json.load(open(os.path.join(GOLDEN, "eval_golden.json")))
+RUNS = [g for g in ALL if "vectors" in g]
+CLI = os.path.join(ROOT, "compute_accuracy")
+
+
+def same_floats(a, b):
+    """bit-identical except that any NaN matches any NaN (x86 0/0 is -nan, the GPU's is +nan)"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    nan = np.isnan(a) & np.isnan(b)
+    return np.array_equal(a.view(np.uint32)[~nan], b.view(np.uint32)[~nan]) and np.array_equal(np.isnan(a), np.isnan(b))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("vec,bitlevel,threshold", [("eval_1bit.bin", 0, 0), ("eval_1bit.bin", 0, 100),
+                                                    ("eval_fp.bin", 0, 0), ("eval_fp.bin", 1, 0),
+                                                    ("eval_fp.bin", 2, 0), ("eval_fp.bin", 4, 0),
+                                                    ("eval_fp.bin", 3, 150), ("eval_fp.bin", 8, 0)])
+def test_load_normalise_and_top1_bit_exact_on_fixtures(gpu, vec, bitlevel, threshold, fused):
+    E = eval_oracle()
+    path = os.path.join(GOLDEN, vec)
+    om = E.EvalModel(path, bitlevel, threshold, fma=fused)
+    ev = w2b.Evaluator(path, bitlevel, threshold, fused=fused)
+    assert (ev.words, ev.size) == (om.words, om.size)
+    assert [ev.word(i) for i in range(ev.words)] == om.names
+    for w in (b"THE", b"X" * 50, b"Y" * 50, b"NOPE", b"</S>"):
+        assert ev.lookup(w) == om.lookup(w)
+    assert same_floats(ev.matrix(), om.M)
+    rng = np.random.default_rng(5)
+    b = rng.integers(0, ev.words, (3, 400)).astype(np.int32)
+    b[:, :20] = b[0, :20]                      # b1 == b2 == b3
+    got, gd = ev.top1(*b)
+    want, wd = om.top1(*b)
+    assert np.array_equal(got, want)
+    assert same_floats(gd, wd)
+    ev.close()
+
+
+@pytest.mark.parametrize("build", ["compute_accuracy", "compute_accuracy_nofma"])
+def test_transcripts_equal_reference_stdout(gpu, build):
+    evs = {}
+    for g in RUNS:
+        if g["build"] != build:
+            continue
+        key = (g["vectors"], g["bitlevel"], g["threshold"])
+        if key not in evs:
+            evs[key] = w2b.Evaluator(os.path.join(GOLDEN, g["vectors"]), g["bitlevel"], g["threshold"],
+                                     fused=(build == "compute_accuracy"))
+        got = evs[key].transcript(open(os.path.join(GOLDEN, g["questions"]), "rb").read())
+        assert got.decode("latin1") == g["stdout"], key + (g["questions"],)
+    for e in evs.values():
+        e.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("kind,V,D,Q", [("1bit", 3000, 200, 700), ("2bit", 1500, 400, 300), ("fp", 5000, 300, 300),
+                                        ("fp", 777, 1000, 130), ("1bit", 129, 5, 257)])
+def test_top1_bit_exact_on_seeded_inputs(gpu, kind, V, D, Q, fused, tmp_path):
+    """sizes that cross tile edges (rows % 128, questions % 128, size % 16 all != 0) and the question-row
+    exclusions; 1-bit / 2-bit inputs tie on most questions"""
+    E = eval_oracle()
+    rng = np.random.default_rng(V + D)
+    if kind == "1bit":
+        M = (rng.integers(0, 2, (V, D)) * 2 - 1).astype(np.float32) / np.float32(3)
+    elif kind == "2bit":
+        M = (rng.choice([.25, .75], (V, D)) * rng.choice([-1, 1], (V, D))).astype(np.float32)
+    else:
+        M = (rng.standard_normal((V, D)) * rng.choice([1e-3, 1, 30], (V, 1))).astype(np.float32)
+    names = [("w%d" % i).encode() for i in range(V)]
+    path = write_vectors_file(str(tmp_path / "v.bin"), names, M)
+    om, ev = E.EvalModel(path, 0, 0, fma=fused), w2b.Evaluator(path, 0, 0, fused=fused)
+    assert same_floats(ev.matrix(), om.M)
+    b = rng.integers(0, V, (3, Q)).astype(np.int32)
+    got, gd = ev.top1(*b)
+    want, wd = om.top1(*b)
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    assert same_floats(gd, wd)
+    if kind != "fp":
+        # the fixture really is tie-dominated: the best score is shared by several rows for most questions
+        q = 0
+        vec = (om.M[b[1, q]] - om.M[b[0, q]]) + om.M[b[2, q]]
+        assert (np.abs(om.M @ vec - wd[q]) < 1e-6).sum() >= 1
+    ev.close()
+
+
+def test_full_size_properties(gpu, tmp_path):
+    """text8-sized vocabulary (60238 x 200, 1-bit), 70000 questions (two launches): answers that are known
+    without a reference.  For b1 == b2 the query is exactly row b3, so the best row is the lowest-numbered
+    duplicate of row b3 when one is planted (score |row|^2, strictly above every non-identical row), and
+    running the same questions twice or in a different order gives the same answers."""
+    V, D, Q = 60238, 200, 70000
+    rng = np.random.default_rng(11)
+    M = (rng.integers(0, 2, (V, D)) * 2 - 1).astype(np.float32) / np.float32(3)
+    dup_src = rng.choice(np.arange(1000, V), 500, replace=False)
+    dup_dst = np.arange(200, 700)
+    M[dup_dst] = M[dup_src]                       # rows 200..699 are copies of later rows
+    names = [("w%d" % i).encode() for i in range(V)]
+    path = write_vectors_file(str(tmp_path / "v.bin"), names, M)
+    ev = w2b.Evaluator(path, 0, 0)
+    x = rng.integers(0, V, Q).astype(np.int32)
+    b3 = rng.choice(dup_src, Q).astype(np.int32)
+    best, bestd = ev.top1(x, x, b3)
+    where = {int(s): int(d) for s, d in zip(dup_src, dup_dst)}
+    want = np.array([where[int(s)] for s in b3], np.int32)
+    ok = x != want                                # the duplicate itself may be an excluded question row
+    assert np.array_equal(best[ok], want[ok])
+    assert np.all(bestd[ok] > 0.99) and np.all(bestd[ok] < 1.01)
+    perm = rng.permutation(Q)
+    best2, bestd2 = ev.top1(x[perm], x[perm], b3[perm])
+    assert np.array_equal(best2, best[perm]) and np.array_equal(bestd2.view(np.uint32), bestd[perm].view(np.uint32))
+    ms, launches, macs = ev.timing()
+    assert launches == 4 and ms > 0 and macs >= 2.0 * Q * V * D
+    ev.close()
+
+
+def test_cli_stdout_equals_reference(gpu):
+    for g in RUNS:
+        if g["questions"] == "eval_q_empty.txt" or g["bitlevel"] not in (0, 2):
+            continue
+        args = [CLI, os.path.join(GOLDEN, g["vectors"]), str(g["bitlevel"]), str(g["threshold"])]
+        if g["build"] == "compute_accuracy_nofma":
+            args.append("nofma")
+        r = subprocess.run(args, stdin=open(os.path.join(GOLDEN, g["questions"]), "rb"), capture_output=True)
+        assert r.returncode == 0, r.stderr[-300:]
+        assert r.stdout.decode("latin1") == g["stdout"], args

@@ -233,3 +233,22 @@ def read_vectors(path, binary):
         assert data[pos:pos + 1] == b"\n"
         pos += 1
     return words, M
+
+
+def eval_oracle():
+    """oracle/eval_oracle.py (the CPU restatement of the reference evaluator) as a module; builds the C part."""
+    import importlib.util
+    build_oracle()
+    spec = importlib.util.spec_from_file_location("eval_oracle", os.path.join(ORACLE_DIR, "eval_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def write_vectors_file(path, names, M):
+    """the binary writer's format (ref src/word2bits.cpp:560-576): 'V D\\n', then 'word ' + D float32 + '\\n'."""
+    with open(path, "wb") as f:
+        f.write(b"%d %d\n" % M.shape)
+        for n, row in zip(names, M):
+            f.write(n + b" " + np.asarray(row, "<f4").tobytes() + b"\n")
+    return path

@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI in include/word2bits_hip.h and include/word2bits_corpus.h.
+"""ctypes binding of the C ABI in include/word2bits_hip.h, word2bits_corpus.h and word2bits_eval.h.
 
 The shared library is built in-tree by word2bits_amd/csrc/Makefile (hipcc, gfx950).  Importing
 this module fails loudly when it is missing: there is no Python/CPU fallback for the hot path.
@@ -84,6 +84,18 @@ SIGNATURES = {
     "w2b_corpus_tokens": (i32p, [vp]),
     "w2b_corpus_shards": (C.c_int, [vp, C.c_int32, i64p, i32p]),
     "w2b_save_vectors": (C.c_int, [C.c_char_p, vp, f32p, C.c_int64, C.c_int32]),
+    # include/word2bits_eval.h
+    "w2b_eval_load": (C.c_int, [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(vp)]),
+    "w2b_eval_free": (None, [vp]),
+    "w2b_eval_words": (C.c_int64, [vp]),
+    "w2b_eval_size": (C.c_int64, [vp]),
+    "w2b_eval_word": (C.c_char_p, [vp, C.c_int64]),
+    "w2b_eval_lookup": (C.c_int64, [vp, C.c_char_p]),
+    "w2b_eval_get_matrix": (C.c_int, [vp, f32p]),
+    "w2b_eval_top1": (C.c_int, [vp, C.c_int64, i32p, i32p, i32p, i32p, f32p]),
+    "w2b_eval_transcript": (C.c_int, [vp, C.c_char_p, C.c_int64, C.POINTER(vp), i64p]),
+    "w2b_eval_free_text": (None, [vp]),
+    "w2b_eval_timing_read": (C.c_int, [vp, f64p, i64p, f64p]),
 }
 
 _lib = None

@@ -18,6 +18,8 @@ static int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
 }
+// shared with the other host translation units of the library (w2b_eval.cpp)
+int w2b_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
 #define HIPCHK(x)                                                                         \
   do {                                                                                    \
     hipError_t e_ = (x);                                                                  \
