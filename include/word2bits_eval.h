@@ -4,8 +4,9 @@
  * Replaces the reference's evaluator program, src/compute-accuracy.c (`compute_accuracy <FILE> <bitlevel>
  * <threshold> < questions-words.txt`), whose whole cost is the exhaustive scan of ref :158-177: for every
  * question a [1 x D] . [D x V] product over the normalised matrix followed by a strict-greater arg-max.
- * On the GPU that scan is one batched, register-tiled fp32 product (all questions x all rows) with the arg-max
- * fused into its epilogue (word2bits_amd/csrc/w2b_kernels_eval.hip).
+ * On the GPU that scan is one batched fp32 product (all questions x all rows) with the arg-max fused into its
+ * epilogue (word2bits_amd/csrc/w2b_kernels_eval.hip): on the matrix cores (f32 MFMA = sequential fmaf chains,
+ * bit for bit) in fused mode, on the vector ALU (packed mul + add) in the two-rounding mode.
  *
  * Parity contract: answers -- and therefore the stdout transcript -- are IDENTICAL to the reference's, ties
  * included.  Every score is accumulated in the reference's order (a = 0 .. size-1, one accumulator per

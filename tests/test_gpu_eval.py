@@ -137,3 +137,28 @@ def test_cli_stdout_equals_reference(gpu):
         r = subprocess.run(args, stdin=open(os.path.join(GOLDEN, g["questions"]), "rb"), capture_output=True)
         assert r.returncode == 0, r.stderr[-300:]
         assert r.stdout.decode("latin1") == g["stdout"], args
+
+
+@pytest.mark.parametrize("bitlevel", [1, 2])
+def test_train_then_evaluate_end_to_end(gpu, bitlevel, tmp_path):
+    """./word2bits (GPU) -> vectors file -> ./compute_accuracy (GPU): the evaluator's stdout on really trained,
+    quantized vectors equals the CPU restatement's (and the unmodified reference evaluator's where its binary
+    travelled), and the planted analogies are actually found."""
+    from planted import make_planted, parse_accuracy
+    from w2b_testlib import ref_binary
+    corpus, questions, out = (str(tmp_path / n) for n in ("c.txt", "q.txt", "v.bin"))
+    make_planted(corpus, questions, sections=8, pairs=12, repeats=60, seed=3)
+    r = subprocess.run([os.path.join(ROOT, "word2bits"), "-train", corpus, "-output", out, "-bitlevel", str(bitlevel),
+                        "-size", "200", "-window", "8", "-negative", "24", "-threads", "64", "-iter", "5",
+                        "-min-count", "5", "-binary", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    qs = open(questions, "rb").read()
+    got = subprocess.run([CLI, out, "0", "0"], input=qs, capture_output=True)
+    assert got.returncode == 0, got.stderr[-300:]
+    E = eval_oracle()
+    assert got.stdout == E.transcript(E.EvalModel(out, 0, 0, fma=True), qs)
+    exe = ref_binary("compute_accuracy")
+    if exe:
+        assert got.stdout == subprocess.run([exe, out, "0", "0"], input=qs, capture_output=True).stdout
+    acc = parse_accuracy(got.stdout.decode())
+    assert acc["seen"] == acc["questions"] == 8 * 12 * 11 and acc["total"] > 5.0, acc

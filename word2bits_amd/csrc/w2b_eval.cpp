@@ -15,7 +15,7 @@
 
 namespace {
 constexpr int64_t kMaxW = 50;            // ref :24 max_w
-constexpr int64_t kTile = 128;           // rows / questions per workgroup tile (w2b_kernels_eval.hip)
+constexpr int64_t kTile = 256;           // padding unit of rows / questions (covers both kernels' tiles)
 constexpr int64_t kChunkQ = 1 << 16;     // questions per launch
 
 inline bool is_space(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }   // isspace, C locale
@@ -34,6 +34,7 @@ struct w2b_eval {
   hipStream_t stream = nullptr;
   int64_t words = 0, size = 0, ld = 0, rows_padded = 0;
   int fused = 1;
+  int variant = 1;                                      // W2B_EVAL_KERNEL=0: vector-ALU kernel also in fused mode (default: MFMA)
   std::vector<char> vocab;                              // flat [words * max_w] (+ slack), as ref :88
   std::unordered_map<std::string, int64_t> first;       // upper-cased word -> first row (ref :140)
   float *M = nullptr;                                   // [rows_padded][ld], zero padded, normalised
@@ -106,6 +107,7 @@ extern "C" int w2b_eval_load(const char *file, int32_t bitlevel, int64_t thresho
   e->words = words;
   e->size = size;
   e->fused = fused ? 1 : 0;
+  if (const char *env = getenv("W2B_EVAL_KERNEL")) e->variant = atoi(env);   // 0 vector ALU; 1 MFMA (default grouping); >1 MFMA with that many question tiles per row tile
   e->ld = (size + 15) / 16 * 16;
   e->rows_padded = (words + kTile - 1) / kTile * kTile;
   if (e->rows_padded == 0) e->rows_padded = kTile;
@@ -204,13 +206,13 @@ extern "C" int w2b_eval_top1(w2b_eval *e, int64_t nq, const int32_t *b1, const i
     EHIP(hipMemcpyAsync(d3, b3 + q0, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
     EHIP(hipMemsetAsync(e->Q, 0, (size_t)np * e->ld * 4, e->stream));
     EHIP(hipMemsetAsync(e->best, 0, (size_t)np * 8, e->stream));
-    EHIP(w2b_launch_eval_queries(e->M, e->ld, n, d1, d2, d3, e->Q, e->stream));
+    EHIP(w2b_launch_eval_queries(e->M, e->ld, n, d1, d2, d3, e->Q, e->variant, e->stream));
     hipEvent_t t0, t1;
     EHIP(hipEventCreate(&t0));
     EHIP(hipEventCreate(&t1));
     EHIP(hipEventRecord(t0, e->stream));
     EHIP(w2b_launch_eval_scores(e->Q, e->M, (int)n, (int)e->words, (int)e->ld, e->fused, d1, d2, d3, e->best,
-                                e->stream));
+                                e->variant, e->stream));
     EHIP(hipEventRecord(t1, e->stream));
     e->ev.push_back(t0);
     e->ev.push_back(t1);
