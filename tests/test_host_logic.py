@@ -149,3 +149,39 @@ def test_cli_argument_handling_like_reference(tmp_path):
     assert "Starting training using file %s" % CORPUS in r.stdout
     assert "Vocab size: %d" % m["vocab_size"] in r.stdout
     assert "Words in train file: %d" % m["train_words"] in r.stdout
+
+
+def test_text_writer_equals_printf_lf(tmp_path):
+    """ref :571 prints every value with fprintf("%lf "); the product formats in integer arithmetic (320 M values
+    at cfg2).  Same bytes as libc's printf on ties (k/128 -> half-to-even), denormals, -0, huge values, inf, nan."""
+    import ctypes.util
+    libc = C.CDLL(ctypes.util.find_library("c"))
+    libc.snprintf.restype = C.c_int
+    c = w2b.Corpus(CORPUS, 1)
+    V, D = c.vocab_size, 3000
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 2**32, V * D, dtype=np.uint64).astype(np.uint32).view(np.float32).copy()   # any bit pattern
+    x[:4000] = (rng.integers(-10**6, 10**6, 4000) / 128.0).astype(np.float32)                       # exact ties
+    x[4000:8000] = rng.standard_normal(4000).astype(np.float32) * np.float32(0.3)
+    x[8000:8016] = [0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 1e-45, -1e-45, 2.0**31, -2.0**31, 2.0**31 - 128,
+                    3.4e38, 0.0000005, 0.0000015, 1 / 3, -1 / 3]
+    x[8016:12000] = (rng.integers(0, 2**24, 3984) * 2.0 ** rng.integers(-30, 8, 3984)).astype(np.float32)
+    out = str(tmp_path / "t.vec")
+    _lib.check(w2b.lib().w2b_save_vectors(out.encode(), c._h, x.ctypes.data_as(_lib.f32p), D, 0))
+    lines = open(out, "rb").read().split(b"\n")
+    assert lines[0] == b"%d %d" % (V, D)
+    buf = C.create_string_buffer(128)
+    k = 0
+    for a in range(V):
+        toks = lines[1 + a].split(b" ")
+        assert toks[0] == c.words()[a].encode() and toks[-1] == b"" and len(toks) == D + 2
+        for b in range(D):
+            v = float(x[k])
+            if np.isfinite(v) and abs(v) < 1e15:
+                want = b"%f" % v                      # Python's %f == glibc's %lf for finite doubles
+            else:
+                libc.snprintf(buf, 128, b"%lf", C.c_double(v))
+                want = buf.value
+            assert toks[1 + b] == want, (k, v, toks[1 + b], want)
+            k += 1
+    c.close()

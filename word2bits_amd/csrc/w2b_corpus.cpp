@@ -239,6 +239,44 @@ extern "C" int w2b_corpus_shards(const w2b_corpus *c, int32_t num_threads, int64
   return W2B_OK;
 }
 
+// "%lf " of one float, exactly as glibc prints it (the value is exact in binary, printf rounds the exact decimal
+// expansion half-to-even at 6 decimals), without going through printf: the text form of a cfg2 model is 320 M
+// values (ref :571 calls fprintf once per value).  |x| < 2^31 is done in integer arithmetic: x = m * 2^e, so
+// x * 10^6 = (m * 10^6) * 2^e with m * 10^6 < 2^44; everything else (huge, inf, nan) falls back to snprintf.
+static inline char *format_lf(char *p, float x) {
+  uint32_t bits;
+  memcpy(&bits, &x, 4);
+  const uint32_t ex = (bits >> 23) & 0xFF, frac = bits & 0x7FFFFF;
+  if (ex >= 127 + 31) return p + snprintf(p, 64, "%lf ", (double)x);    // >= 2^31, inf, nan
+  const uint64_t m = ex ? (uint64_t)(frac | 0x800000) : frac;               // denormals: no hidden bit
+  const int e = (ex ? (int)ex : 1) - 127 - 23;                               // x = m * 2^e
+  const uint64_t scaled = m * 1000000ull;
+  uint64_t q;
+  if (e >= 0) {
+    q = scaled << e;
+  } else if (-e >= 64) {
+    q = 0;                                                                   // < 2^44 / 2^64: far below one half
+  } else {
+    const int sh = -e;
+    q = scaled >> sh;
+    const uint64_t rem = scaled & ((1ull << sh) - 1), halfway = 1ull << (sh - 1);
+    if (rem > halfway || (rem == halfway && (q & 1))) q++;                   // round half to even
+  }
+  if (bits >> 31) *p++ = '-';                                                // also "-0.000000"
+  const uint64_t ip = q / 1000000ull;
+  uint32_t fp = (uint32_t)(q % 1000000ull);
+  char tmp[24];
+  int n = 0;
+  uint64_t t = ip;
+  do { tmp[n++] = (char)('0' + t % 10); t /= 10; } while (t);
+  while (n) *p++ = tmp[--n];
+  *p++ = '.';
+  for (int i = 5; i >= 0; i--) { p[i] = (char)('0' + fp % 10); fp /= 10; }
+  p += 6;
+  *p++ = ' ';
+  return p;
+}
+
 extern "C" int w2b_save_vectors(const char *path, const w2b_corpus *c, const float *values, int64_t dim,
                                 int32_t binary) {
   if (!path || !c || !values) return W2B_EINVAL;
@@ -248,12 +286,19 @@ extern "C" int w2b_save_vectors(const char *path, const w2b_corpus *c, const flo
   setvbuf(fo, big, _IOFBF, sizeof big);
   const int64_t V = (int64_t)c->words.size();
   fprintf(fo, "%lld %lld\n", (long long)V, (long long)dim);
+  std::vector<char> line;
+  if (!binary) line.resize((size_t)dim * 64 + 64);
   for (int64_t a = 0; a < V; a++) {
     fputs(c->words[a].c_str(), fo);
     fputc(' ', fo);
     const float *row = values + a * dim;
-    if (binary) fwrite(row, sizeof(float), (size_t)dim, fo);
-    else for (int64_t b = 0; b < dim; b++) fprintf(fo, "%lf ", row[b]);
+    if (binary) {
+      fwrite(row, sizeof(float), (size_t)dim, fo);
+    } else {                                                                 // ref :571  fprintf(fo, "%lf ", ...)
+      char *p = line.data();
+      for (int64_t b = 0; b < dim; b++) p = format_lf(p, row[b]);
+      fwrite(line.data(), 1, (size_t)(p - line.data()), fo);
+    }
     fputc('\n', fo);
   }
   return fclose(fo) == 0 ? W2B_OK : W2B_EIO;
