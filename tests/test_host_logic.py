@@ -43,7 +43,11 @@ def test_config_struct_layout_matches_header():
 
 
 @pytest.mark.parametrize("min_count", [1, 2, 5])
-def test_corpus_ingest_matches_oracle_and_reference(min_count, tmp_path):
+@pytest.mark.parametrize("host_split", [None, (8, 1000), (64, 64)])
+def test_corpus_ingest_matches_oracle_and_reference(min_count, host_split, tmp_path, monkeypatch):
+    if host_split:   # force the parallel ingest to cut the small test files into pieces
+        monkeypatch.setenv("W2B_INGEST_THREADS", str(host_split[0]))
+        monkeypatch.setenv("W2B_INGEST_MIN_PIECE", str(host_split[1]))
     O = oracle()
     for path in (CORPUS, write_corpus(str(tmp_path / "c.txt"), seed=5, vocab=400, n_tokens=20000)):
         c = w2b.Corpus(path, min_count)

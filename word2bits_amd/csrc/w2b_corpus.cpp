@@ -13,13 +13,16 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
 
 constexpr int kMaxWord = 4096;          // MAX_STRING, ref :29
-constexpr int64_t kCheckpointEvery = 1 << 15;
+constexpr int64_t kCheckpointEvery = 1 << 12;
 
 struct Reader {                          // byte cursor over the mapped file
   const unsigned char *buf;
@@ -142,23 +145,89 @@ extern "C" int w2b_corpus_load(const char *train_file, int32_t min_count, w2b_co
     if (m == MAP_FAILED) { w2b_corpus_free(c); return W2B_EIO; }
     c->map = (const unsigned char *)m;
   }
-  // ---- pass 1: count (ref :277-293).  "</s>" is vocabulary entry 0 from the start (ref :276).
+  // ---- pass 1, parallel: the file is cut at token boundaries (right after a ' ', '\t' or '\n': the reader's
+  // state there is "no word open", so every piece tokenises exactly like the sequential scan) and each host
+  // thread tokenises and counts its piece into a private table (ref :277-293 per piece).
+  int nthreads = (int)std::thread::hardware_concurrency();
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 32) nthreads = 32;     // the merge below is serial in (pieces x distinct words per piece)
+  int64_t min_piece = 4 << 20;
+  if (const char *e = getenv("W2B_INGEST_THREADS")) nthreads = std::max(1, atoi(e));
+  if (const char *e = getenv("W2B_INGEST_MIN_PIECE")) min_piece = std::max<int64_t>(1, atoll(e));
+  const int npieces = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, c->file_size / min_piece));
+  std::vector<int64_t> cut(npieces + 1, c->file_size);
+  cut[0] = 0;
+  for (int t = 1; t < npieces; t++) {
+    int64_t p = std::max(cut[t - 1], c->file_size / npieces * t);
+    while (p < c->file_size && p > 0 && !(c->map[p - 1] == ' ' || c->map[p - 1] == '\t' || c->map[p - 1] == '\n')) p++;
+    cut[t] = p;
+  }
+  struct Piece {
+    StringMap seen;                       // private first-appearance ids
+    std::vector<int64_t> cn;
+    std::vector<int32_t> raw;             // private id of every raw token
+    std::vector<int64_t> cp_raw, cp_byte; // every kCheckpointEvery-th raw token: its index and first byte
+    std::vector<int32_t> to_final;        // private id -> final vocabulary id (-1: dropped)
+    std::vector<int32_t> out;             // in-vocabulary tokens of the piece
+    std::vector<int64_t> cp_index;        // in-vocabulary tokens of the piece before each checkpoint
+  };
+  std::vector<Piece> pieces(npieces);
+  const bool timing = getenv("W2B_INGEST_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[ingest] %-18s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
+  auto run_parallel = [&](auto &&fn) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < npieces; t++) th.emplace_back(fn, t);
+    fn(0);
+    for (auto &x : th) x.join();
+  };
+  run_parallel([&](int t) {
+    Piece &P = pieces[t];
+    char word[kMaxWord];
+    int len;
+    int64_t begin = 0;
+    // a piece that is not the last one ends right after a separator, so treating its end as end-of-file never
+    // drops a word; the last piece has the real end-of-file semantics (ref :135-138,278-279)
+    Reader r{c->map, cut[t + 1], cut[t]};
+    while (next_token(r, word, len, begin)) {
+      const uint64_t h = fnv1a(word, len);
+      int32_t id = P.seen.hash.empty() ? -1 : P.seen.find(word, len, h);
+      if (id < 0) { id = P.seen.add(word, len, h); P.cn.push_back(0); }
+      P.cn[id]++;
+      if ((P.raw.size() % kCheckpointEvery) == 0) {
+        P.cp_raw.push_back((int64_t)P.raw.size());
+        P.cp_byte.push_back(begin);
+      }
+      P.raw.push_back(id);
+    }
+  });
+  lap("tokenise+count");
+  // ---- merge in file order: walking the pieces in order and each piece's words in its own first-appearance
+  // order reproduces the sequential first-appearance order, which is what breaks ties in SortVocab.
   StringMap seen;
   std::vector<int64_t> cn;
-  seen.add("</s>", 4, fnv1a("</s>", 4));
+  seen.add("</s>", 4, fnv1a("</s>", 4));      // "</s>" is vocabulary entry 0 from the start (ref :276)
   cn.push_back(0);
-  std::vector<int32_t> raw;               // first-appearance id of every raw token
-  char word[kMaxWord];
-  int len;
-  int64_t begin = 0;
-  Reader r{c->map, c->file_size, 0};
-  while (next_token(r, word, len, begin)) {
-    const uint64_t h = fnv1a(word, len);
-    int32_t id = seen.find(word, len, h);
-    if (id < 0) { id = seen.add(word, len, h); cn.push_back(0); }
-    cn[id]++;
-    raw.push_back(id);
+  std::vector<std::vector<int32_t>> to_global(npieces);
+  for (int t = 0; t < npieces; t++) {
+    Piece &P = pieces[t];
+    to_global[t].resize(P.cn.size());
+    for (size_t i = 0; i < P.cn.size(); i++) {
+      const char *w = P.seen.word((int32_t)i);
+      const int len = (int)strlen(w);
+      const uint64_t h = P.seen.hash[i];
+      int32_t id = seen.find(w, len, h);
+      if (id < 0) { id = seen.add(w, len, h); cn.push_back(0); }
+      cn[id] += P.cn[i];
+      to_global[t][i] = id;
+    }
   }
+  lap("merge");
   // ---- SortVocab (ref :215-242): "</s>" stays first, the rest by count descending.  glibc's qsort
   // is a merge sort for arrays of this size, i.e. ties keep first-appearance order: stable_sort.
   const int32_t nseen = (int32_t)cn.size();
@@ -177,19 +246,36 @@ extern "C" int w2b_corpus_load(const char *train_file, int32_t min_count, w2b_co
   for (size_t i = 0; i < c->words.size(); i++)
     c->final_map.add(c->words[i].c_str(), (int)c->words[i].size(),
                      fnv1a(c->words[i].c_str(), (int)c->words[i].size()));
-  // ---- pass 2: token stream + sparse byte index
-  c->tokens.reserve(raw.size());
-  r.pos = 0;
-  int64_t k = 0;
-  while (next_token(r, word, len, begin)) {
-    if ((k % kCheckpointEvery) == 0) {
-      c->cp_byte.push_back(begin);
-      c->cp_index.push_back((int64_t)c->tokens.size());
+  lap("sort+vocab");
+  // ---- pass 2, parallel, no second look at the text: private ids -> final ids, out-of-vocabulary words dropped
+  // (ref :398), plus the sparse (byte, token index) index used by the shard arithmetic
+  run_parallel([&](int t) {
+    Piece &P = pieces[t];
+    P.to_final.resize(P.cn.size());
+    for (size_t i = 0; i < P.cn.size(); i++) P.to_final[i] = remap[to_global[t][i]];
+    P.out.reserve(P.raw.size());
+    size_t cp = 0;
+    for (size_t k = 0; k < P.raw.size(); k++) {
+      if (cp < P.cp_raw.size() && (int64_t)k == P.cp_raw[cp]) { P.cp_index.push_back((int64_t)P.out.size()); cp++; }
+      const int32_t id = P.to_final[P.raw[k]];
+      if (id >= 0) P.out.push_back(id);
     }
-    const int32_t id = remap[raw[k]];
-    if (id >= 0) c->tokens.push_back(id);
-    k++;
-  }
+    std::vector<int32_t>().swap(P.raw);
+  });
+  lap("remap");
+  std::vector<int64_t> base(npieces + 1, 0);
+  for (int t = 0; t < npieces; t++) base[t + 1] = base[t] + (int64_t)pieces[t].out.size();
+  c->tokens.resize((size_t)base[npieces]);
+  run_parallel([&](int t) {
+    if (!pieces[t].out.empty())
+      memcpy(c->tokens.data() + base[t], pieces[t].out.data(), pieces[t].out.size() * sizeof(int32_t));
+  });
+  for (int t = 0; t < npieces; t++)
+    for (size_t i = 0; i < pieces[t].cp_byte.size(); i++) {
+      c->cp_byte.push_back(pieces[t].cp_byte[i]);
+      c->cp_index.push_back(base[t] + pieces[t].cp_index[i]);
+    }
+  lap("concat");
   *out = c;
   return W2B_OK;
 }
