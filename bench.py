@@ -345,16 +345,26 @@ def main():
         if world > 1:
             dist.barrier()
 
+    n_syncs = [0]
+
+    def exchange():
+        if torch_sync is not None:
+            t.synchronize()
+            torch_sync.sync(model_view, base_view)
+            torch.cuda.synchronize()
+        else:
+            t.sync_replicas(args.sync_mode)
+        n_syncs[0] += 1
+
     def run(n0, n1, timed):
+        # replicas exchange every --sync-every timed steps AND after the last timed step (the CLI also exchanges at
+        # every epoch end), so the timed region always contains the exchange, whatever --steps is
         for i in range(n0, n1):
             step(i)
-            if world > 1 and (i + 1 - args.warmup) % args.sync_every == 0 and i >= args.warmup:
-                if torch_sync is not None:
-                    t.synchronize()
-                    torch_sync.sync(model_view, base_view)
-                    torch.cuda.synchronize()
-                else:
-                    t.sync_replicas(args.sync_mode)
+            if world > 1 and timed:
+                done = i + 1 - args.warmup
+                if done % args.sync_every == 0 or i + 1 == n1:
+                    exchange()
 
     run(0, args.warmup, False)
     t.synchronize()
@@ -393,7 +403,8 @@ def main():
                    "row_coherence": "relaxed (plain cached accesses)" if args.relaxed else
                                     "agent scope (sc1): Hogwild coherent across the 8 XCD L2s",
                    "replica_sync": ("%s every %d steps, mode %d (0 = delta-sum)" %
-                                    (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl},
+                                    (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl,
+                   "exchanges_in_timed_region": n_syncs[0]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
                      "kernel": "k_train_tuples" if args.form == "tuples" else
