@@ -73,7 +73,13 @@ typedef struct w2b_config {
    * 0 = automatic (sentence-resident for coherent rows when the window fits in LDS, plain otherwise),
    * 1 = plain, 2 = sentence-resident whenever it fits. */
   int32_t plain_worker_kernel;
-  int32_t reserved[3];   /* must be zero */
+  /* 1: parity mode.  The dot product of ref :461-467 is accumulated serially in the reference's own order
+   * (c = 0 .. layer1_size-1, product rounded, then added) instead of the wavefront reduction tree -- the one
+   * place where the fast path re-associates.  With it a single-worker run (num_threads == 1) reproduces the
+   * CPU program built with -ffp-contract=off bit for bit: same u, v, same output file.  Implemented by the plain
+   * worker kernel and the tuple kernel with coherent rows; several times slower, not meant for throughput. */
+  int32_t exact_reduction;
+  int32_t reserved[2];   /* must be zero */
 } w2b_config;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -30,7 +30,7 @@ class Config(C.Structure):
         ("alpha", C.c_float), ("sample", C.c_float), ("reg", C.c_float),
         ("compute_loss", C.c_int32), ("device", C.c_int32),
         ("worker_offset", C.c_int32), ("total_threads", C.c_int32), ("relaxed_coherence", C.c_int32),
-        ("plain_worker_kernel", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("plain_worker_kernel", C.c_int32), ("exact_reduction", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 

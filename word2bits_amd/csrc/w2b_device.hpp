@@ -78,8 +78,13 @@ template <int VEC> struct Col { float e[VEC]; };
 // row is private to an XCD's L2 / a CU's L1 until it is evicted or the launch ends); 2 = nontemporal.
 // experimental: 2 = nontemporal (L1-bypassing, L2-cached) loads + sc1 write-through stores;
 //               3 = plain loads + sc1 write-through stores
+// MM 4 = coherent rows (as 0) + EXACT serial reduction: the dot product of ref :461-467 is accumulated in the
+// reference's own order (c = 0 .. D-1, one rounding per add) instead of the wavefront tree, which makes a
+// single-worker run bit-identical to the CPU program (w2b_config.exact_reduction; parity mode, not a fast path).
+#define W2B_MM_EXACT 4
+#define W2B_EXACT_COLS 256    // columns whose products sit in LDS at a time in the exact mode
 template <int MM> struct Aux {
-  static constexpr int load = (MM == 0) ? 16 : ((MM == 2) ? 2 : 0);
+  static constexpr int load = (MM == 0 || MM == W2B_MM_EXACT) ? 16 : ((MM == 2) ? 2 : 0);
   static constexpr int store = (MM == 1) ? 0 : 16;
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -200,6 +205,7 @@ struct WordLds {
   float *red;   // [2][W2B_T][W2B_MAXW] cross-wave partial dot products (double buffered)
   float *stash; // [W2B_STASH][blockDim][VEC] raw u columns of the first context rows, private to the
                 // owning thread: phase C updates them without a second trip to memory
+  float *xprod; // exact mode only: [W2B_T][W2B_EXACT_COLS + 1] products of the current column block
 };
 
 __device__ __forceinline__ int round4(int x) { return (x + 3) & ~3; }
@@ -216,6 +222,7 @@ __device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int neg
   L.tgt = p; p += maxt;
   L.prev = p; p += maxt;
   L.cend = p; p += maxt;
+  L.xprod = nullptr;   // set by the kernels that support the exact mode
   return L;
 }
 
@@ -382,12 +389,41 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
       p2[i] = active ? s2 : 0.f;
     }
     float *red = L.red + par * (TC * W2B_MAXW);
+    if (MM == W2B_MM_EXACT) {
+      // ref :461-467 in the reference's own order: f = 0; for c: f += context_avg[c] * quantize(v[c]) -- every
+      // product rounded, then added to the running sum.  The products of a block of columns go to LDS, lane i of
+      // wavefront 0 continues the chain of target i over them, block after block.
+      float fchain = 0.f;
+      for (int b0 = 0; b0 < dim; b0 += W2B_EXACT_COLS) {
+        if (active && col0 >= b0 && col0 < b0 + W2B_EXACT_COLS) {
 #pragma unroll
-    for (int i = 0; i < TC; i++) p[i] = wave_sum(p[i]);     // unconditional: W2B_T independent chains interleave
-    if (lane == 0) {
+          for (int i = 0; i < TC; i++)
+            if (i < n) {
 #pragma unroll
-      for (int i = 0; i < TC; i++)
-        if (i < n) red[i * W2B_MAXW + wave] = p[i];
+              for (int e = 0; e < VEC; e++)
+                L.xprod[i * (W2B_EXACT_COLS + 1) + (col0 - b0) + e] = avg.e[e] * quant<QM>(x[i].e[e], qp);
+            }
+        }
+        __syncthreads();
+        if (wave == 0 && lane < n) {
+          const int cnt = min(W2B_EXACT_COLS, dim - b0);
+          const float *src = L.xprod + lane * (W2B_EXACT_COLS + 1);
+          for (int c = 0; c < cnt; c++) fchain += src[c];
+        }
+        __syncthreads();
+      }
+      if (wave == 0 && lane < n) {
+        red[lane * W2B_MAXW] = fchain;
+        for (int w = 1; w < nwaves; w++) red[lane * W2B_MAXW + w] = 0.f;   // the sum below adds exact zeros
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TC; i++) p[i] = wave_sum(p[i]);     // unconditional: W2B_T independent chains interleave
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < TC; i++)
+          if (i < n) red[i * W2B_MAXW + wave] = p[i];
+      }
     }
     __syncthreads();
     // lane i of every wavefront: f_i, then g_i (ref :473-475)
@@ -573,6 +609,10 @@ hipError_t dispatch_q(int bitlevel, F &&f) {
 }
 
 
+// mem-mode dispatch for the kernels that implement the exact serial reduction (plain worker / tuple kernels)
+template <typename F>
+hipError_t dispatch_mm_exact(int mem_mode, int exact, F &&f);
+
 // mem-mode dispatch: f(std::integral_constant<int, MM>)
 template <typename F>
 hipError_t dispatch_mm(int mem_mode, F &&f) {
@@ -584,6 +624,12 @@ hipError_t dispatch_mm(int mem_mode, F &&f) {
 #endif
     default: return f(std::integral_constant<int, 0>());
   }
+}
+
+template <typename F>
+hipError_t dispatch_mm_exact(int mem_mode, int exact, F &&f) {
+  if (exact) return f(std::integral_constant<int, W2B_MM_EXACT>());
+  return dispatch_mm(mem_mode, f);
 }
 
 }  // namespace

@@ -52,13 +52,14 @@ struct W2bParams {
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
   int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
   int hot_rows;                   // sentence-resident kernel: keep rows 1 and 2 of v in registers (0 = off)
+  int exact;                      // serial dot product in the reference's order (plain worker / tuple kernels)
   float starting_alpha, sample, reg;
 };
 
 // launchers implemented in w2b_kernels.hip --------------------------------------------------------
 // block size chosen from dim: one thread per 16-byte (or 4-byte) column of a row
 int w2b_block_threads(int dim, int *vec_out);
-size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form);
+size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact = false);
 hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *center,
                              const int32_t *ctx_off, const int32_t *ctx, const int32_t *neg,
                              float alpha, int grid, int num_cus, int per_cu_override, bool loss,

@@ -11,8 +11,9 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
                                                       const int32_t *__restrict__ neg,
                                                       const float alpha) {
   extern __shared__ int smem[];
-  const WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
+  WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
   int *s_cnt = L.cend + round4(P.negative + 1);   // [0] cw, [1] nt
+  if (MM == W2B_MM_EXACT) L.xprod = reinterpret_cast<float *>(s_cnt + 4);
   const int tid = threadIdx.x, lane = tid & 63;
   QParam qp;
   qp.bitlevel = P.bitlevel;
@@ -70,8 +71,8 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
                              int per_cu_override, bool loss, hipStream_t s) {
   int vec;
   const int threads = w2b_block_threads(p.dim, &vec);
-  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, false);
-  return dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
+  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, false, p.exact != 0);
+  return dispatch_mm_exact(p.mem_mode, p.exact, [&](auto mm) -> hipError_t {
   constexpr int MM = decltype(mm)::value;
   return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
     constexpr int QM = decltype(qm)::value;

@@ -8,9 +8,10 @@ namespace {
 template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM>
 __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES : 1)) k_train_workers(const W2bParams P, const long long max_positions) {
   extern __shared__ int smem[];
-  const WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
+  WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
   int *s_sen = L.cend + round4(P.negative + 1);
   WorkerLds *S = reinterpret_cast<WorkerLds *>(s_sen + round4(W2B_MAX_SEN) + 4);
+  if (MM == W2B_MM_EXACT) L.xprod = reinterpret_cast<float *>(reinterpret_cast<int *>(S) + (sizeof(WorkerLds) + 3) / 4 + 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wid = blockIdx.x;
   if (wid >= P.num_threads) return;
@@ -133,9 +134,9 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
 int w2b_workers_per_cu(const W2bParams &p, bool loss) {
   int vec;
   const int threads = w2b_block_threads(p.dim, &vec);
-  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, true);
+  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, true, p.exact != 0);
   int nb = 0;
-  (void)dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
+  (void)dispatch_mm_exact(p.mem_mode, p.exact, [&](auto mm) -> hipError_t {
     constexpr int MM = decltype(mm)::value;
     return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
       constexpr int QM = decltype(qm)::value;
@@ -150,8 +151,8 @@ int w2b_workers_per_cu(const W2bParams &p, bool loss) {
 hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s) {
   int vec;
   const int threads = w2b_block_threads(p.dim, &vec);
-  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, true);
-  return dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
+  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, true, p.exact != 0);
+  return dispatch_mm_exact(p.mem_mode, p.exact, [&](auto mm) -> hipError_t {
   constexpr int MM = decltype(mm)::value;
   return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
     constexpr int QM = decltype(qm)::value;

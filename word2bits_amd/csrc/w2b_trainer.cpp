@@ -165,6 +165,8 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.total_threads = t->cfg.total_threads > 0 ? t->cfg.total_threads : t->cfg.num_threads;
   p.mem_mode = t->cfg.relaxed_coherence;   // 0 coherent (sc1), 1 relaxed (plain); >1 experimental builds only
   if (const char *e = getenv("W2B_MEM_MODE")) p.mem_mode = atoi(e);
+  p.exact = t->cfg.exact_reduction != 0;
+  if (p.exact) p.mem_mode = 0;             // the exact mode exists for coherent rows only
   p.hot_rows = 1;
   if (const char *e = getenv("W2B_HOT_ROWS")) p.hot_rows = atoi(e) != 0;
   p.starting_alpha = t->cfg.alpha;
@@ -486,7 +488,7 @@ extern "C" int w2b_epoch_begin(w2b_trainer *t) {
 static int worker_radius(const w2b_trainer *t) {
   int mode = t->cfg.plain_worker_kernel;
   if (const char *e = getenv("W2B_WORKER_KERNEL")) mode = atoi(e);
-  if (mode == 1) return -1;
+  if (mode == 1 || t->cfg.exact_reduction) return -1;   // the serial reduction lives in the plain kernel
   if (mode == 0 && t->cfg.relaxed_coherence) return -1;
   return w2b_window_radius(t->cfg.layer1_size, t->cfg.window, t->cfg.negative);
 }

@@ -35,6 +35,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   long long table_size = W2B_UNIGRAM_TABLE_SIZE;
   int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
   int window_cache = -1;               // -1 automatic, 0 plain worker kernel, 1 sentence-resident kernel
+  int exact = 0;                       // 1: serial dot product in the reference's order (bit parity at -threads 1)
 };
 
 // ArgPos, ref :579-589: exact-match search; a flag in last position has no value -> exit(1)
@@ -111,6 +112,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-table-size", argc, argv)) > 0) o.table_size = atoll(argv[i + 1]);
   if ((i = arg_pos("-relaxed", argc, argv)) > 0) o.relaxed = atoi(argv[i + 1]);
   if ((i = arg_pos("-window-cache", argc, argv)) > 0) o.window_cache = atoi(argv[i + 1]);
+  if ((i = arg_pos("-exact", argc, argv)) > 0) o.exact = atoi(argv[i + 1]);
 
   // ---- TrainModel, ref :518-577
   printf("Starting training using file %s\n", o.train_file.c_str());
@@ -145,6 +147,7 @@ int main(int argc, char **argv) {
     probe_cfg.alpha = o.alpha; probe_cfg.compute_loss = 1; probe_cfg.device = o.device;
     probe_cfg.relaxed_coherence = o.relaxed;
     probe_cfg.plain_worker_kernel = o.window_cache < 0 ? 0 : (o.window_cache ? 2 : 1);
+    probe_cfg.exact_reduction = o.exact;
     w2b_trainer *probe = nullptr;
     int32_t per_gpu = 1024;
     CK(w2b_trainer_create(&probe_cfg, &probe));
@@ -190,6 +193,7 @@ int main(int argc, char **argv) {
     cfg.worker_offset = a->r->index * a->per_gpu;             // worker_offset: global id of local worker 0
     cfg.relaxed_coherence = o.relaxed;
     cfg.plain_worker_kernel = o.window_cache < 0 ? 0 : (o.window_cache ? 2 : 1);
+    cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
     CK(w2b_init_net(a->r->t));                              // ref :528

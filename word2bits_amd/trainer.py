@@ -86,7 +86,7 @@ class Trainer:
 
     def __init__(self, vocab_size, layer1_size=100, window=5, negative=5, bitlevel=1, num_threads=12,
                  iter=5, alpha=0.05, sample=1e-3, reg=0.0, train_words=0, compute_loss=True, device=0,
-                 worker_offset=0, total_threads=0, relaxed_coherence=False, window_cache=None):
+                 worker_offset=0, total_threads=0, relaxed_coherence=False, window_cache=None, exact=False):
         cfg = Config()
         cfg.vocab_size, cfg.train_words, cfg.iter = int(vocab_size), int(train_words), int(iter)
         cfg.layer1_size, cfg.window, cfg.negative = int(layer1_size), int(window), int(negative)
@@ -97,6 +97,8 @@ class Trainer:
         cfg.relaxed_coherence = int(bool(relaxed_coherence))
         # window_cache: None = automatic, True = sentence-resident kernel whenever it fits, False = plain
         cfg.plain_worker_kernel = 0 if window_cache is None else (2 if window_cache else 1)
+        # exact: serial dot product in the reference's order -> a 1-worker run is bit-identical to the CPU program
+        cfg.exact_reduction = int(bool(exact))
         self.cfg = cfg
         self._h = _lib.vp()
         check(lib().w2b_trainer_create(C.byref(cfg), C.byref(self._h)))
@@ -249,13 +251,14 @@ def comm_unique_id():
 
 def train_model(train_file, output_file, bitlevel=1, size=100, window=5, negative=5, threads=12, iter=5,
                 min_count=5, alpha=0.05, sample=1e-3, reg=0.0, binary=0, table_size=100000000,
-                positions_per_launch=4096, device=0, verbose=False, relaxed_coherence=False, window_cache=None):
+                positions_per_launch=4096, device=0, verbose=False, relaxed_coherence=False, window_cache=None,
+                exact=False):
     """TrainModel (ref :518-577) on one GPU: vocab, InitNet, unigram table, `iter` epochs, save.
     Returns the list of epoch losses."""
     corpus = Corpus(train_file, min_count)
     t = Trainer(corpus.vocab_size, size, window, negative, bitlevel, threads, iter, alpha, sample, reg,
                 corpus.train_words, True, device, relaxed_coherence=relaxed_coherence,
-                window_cache=window_cache)
+                window_cache=window_cache, exact=exact)
     t.init_net()
     t.set_vocab_counts(corpus.counts(), table_size if negative > 0 else 0)
     t.set_corpus(corpus.tokens())
