@@ -94,13 +94,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // instead of a 4-SGPR descriptor per row (the kernels were close to issue-bound with as many SALU as VALU
 // instructions).  Lanes beyond the row are masked by the callers (`active`).  tab_bytes == 0 (tables >= 4 GiB,
 // e.g. V=3.7M x D=1000): per-row resource whose size is the row length.
-template <int VEC, int MM>
+// TB: -1 = decide at run time from tab_bytes; 0 / 1 = the caller's kernel was instantiated for tab_bytes != 0 / == 0
+// (the sentence-resident kernel: its instruction stream is the bottleneck, and the run-time form costs ~20 scalar
+// instructions and three branches per row access).
+template <int VEC, int MM, int TB = -1>
 __device__ __forceinline__ Col<VEC> load_col(const float *tab, long long row, int dim, int col0, unsigned tab_bytes) {
   Col<VEC> c;
   const int urow = __builtin_amdgcn_readfirstlane((int)row);
   __amdgpu_buffer_rsrc_t r;
   int soff;
-  if (tab_bytes) {
+  if (TB == 0 || (TB < 0 && tab_bytes)) {
     r = __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, (int)tab_bytes, 0x27000);
     soff = urow * dim * 4;
   } else {
@@ -119,13 +122,13 @@ __device__ __forceinline__ Col<VEC> load_col(const float *tab, long long row, in
   }
   return c;
 }
-template <int VEC, int MM>
+template <int VEC, int MM, int TB = -1>
 __device__ __forceinline__ void store_col(float *tab, long long row, int dim, int col0, const Col<VEC> &c,
                                           unsigned tab_bytes) {
   const int urow = __builtin_amdgcn_readfirstlane((int)row);
   __amdgpu_buffer_rsrc_t r;
   int soff;
-  if (tab_bytes) {
+  if (TB == 0 || (TB < 0 && tab_bytes)) {
     r = __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, (int)tab_bytes, 0x27000);
     soff = urow * dim * 4;
   } else {

@@ -201,7 +201,7 @@ __device__ __forceinline__ void window_retire(const W2bParams &P, const Win2 &L,
         if (active) {
           rw[i] = lds_ld<VEC>(L.win + s * dim + col0);
           rd[i] = lds_ldh<VEC>(L.dlt + s * dim + col0);
-          g[i] = load_col<VEC, MM>(P.u, L.ret_row[i0 + i], dim, col0, P.tab_bytes);
+          g[i] = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.ret_row[i0 + i], dim, col0, P.tab_bytes);
         }
       }
 #pragma unroll
@@ -214,7 +214,7 @@ __device__ __forceinline__ void window_retire(const W2bParams &P, const Win2 &L,
           Col<VEC> o;
 #pragma unroll
           for (int e = 0; e < VEC; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
-          store_col<VEC, MM>(P.u, L.ret_row[i0 + i], dim, col0, o, P.tab_bytes);
+          store_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.ret_row[i0 + i], dim, col0, o, P.tab_bytes);
         }
       }
   }
@@ -232,7 +232,7 @@ __device__ __forceinline__ void window_admit(const W2bParams &P, const Win2 &L, 
       if (i0 + i < n_adm) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) a[i].e[e] = 0.f;
-        if (active) a[i] = load_col<VEC, MM>(P.u, L.adm_row[i0 + i], dim, col0, P.tab_bytes);
+        if (active) a[i] = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.adm_row[i0 + i], dim, col0, P.tab_bytes);
       }
 #pragma unroll
     for (int i = 0; i < W2B_RCH; i++)
@@ -272,13 +272,13 @@ __device__ __forceinline__ void hot_merge(const W2bParams &P, const Win2 &L, Hot
     Col<VEC> g;
 #pragma unroll
     for (int e = 0; e < VEC; e++) g.e[e] = 0.f;
-    if (active) g = load_col<VEC, MM>(P.v, k + 1, P.dim, col0, P.tab_bytes);
+    if (active) g = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.v, k + 1, P.dim, col0, P.tab_bytes);
     const unsigned now = wave_xor(active ? col_bits(g) : 0u);
     const bool untouched = (now == L.csum[(NS + k) * W2B_NDWMAX + wave]);
     if (active) {
 #pragma unroll
       for (int e = 0; e < VEC; e++) { val.e[e] = untouched ? val.e[e] : g.e[e] + del.e[e]; del.e[e] = 0.f; }
-      store_col<VEC, MM>(P.v, k + 1, P.dim, col0, val, P.tab_bytes);
+      store_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.v, k + 1, P.dim, col0, val, P.tab_bytes);
     }
     const unsigned cs = wave_xor(active ? col_bits(val) : 0u);
     if (lane == 0) L.csum[(NS + k) * W2B_NDWMAX + wave] = cs;
@@ -301,7 +301,7 @@ __device__ __forceinline__ void retire_finish(const W2bParams &P, int row, unsig
     Col<VEC> o;
 #pragma unroll
     for (int e = 0; e < VEC; e++) o.e[e] = untouched ? rw.e[e] : g.e[e] + rd.e[e];
-    store_col<VEC, MM>(P.u, row, P.dim, col0, o, P.tab_bytes);
+    store_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, row, P.dim, col0, o, P.tab_bytes);
   }
 }
 
@@ -319,12 +319,12 @@ __device__ __forceinline__ void window_exchange(const W2bParams &P, const Win2 &
       const int s = L.ret_slot[i];
       rw[i] = lds_ld<VEC>(L.win + s * dim + col0);
       rd[i] = lds_ldh<VEC>(L.dlt + s * dim + col0);
-      g[i] = load_col<VEC, MM>(P.u, L.ret_row[i], dim, col0, P.tab_bytes);
+      g[i] = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.ret_row[i], dim, col0, P.tab_bytes);
     }
   }
 #pragma unroll
   for (int i = 0; i < W2B_RCH; i++)
-    if (active && i < n_adm) a[i] = load_col<VEC, MM>(P.u, L.adm_row[i], dim, col0, P.tab_bytes);
+    if (active && i < n_adm) a[i] = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.adm_row[i], dim, col0, P.tab_bytes);
 #pragma unroll
   for (int i = 0; i < W2B_RCH; i++)
     if (i < n_ret) {
@@ -335,7 +335,7 @@ __device__ __forceinline__ void window_exchange(const W2bParams &P, const Win2 &
         Col<VEC> o;
 #pragma unroll
         for (int e = 0; e < VEC; e++) o.e[e] = untouched ? rw[i].e[e] : g[i].e[e] + rd[i].e[e];
-        store_col<VEC, MM>(P.u, L.ret_row[i], dim, col0, o, P.tab_bytes);
+        store_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.ret_row[i], dim, col0, o, P.tab_bytes);
       }
     }
 #pragma unroll
@@ -378,14 +378,18 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
 #pragma unroll
     for (int i = 0; i < W2B_T2; i++) Rw[i] = __builtin_amdgcn_readlane(mine, i);
 #pragma unroll
-    for (int i = 0; i < W2B_T2; i++) {
+    for (int i = 0; i < W2B_T2; i++)
 #pragma unroll
       for (int ee = 0; ee < VEC; ee++) X[i].e[ee] = 0.f;
-      if (active && s + i < e) {
-        // the register-resident hot rows can only sit at slot 0 (row 1 or 2) or slot 1 (row 2)
-        if (i == 0 && H.on && Rw[i] == 1) X[i] = H.v0;
-        else if (i <= 1 && H.on && Rw[i] == 2) X[i] = H.v1;
-        else X[i] = load_col<VEC, MM>(P.v, Rw[i], dim, col0, P.tab_bytes);
+    if (active) {      // one exec mask for the whole chunk, not one per row
+#pragma unroll
+      for (int i = 0; i < W2B_T2; i++) {
+        if (s + i < e) {
+          // the register-resident hot rows can only sit at slot 0 (row 1 or 2) or slot 1 (row 2)
+          if (i == 0 && H.on && Rw[i] == 1) X[i] = H.v0;
+          else if (i <= 1 && H.on && Rw[i] == 2) X[i] = H.v1;
+          else X[i] = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.v, Rw[i], dim, col0, P.tab_bytes);
+        }
       }
     }
   };
@@ -395,8 +399,8 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
   Col<VEC> ur0, ur1;
 #pragma unroll
   for (int e = 0; e < VEC; e++) { ur0.e[e] = 0.f; ur1.e[e] = 0.f; }
-  if (active && uc_n > 0) ur0 = load_col<VEC, MM>(P.u, L.uc_row[0], dim, col0, P.tab_bytes);
-  if (active && uc_n > 1) ur1 = load_col<VEC, MM>(P.u, L.uc_row[1], dim, col0, P.tab_bytes);
+  if (active && uc_n > 0) ur0 = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.uc_row[0], dim, col0, P.tab_bytes);
+  if (active && uc_n > 1) ur1 = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.uc_row[1], dim, col0, P.tab_bytes);
 
   W2B_TICK2(6);
   // ---- phase A from LDS (ref :431-449), window order
@@ -488,11 +492,11 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
           if (lane == 0) loss_acc -= (double)(P.reg * s2);
         }
     }
+    if (active) {        // one exec mask for the whole update section, not one per row
 #pragma unroll
-    for (int i = 0; i < W2B_T2; i++) {
-      if (i < n) {
-        const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
-        if (active) {
+      for (int i = 0; i < W2B_T2; i++) {
+        if (i < n) {
+          const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
           float dd[VEC];
 #pragma unroll
           for (int e = 0; e < VEC; e++) {
@@ -513,7 +517,7 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
 #pragma unroll
             for (int e = 0; e < VEC; e++) H.d1.e[e] += dd[e];
           } else {
-            store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i], P.tab_bytes);
+            store_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.v, rows[i], dim, col0, x[i], P.tab_bytes);
           }
         }
       }
@@ -566,8 +570,8 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
         for (int e = 0; e < VEC; e++) ur1.e[e] = ur1.e[e] + (err.e[e] - ar2 * ur1.e[e]);
       }
     }
-    if (uc_n > 0) store_col<VEC, MM>(P.u, L.uc_row[0], dim, col0, ur0, P.tab_bytes);
-    if (uc_n > 1) store_col<VEC, MM>(P.u, L.uc_row[1], dim, col0, ur1, P.tab_bytes);
+    if (uc_n > 0) store_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.uc_row[0], dim, col0, ur0, P.tab_bytes);
+    if (uc_n > 1) store_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, L.uc_row[1], dim, col0, ur1, P.tab_bytes);
   }
   W2B_TICK2(9);
   if (LOSS && P.reg != 0.f) {
@@ -645,8 +649,8 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
 #pragma unroll
   for (int e = 0; e < VEC; e++) { H.v0.e[e] = 0.f; H.v1.e[e] = 0.f; H.d0.e[e] = 0.f; H.d1.e[e] = 0.f; }
   if (!producer && H.on) {
-    if (active) H.v0 = load_col<VEC, MM>(P.v, 1, P.dim, col0, P.tab_bytes);
-    if (active && P.vocab_size > 2) H.v1 = load_col<VEC, MM>(P.v, 2, P.dim, col0, P.tab_bytes);
+    if (active) H.v0 = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.v, 1, P.dim, col0, P.tab_bytes);
+    if (active && P.vocab_size > 2) H.v1 = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.v, 2, P.dim, col0, P.tab_bytes);
     const unsigned c0 = wave_xor(active ? col_bits(H.v0) : 0u), c1 = wave_xor(active ? col_bits(H.v1) : 0u);
     if (lane == 0) { L.csum[(NS + 0) * W2B_NDWMAX + wave] = c0; L.csum[(NS + 1) * W2B_NDWMAX + wave] = c1; }
   }
@@ -874,7 +878,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
           if (active) {
             d_rw = lds_ld<VEC>(L.win + s * P.dim + col0);
             d_rd = lds_ldh<VEC>(L.dlt + s * P.dim + col0);
-            d_g = load_col<VEC, MM>(P.u, d_row, P.dim, col0, P.tab_bytes);               // consumed after the step: no stall
+            d_g = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, d_row, P.dim, col0, P.tab_bytes);               // consumed after the step: no stall
           }
           deferred = true;
         }
@@ -884,7 +888,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
           if (row != apre_row) {
 #pragma unroll
             for (int e = 0; e < VEC; e++) a.e[e] = 0.f;
-            if (active) a = load_col<VEC, MM>(P.u, row, P.dim, col0, P.tab_bytes);
+            if (active) a = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, row, P.dim, col0, P.tab_bytes);
           }
           const unsigned cs = wave_xor(active ? col_bits(a) : 0u);
           if (lane == 0) L.csum[s * W2B_NDWMAX + wave] = cs;
@@ -905,7 +909,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
         const int nr = I.St->next_row;
         const bool is_uc = (uc_n > 0 && I.uc_row[0] == nr) || (uc_n > 1 && I.uc_row[1] == nr);
         apre_row = (nr >= 0 && !(deferred && nr == d_row) && !is_uc) ? nr : -1;
-        if (apre_row >= 0 && active) apre = load_col<VEC, MM>(P.u, apre_row, P.dim, col0, P.tab_bytes);
+        if (apre_row >= 0 && active) apre = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.u, apre_row, P.dim, col0, P.tab_bytes);
       } else {
         if (n_ret <= W2B_RCH && n_adm <= W2B_RCH) {
           window_exchange<VEC, MM>(P, I, n_ret, n_adm, active, col0, lane, wave);
@@ -984,8 +988,14 @@ hipError_t w2b_launch_workers2(const W2bParams &p, long long max_positions, int 
     constexpr int MM = decltype(mm)::value;
     return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
       constexpr int QM = decltype(qm)::value;
-      if (loss) hipLaunchKernelGGL((k_train_workers2<QM, 2, true, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
-      else hipLaunchKernelGGL((k_train_workers2<QM, 2, false, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
+      // template MM carries the memory mode in bits 0-2 and "tables >= 2 GiB" (per-row descriptors) in bit 3
+      if (p.tab_bytes) {
+        if (loss) hipLaunchKernelGGL((k_train_workers2<QM, 2, true, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
+        else hipLaunchKernelGGL((k_train_workers2<QM, 2, false, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
+      } else {
+        if (loss) hipLaunchKernelGGL((k_train_workers2<QM, 2, true, MM + 8>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
+        else hipLaunchKernelGGL((k_train_workers2<QM, 2, false, MM + 8>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
+      }
       return hipGetLastError();
     });
   });
