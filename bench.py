@@ -5,11 +5,13 @@ Workload (BASELINE.json configs[1]): synthetic 100M-token Zipf(1) stream, vocab=
 size=800, window=8, negative=24, sample=0, on one MI355X.  A "step" is ONE launch of the fused
 CBOW/negative-sampling update kernel over one batch of centre words:
 
-  --form tuples  (default) : 2^20 explicit (centre, 9 context rows, 24 negatives) tuples per step,
-                             SURVEY.md 8d / north_star "synthetic (center, context, K-negatives) tuples"
-  --form worker            : every Hogwild worker (workgroup) advances --positions sentence positions
+  --form worker  (default) : every Hogwild worker (workgroup) advances --positions sentence positions
                              of the resident token stream, drawing windows/negatives on device exactly
-                             like TrainModelThread (ref src/word2bits.cpp:363-516)
+                             like TrainModelThread (ref src/word2bits.cpp:363-516); 2^20 centre words per step
+  --form tuples            : 2^20 explicit (centre, 9 context rows, 24 negatives) tuples per step,
+                             SURVEY.md 8d / north_star "synthetic (center, context, K-negatives) tuples"
+  --form eval              : NOT the headline metric -- the analogy evaluator's scan (include/word2bits_eval.h,
+                             SURVEY.md 8 f4) with its own metric, roofline (fp32 MFMA) and CPU reference
 
 All inputs are resident in HBM before the timed region.  N>1: one process per GPU
 (torch.distributed.run), each rank trains its own shard (weak scaling) on its own replica and
@@ -24,6 +26,7 @@ Prints ONE JSON line on rank 0 (contract in the task description) with two extra
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -40,7 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--form", choices=["tuples", "worker"], default="worker")
+    ap.add_argument("--form", choices=["tuples", "worker", "eval"], default="worker",
+                    help="worker / tuples: the training hot path (the headline metric); eval: the analogy evaluator's "
+                         "scan (include/word2bits_eval.h), reported with its own metric")
     ap.add_argument("--vocab", type=int, default=400_000)
     ap.add_argument("--dim", type=int, default=800)
     ap.add_argument("--window", type=int, default=8)
@@ -71,6 +76,9 @@ def parse():
                          "LDS), 0 = plain kernel")
     ap.add_argument("--relaxed", type=int, default=0,
                     help="1: plain cached row accesses (not coherent between XCDs); default 0 = agent-scope (sc1)")
+    ap.add_argument("--eval-questions", type=int, default=19544, help="--form eval: questions (questions-words.txt)")
+    ap.add_argument("--eval-kind", choices=["1bit", "fp"], default="1bit")
+    ap.add_argument("--eval-cpu-questions", type=int, default=24)
     return ap.parse_args()
 
 
@@ -203,9 +211,77 @@ def cpu_baseline_port(args):
                       (n, V, D, args.window, args.negative, args.bitlevel, cores, dt)}
 
 
+# ------------------------------------------------------------------------------------------ --form eval
+def run_eval_form(args):
+    """The evaluator's scan: `steps` batched top-1 scans of --eval-questions questions over a
+    --vocab x --dim matrix resident in HBM (defaults of this form: text8-sized 60238 x 200, 1-bit).  One JSON line
+    in the shape of the contract; the unmodified reference evaluator (oracle/_ref/compute_accuracy) is timed
+    beside it on a bounded sample as `cpu_baseline`."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import word2bits_amd as w2b
+    from w2b_testlib import write_vectors_file, ref_binary
+    V = args.vocab if args.vocab != 400_000 else 60238      # text8' vocabulary (reference README.md:122-131)
+    D = args.dim if args.dim != 800 else 200
+    Q, steps, warmup = args.eval_questions, args.steps, max(1, args.warmup)
+    rng = np.random.default_rng(3)
+    M = ((rng.integers(0, 2, (V, D)) * 2 - 1).astype(np.float32) / np.float32(3)) if args.eval_kind == "1bit" \
+        else rng.standard_normal((V, D)).astype(np.float32)
+    path = write_vectors_file(os.path.join(tempfile.mkdtemp(), "v.bin"), [("w%d" % i).encode() for i in range(V)], M)
+    b = rng.integers(0, V, (3, Q)).astype(np.int32)
+    peak = {True: 78.6e12, False: 39.3e12}    # multiply-adds/s: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz / 2 (fused), /4
+    modes, answers = {}, {}
+    for fused in (True, False):
+        ev = w2b.Evaluator(path, 0, 0, fused=fused)
+        for _ in range(warmup):
+            ev.top1(*b)
+        ev.timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            answers[fused], _ = ev.top1(*b)
+        wall = (time.perf_counter() - t0) / steps
+        ms, launches, macs = ev.timing()
+        rate = macs / (ms * 1e-3)
+        modes[fused] = {"questions_per_s": Q / wall, "ms_per_step": wall * 1e3, "kernel_ms": ms / launches,
+                        "achieved": 2 * rate / 1e12, "peak": 2 * peak[fused] / 1e12, "frac": rate / peak[fused]}
+        ev.close()
+    f = modes[True]
+    result = {
+        "metric": "analogy questions/sec (exhaustive top-1 scan, vocab=%d dim=%d)" % (V, D),
+        "value": f["questions_per_s"], "unit": "questions/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": f["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "analogy scan: %d questions x %d rows x %d dims (%s vectors), arithmetic of the "
+                               "reference's stock (FMA) build" % (Q, V, D, args.eval_kind)},
+        "roofline": {"bound": "mfma", "achieved": f["achieved"], "peak": f["peak"], "unit": "TFLOP/s",
+                     "frac": f["frac"], "traffic": None, "kernel": "k_eval_scores_mfma", "avg_launch_ms": f["kernel_ms"]},
+        "two_rounding_mode": {"kernel": "k_eval_scores<false> (packed fp32 VALU)", **modes[False]},
+        "answers_differ_between_modes": int((answers[True] != answers[False]).sum()),
+    }
+    exe = ref_binary("compute_accuracy")
+    n = args.eval_cpu_questions
+    if exe and n > 0 and args.cpu_baseline != "none":
+        qs = ": s\n" + "".join("w%d w%d w%d w%d\n" % (b[0, i], b[1, i], b[2, i], b[2, i]) for i in range(n))
+        t0 = time.perf_counter()
+        subprocess.run([exe, path, "0", "0"], input=b"", capture_output=True)
+        t_load = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        subprocess.run([exe, path, "0", "0"], input=qs.encode(), capture_output=True)
+        t_all = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": n / max(t_all - t_load, 1e-9), "unit": "questions/s", "cores": 1,
+                                  "kind": "reference",
+                                  "sample": "%d questions through the unmodified evaluator (single-threaded program); "
+                                            "its load time (%.1f s) subtracted" % (n, t_load)}
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result), flush=True)
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
+    if args.form == "eval":
+        return run_eval_form(args)
     import torch
     import torch.distributed as dist
     import word2bits_amd as w2b

@@ -18,8 +18,8 @@ head -3 $OUT/prof_stats_$form/r01_kernel_stats.csv | cut -c1-250
 head -2 $OUT/prof_stats_relaxed/r01_kernel_stats.csv | cut -c1-250
 # the evaluator's scan (include/word2bits_eval.h)
 timeout 300 python tools/eval_bench.py 2>/dev/null | tail -1 > $OUT/eval_bench.json; cut -c1-300 $OUT/eval_bench.json
-W2B_EVAL_KERNEL=0 timeout 300 python tools/eval_bench.py --cpu-questions 0 2>/dev/null | tail -1 > $OUT/eval_bench_valu.json
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_eval -o r01 -- python $R/tools/eval_bench.py --cpu-questions 0 > /dev/null 2>&1)
+W2B_EVAL_KERNEL=0 timeout 300 python tools/eval_bench.py --eval-cpu-questions 0 2>/dev/null | tail -1 > $OUT/eval_bench_valu.json
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_eval -o r01 -- python $R/tools/eval_bench.py --eval-cpu-questions 0 > /dev/null 2>&1)
 head -3 $OUT/prof_eval/r01_kernel_stats.csv | cut -c1-200
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
 echo "== done"
