@@ -2,10 +2,10 @@
 trainer on the planted-analogy corpus, both scored by the UNMODIFIED reference evaluator
 (oracle/_ref/compute_accuracy).  Prints one JSON line per run.
 
-usage: python tools/accuracy_experiment.py [--bitlevel 1] [--size 200] [--iter 5] [--variants ,_sc1]
+usage: python tests/experiments/accuracy_experiment.py [--bitlevel 1] [--size 200] [--iter 5] [--variants ,_sc1]
 """
 import argparse, json, os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from planted import make_planted, parse_accuracy
 

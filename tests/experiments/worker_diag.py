@@ -1,7 +1,7 @@
 """Diagnostics (GPU box): drift of the HIP worker form from the bit-reference oracle, next to the
 drift between two builds of the oracle itself (FMA contraction on/off)."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import word2bits_amd as w2b
