@@ -368,8 +368,8 @@ extern "C" int w2b_save_vectors(const char *path, const w2b_corpus *c, const flo
   if (!path || !c || !values) return W2B_EINVAL;
   FILE *fo = fopen(path, "wb");
   if (!fo) return W2B_EIO;
-  static char big[1 << 20];
-  setvbuf(fo, big, _IOFBF, sizeof big);
+  std::vector<char> big(1 << 20);          // stdio buffer of this call (released after fclose)
+  setvbuf(fo, big.data(), _IOFBF, big.size());
   const int64_t V = (int64_t)c->words.size();
   fprintf(fo, "%lld %lld\n", (long long)V, (long long)dim);
   std::vector<char> line;

@@ -43,7 +43,7 @@ struct w2b_eval {
   int32_t *b123 = nullptr;
   unsigned long long *best = nullptr;
   int64_t cap_q = 0;
-  std::vector<hipEvent_t> ev;                           // start/stop pairs of the score kernel
+  double kernel_ms = 0;                                 // score-kernel time since the last timing_read
   int64_t launches = 0;
   double macs = 0;
 };
@@ -51,7 +51,6 @@ struct w2b_eval {
 static void eval_release(w2b_eval *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
   if (e->M) (void)hipFree(e->M);
   if (e->Q) (void)hipFree(e->Q);
   if (e->b123) (void)hipFree(e->b123);
@@ -211,16 +210,20 @@ extern "C" int w2b_eval_top1(w2b_eval *e, int64_t nq, const int32_t *b1, const i
     EHIP(hipEventCreate(&t0));
     EHIP(hipEventCreate(&t1));
     EHIP(hipEventRecord(t0, e->stream));
-    EHIP(w2b_launch_eval_scores(e->Q, e->M, (int)n, (int)e->words, (int)e->ld, e->fused, d1, d2, d3, e->best,
-                                e->variant, e->stream));
-    EHIP(hipEventRecord(t1, e->stream));
-    e->ev.push_back(t0);
-    e->ev.push_back(t1);
+    hipError_t le = w2b_launch_eval_scores(e->Q, e->M, (int)n, (int)e->words, (int)e->ld, e->fused, d1, d2, d3,
+                                           e->best, e->variant, e->stream);
+    if (le == hipSuccess) le = hipEventRecord(t1, e->stream);
+    keys.resize((size_t)n);
+    if (le == hipSuccess) le = hipMemcpyAsync(keys.data(), e->best, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
+    float ms = 0;
+    if (le == hipSuccess) le = hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (le != hipSuccess) return efail(W2B_EHIP, std::string("w2b_eval_top1: ") + hipGetErrorString(le));
+    e->kernel_ms += ms;
     e->launches++;
     e->macs += (double)np * (double)e->rows_padded * (double)e->ld;
-    keys.resize((size_t)n);
-    EHIP(hipMemcpyAsync(keys.data(), e->best, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
-    EHIP(hipStreamSynchronize(e->stream));
     for (int64_t q = 0; q < n; q++) {
       const unsigned long long k = keys[(size_t)q];
       best[q0 + q] = k ? (int32_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull)) : -1;
@@ -236,15 +239,8 @@ extern "C" int w2b_eval_top1(w2b_eval *e, int64_t nq, const int32_t *b1, const i
 extern "C" int w2b_eval_timing_read(w2b_eval *e, double *kernel_ms, int64_t *launches, double *macs) {
   if (!e) return efail(W2B_EINVAL, "w2b_eval_timing_read: null handle");
   EHIP(hipSetDevice(e->device));
-  EHIP(hipStreamSynchronize(e->stream));
-  double ms = 0;
-  for (size_t i = 0; i + 1 < e->ev.size(); i += 2) {
-    float t = 0;
-    EHIP(hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]));
-    ms += t;
-  }
-  for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
-  e->ev.clear();
+  const double ms = e->kernel_ms;
+  e->kernel_ms = 0;
   if (kernel_ms) *kernel_ms = ms;
   if (launches) *launches = e->launches;
   if (macs) *macs = e->macs;
