@@ -150,11 +150,12 @@ def test_train_then_evaluate_end_to_end(gpu, bitlevel, tmp_path):
     make_planted(corpus, questions, sections=8, pairs=12, repeats=60, seed=3)
     r = subprocess.run([os.path.join(ROOT, "word2bits"), "-train", corpus, "-output", out, "-bitlevel", str(bitlevel),
                         "-size", "200", "-window", "8", "-negative", "24", "-threads", "64", "-iter", "5",
-                        "-min-count", "5", "-binary", "1"], capture_output=True, text=True)
+                        "-min-count", "5", "-binary", "1", "-eval", questions], capture_output=True)
     assert r.returncode == 0, r.stderr[-300:]
     qs = open(questions, "rb").read()
     got = subprocess.run([CLI, out, "0", "0"], input=qs, capture_output=True)
     assert got.returncode == 0, got.stderr[-300:]
+    assert r.stdout.endswith(got.stdout)           # ./word2bits -eval prints the same transcript after training
     E = eval_oracle()
     assert got.stdout == E.transcript(E.EvalModel(out, 0, 0, fma=True), qs)
     exe = ref_binary("compute_accuracy")

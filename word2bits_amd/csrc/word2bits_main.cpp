@@ -6,7 +6,7 @@
 // happens: the corpus is tokenised once on the host (word2bits_corpus.h) and every epoch is a
 // sequence of GPU launches in which each of the -threads Hogwild workers is one workgroup.
 // GPU-only additions use new flag names: -gpus, -sync-every, -positions, -device, -table-size, -relaxed,
-// -window-cache.
+// -window-cache, -exact, -eval.
 #include <pthread.h>
 #include <unistd.h>
 
@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/word2bits_corpus.h"
+#include "../../include/word2bits_eval.h"
 #include "../../include/word2bits_hip.h"
 
 namespace {
@@ -36,6 +37,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
   int window_cache = -1;               // -1 automatic, 0 plain worker kernel, 1 sentence-resident kernel
   int exact = 0;                       // 1: serial dot product in the reference's order (bit parity at -threads 1)
+  std::string eval_file;               // -eval FILE: questions to score on the GPU after the final save (-binary 1)
 };
 
 // ArgPos, ref :579-589: exact-match search; a flag in last position has no value -> exit(1)
@@ -113,6 +115,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-relaxed", argc, argv)) > 0) o.relaxed = atoi(argv[i + 1]);
   if ((i = arg_pos("-window-cache", argc, argv)) > 0) o.window_cache = atoi(argv[i + 1]);
   if ((i = arg_pos("-exact", argc, argv)) > 0) o.exact = atoi(argv[i + 1]);
+  if ((i = arg_pos("-eval", argc, argv)) > 0) o.eval_file = argv[i + 1];
 
   // ---- TrainModel, ref :518-577
   printf("Starting training using file %s\n", o.train_file.c_str());
@@ -266,5 +269,34 @@ int main(int argc, char **argv) {
   save(o, corpus, reps[0].t, o.output_file);                  // ref :560-576
   for (auto &r : reps) w2b_trainer_destroy(r.t);
   w2b_corpus_free(corpus);
+  if (!o.eval_file.empty()) {
+    // what `compute_accuracy <output> 0 0 < FILE` prints, run on the GPU on the file just written (the evaluator
+    // -- the reference's too -- reads the binary format only)
+    if (!o.binary) {
+      fprintf(stderr, "word2bits: -eval needs -binary 1 (the evaluator reads the binary vector format)\n");
+      return 1;
+    }
+    FILE *qf = fopen(o.eval_file.c_str(), "rb");
+    if (!qf) {
+      fprintf(stderr, "word2bits: cannot open %s\n", o.eval_file.c_str());
+      return 1;
+    }
+    std::string qs;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, qf)) > 0) qs.append(buf, n);
+    fclose(qf);
+    w2b_eval *ev = nullptr;
+    char *txt = nullptr;
+    int64_t len = 0;
+    if (w2b_eval_load(o.output_file.c_str(), 0, 0, 1, o.device, &ev) != W2B_OK ||
+        w2b_eval_transcript(ev, qs.data(), (int64_t)qs.size(), &txt, &len) != W2B_OK) {
+      fprintf(stderr, "word2bits: -eval failed: %s\n", w2b_last_error());
+      return 1;
+    }
+    fwrite(txt, 1, (size_t)len, stdout);
+    w2b_eval_free_text(txt);
+    w2b_eval_free(ev);
+  }
   return 0;
 }
