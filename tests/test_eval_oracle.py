@@ -68,6 +68,33 @@ def test_oracle_matches_live_reference_on_fresh_inputs(seed, tmp_path):
         assert got == want
 
 
+@pytest.mark.parametrize("cut", ["in_name", "after_name", "float_boundary", "partial_float", "row_end"])
+def test_oracle_matches_live_reference_on_truncated_files(cut, tmp_path):
+    """a vector file that ends early (ref :96-105 keeps reading: EOF bytes become names, fread comes up short)"""
+    exe = ref_binary("compute_accuracy")
+    if not exe:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    E = eval_oracle()
+    rng = np.random.default_rng(5)
+    V, D = 30, 6
+    names = [b"</s>"] + [("w%d" % i).encode() for i in range(1, V)]
+    M = rng.standard_normal((V, D)).astype(np.float32)
+    vec = write_vectors_file(str(tmp_path / "v.bin"), names, M)
+    data = open(vec, "rb").read()
+    row20 = data.index(b"w20 ")
+    end = {"in_name": row20 + 2, "after_name": row20 + 4, "float_boundary": row20 + 4 + 8,
+           "partial_float": row20 + 4 + 10, "row_end": row20 + 4 + 4 * D}[cut]
+    open(vec, "wb").write(data[:end])
+    # questions only over rows that were read completely (the cut row's values are indeterminate in the reference)
+    q = (": s\n" + "".join("w%d w%d w%d w%d\n" % tuple(rng.integers(1, 20, 4)) for _ in range(40))).encode()
+    want = subprocess.run([exe, vec, "0", "20"], input=q, capture_output=True).stdout
+    got = E.transcript(E.EvalModel(vec, 0, 20, fma=True), q)
+    assert got == want
+    # the names the reader leaves behind for the rows after the cut
+    m = E.EvalModel(vec, 0, 0, fma=True)
+    assert m.words == V and m.names[19] == b"W19" and all(n == b"" for n in m.names[22:])
+
+
 def test_product_evaluator_has_no_cpu_fallback():
     if w2b.lib().w2b_device_count() > 0:
         pytest.skip("a GPU is visible")
@@ -86,3 +113,33 @@ def test_cli_usage_and_missing_file_match_reference():
     assert (r.stdout.decode(), r.returncode) == (want["usage"]["stdout"], want["usage"]["returncode"])
     r = subprocess.run([cli, os.path.join(GOLDEN, "no_such_file.bin")], capture_output=True, stdin=subprocess.DEVNULL)
     assert (r.stdout.decode(), r.returncode) == (want["notfound"]["stdout"], want["notfound"]["returncode"])
+
+
+def test_oracle_question_loop_matches_live_reference_fuzz(tmp_path):
+    """random token soups through the reference's scanf loop (ref :113-188) vs the oracle's restatement of it:
+    section markers anywhere, EXIT, unknown words, truncated questions, missing trailing white space"""
+    from hypothesis import given, settings, strategies as st
+    exe = ref_binary("compute_accuracy_nofma")
+    if not exe:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    E = eval_oracle()
+    rng = np.random.default_rng(77)
+    names = [b"</s>"] + [n.encode() for n in ("aa ab ac ad ba bb bc bd ca cb cc cd da db dc dd The the THE exit "
+                                              "x1 x2 x3 x4 x5 x6 x7 x8 x9 y1 y2 y3 y4 y5 y6 y7 y8 y9 zz").split()]
+    M = (rng.integers(0, 2, (len(names), 12)) * 2 - 1).astype(np.float32) / np.float32(3)
+    vec = write_vectors_file(str(tmp_path / "v.bin"), names, M)
+    om = E.EvalModel(vec, 0, 0, fma=False)
+    words = [n.decode() for n in names[1:24]] + [":", ":", "EXIT", "exit", "nope", "Aa", "BB"]
+    seps = [" ", " ", "\n", "\n", "\t", "  ", "\r\n", " \n "]
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.lists(st.tuples(st.sampled_from(words), st.sampled_from(seps)), min_size=0, max_size=60), st.booleans())
+    def run(tokens, trailing):
+        text = "".join(w + s for w, s in tokens)
+        if not trailing:
+            text = text.rstrip()
+        q = text.encode()
+        want = subprocess.run([exe, vec, "0", "0"], input=q, capture_output=True).stdout
+        assert E.transcript(om, q) == want, text
+
+    run()

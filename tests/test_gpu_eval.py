@@ -163,3 +163,76 @@ def test_train_then_evaluate_end_to_end(gpu, bitlevel, tmp_path):
         assert got.stdout == subprocess.run([exe, out, "0", "0"], input=qs, capture_output=True).stdout
     acc = parse_accuracy(got.stdout.decode())
     assert acc["seen"] == acc["questions"] == 8 * 12 * 11 and acc["total"] > 5.0, acc
+
+
+def _fuzz_model(tmp_path_factory):
+    rng = np.random.default_rng(77)
+    V, D = 40, 12
+    names = [b"</s>"] + [n.encode() for n in ("aa ab ac ad ba bb bc bd ca cb cc cd da db dc dd The the THE exit "
+                                              "x1 x2 x3 x4 x5 x6 x7 x8 x9 y1 y2 y3 y4 y5 y6 y7 y8 y9 zz").split()]
+    names = names[:V]
+    M = (rng.integers(0, 2, (V, D)) * 2 - 1).astype(np.float32) / np.float32(3)
+    return write_vectors_file(str(tmp_path_factory.mktemp("fz") / "v.bin"), names, M), names
+
+
+def test_question_stream_state_machine_fuzz(gpu, tmp_path_factory):
+    """random token soups through the scanf-style loop (ref :113-188): section markers anywhere, EXIT, unknown
+    words, questions cut short by the end of the input, missing trailing white space -- same stdout as the oracle"""
+    from hypothesis import given, settings, strategies as st
+    E = eval_oracle()
+    path, names = _fuzz_model(tmp_path_factory)
+    om, ev = E.EvalModel(path, 0, 0, fma=True), w2b.Evaluator(path, 0, 0, fused=True)
+    words = [n.decode() for n in names[1:24]] + [":", ":", "EXIT", "exit", "nope", "Aa", "BB"]
+    seps = [" ", " ", "\n", "\n", "\t", "  ", "\r\n", " \n "]
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.tuples(st.sampled_from(words), st.sampled_from(seps)), min_size=0, max_size=60),
+           st.booleans())
+    def run(tokens, trailing):
+        text = "".join(w + s for w, s in tokens)
+        if not trailing:
+            text = text.rstrip()
+        q = text.encode()
+        assert ev.transcript(q) == E.transcript(om, q), text
+
+    run()
+    ev.close()
+
+
+def test_vector_file_reader_fuzz(gpu, tmp_path_factory):
+    """random vector files through the reader of ref :85-112: names with embedded newlines / tabs / upper case /
+    51+ characters / bytes >= 0x80, duplicate names, truncated last row, header with extra white space, threshold"""
+    from hypothesis import given, settings, strategies as st
+    E = eval_oracle()
+    d = tmp_path_factory.mktemp("vf")
+    name_st = st.lists(st.sampled_from(list("abAB\n\t_") + ["\xe9", "x" * 26]), min_size=1, max_size=4).map("".join)
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(name_st, min_size=1, max_size=9), st.integers(1, 5), st.integers(0, 12), st.integers(0, 40),
+           st.sampled_from(["%d %d\n", "%d  %d\n", " %d\n%d\n"]), st.integers(0, 3))
+    def run(names, D, threshold, cut, header, seed):
+        rng = np.random.default_rng(seed)
+        V = len(names)
+        M = rng.standard_normal((V, D)).astype(np.float32)
+        p = str(d / "v.bin")
+        with open(p, "wb") as f:
+            f.write((header % (V, D)).encode())
+            for n, row in zip(names, M):
+                f.write(n.encode("latin1") + b" " + row.tobytes() + b"\n")
+        if cut:
+            data = open(p, "rb").read()
+            open(p, "wb").write(data[:max(len(header), len(data) - cut)])
+        om, ev = E.EvalModel(p, 0, threshold, fma=True), w2b.Evaluator(p, 0, threshold, fused=True)
+        try:
+            assert (ev.words, ev.size) == (om.words, om.size)
+            assert [ev.word(i) for i in range(ev.words)] == om.names
+            assert same_floats(ev.matrix(), om.M)
+            if ev.words >= 1:
+                b = rng.integers(0, ev.words, (3, 8)).astype(np.int32)
+                got, gd = ev.top1(*b)
+                want, wd = om.top1(*b)
+                assert np.array_equal(got, want) and same_floats(gd, wd)
+        finally:
+            ev.close()
+
+    run()

@@ -129,7 +129,7 @@ extern "C" int w2b_eval_load(const char *file, int32_t bitlevel, int64_t thresho
     const size_t want = (size_t)size * 4, have = d.size() - pos;
     const size_t take = (want < have ? want : have) / 4 * 4;
     memcpy(raw.data() + b * size, d.data() + pos, take);
-    pos += take;
+    pos = want <= have ? pos + want : d.size();   // a short fread also swallows the 1-3 bytes of a cut float
   }
   d.clear();
   d.shrink_to_fit();
