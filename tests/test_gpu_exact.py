@@ -89,3 +89,28 @@ def test_cli_exact_output_file_is_byte_identical_to_reference(gpu, name, tmp_pat
     r = subprocess.run(args, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-300:] + r.stderr[-300:]
     assert open(out, "rb").read() == open(os.path.join(GOLDEN, name + ".vec"), "rb").read()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_cli_exact_equals_oracle_on_random_flags(gpu, seed, tmp_path):
+    """the same seeded sweep over the flag space that pins the oracle to the live reference on the CPU side
+    (tests/test_oracle_golden.py): ./word2bits -threads 1 -exact 1 writes the oracle's file, byte for byte"""
+    from w2b_testlib import write_corpus
+    from test_oracle_golden import run_oracle
+    rng = np.random.default_rng(1000 + seed)
+    flags = dict(bitlevel=int(rng.choice([0, 1, 1, 2, 3, 4, 8])), size=int(rng.integers(1, 41)),
+                 window=int(rng.integers(1, 11)), negative=int(rng.integers(0, 13)), iter=int(rng.integers(1, 4)),
+                 min_count=int(rng.integers(1, 4)), binary=int(rng.integers(0, 2)),
+                 sample=float(rng.choice([0.0, 1e-3, 1e-2, 0.1])), reg=float(rng.choice([0.0, 0.0, 1e-3])),
+                 alpha=float(rng.choice([0.05, 0.025, 0.1])))
+    corpus = write_corpus(str(tmp_path / "c.txt"), seed=seed, vocab=int(rng.integers(20, 400)),
+                          n_tokens=int(rng.integers(2000, 9000)), line_len=int(rng.integers(3, 60)),
+                          quirks=bool(rng.integers(0, 2)))
+    gpu_out, ora_out = str(tmp_path / "g.vec"), str(tmp_path / "o.vec")
+    args = [os.path.join(ROOT, "word2bits"), "-train", corpus, "-output", gpu_out, "-threads", "1", "-exact", "1"]
+    for k, v in flags.items():
+        args += ["-" + k.replace("_", "-"), repr(v) if isinstance(v, float) else str(v)]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-300:] + r.stderr[-300:]
+    run_oracle(corpus, ora_out, flags)
+    assert open(gpu_out, "rb").read() == open(ora_out, "rb").read(), flags

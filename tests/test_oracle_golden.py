@@ -104,3 +104,24 @@ def test_init_net_is_the_readme_pattern():
     flat = np.concatenate([v.ravel(), u.ravel()])
     assert np.array_equal(flat[:4464], flat[65536:65536 + 4464])
     assert np.abs(flat).max() <= 0.5
+
+
+@pytest.mark.skipif(ref_binary("word2bits_nofma") is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", range(16))
+def test_oracle_vs_live_reference_random_flags(seed, tmp_path):
+    """a seeded sweep over the flag space (all bitlevels incl. 3, -size 1..40, -window 1..10, -negative 0..12,
+    -sample on/off, -reg, -alpha, 1..3 epochs, text and binary, with and without the tokenizer's corner cases):
+    the oracle's output file equals the live reference's, byte for byte"""
+    rng = np.random.default_rng(1000 + seed)
+    flags = dict(bitlevel=int(rng.choice([0, 1, 1, 2, 3, 4, 8])), size=int(rng.integers(1, 41)),
+                 window=int(rng.integers(1, 11)), negative=int(rng.integers(0, 13)), iter=int(rng.integers(1, 4)),
+                 min_count=int(rng.integers(1, 4)), binary=int(rng.integers(0, 2)),
+                 sample=float(rng.choice([0.0, 1e-3, 1e-2, 0.1])), reg=float(rng.choice([0.0, 0.0, 1e-3])),
+                 alpha=float(rng.choice([0.05, 0.025, 0.1])))
+    corpus = write_corpus(str(tmp_path / "c.txt"), seed=seed, vocab=int(rng.integers(20, 400)),
+                          n_tokens=int(rng.integers(2000, 9000)), line_len=int(rng.integers(3, 60)),
+                          quirks=bool(rng.integers(0, 2)))
+    ref_out, ora_out = str(tmp_path / "r.vec"), str(tmp_path / "o.vec")
+    run_ref("word2bits_nofma", corpus, ref_out, threads=1, **flags)
+    run_oracle(corpus, ora_out, flags)
+    assert open(ref_out, "rb").read() == open(ora_out, "rb").read(), flags
