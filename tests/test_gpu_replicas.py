@@ -1,0 +1,89 @@
+"""-m gpu: the N>1 flow of bench.py on real trainers -- two processes, each with its own model replica in HBM
+(both on GPU 0: the box has one), its own worker ids and corpus shard, exchanging through the zero-copy torch view
+of the library's [u||v] buffer exactly as bench.py does.  The process group is gloo (two ranks cannot share one
+GPU under RCCL); the collective backend is the only thing that differs from the multi-GPU run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import word2bits_amd as w2b
+    from word2bits_amd import replicas
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, D, W, K, nw = 3000, 64, 5, 5, 8
+        rng = np.random.default_rng(100 + rank)                      # every rank its own stream (as in bench.py)
+        ids = (rng.zipf(1.3, 40000) % (V - 1) + 1).astype(np.int32)
+        ids[49::50] = 0
+        counts = np.bincount(ids, minlength=V).astype(np.int64)
+        ct = torch.from_numpy(counts)
+        dist.all_reduce(ct)                                          # one vocabulary for all replicas
+        counts = np.maximum(ct.numpy(), 1)
+        off, per = replicas.worker_plan(nw * world, world, rank)
+        t = w2b.Trainer(V, D, W, K, 1, num_threads=nw, iter=1, sample=0.0, train_words=int(counts.sum()),
+                        compute_loss=False, device=0, worker_offset=off, total_threads=nw * world)
+        t.init_net()
+        t.set_vocab_counts(counts, 100000)
+        t.set_corpus(ids)
+        t.set_shards(replicas.token_shard_starts(len(ids), nw, 0, nw))
+        t.epoch_begin()
+        view = t.model_tensor()                                      # zero-copy view of the library's buffer
+        base = view.clone()
+        u0, v0 = t.get_model()
+        assert np.array_equal(np.concatenate([u0.ravel(), v0.ravel()]), view.cpu().numpy())   # same memory
+        sync = replicas.TorchReplicaSync(dist, 0)
+        ok = True
+        for rnd in range(3):
+            for _ in range(4):
+                t.train_step(200)
+            t.synchronize()
+            mine = view.cpu().clone()
+            deltas = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(deltas, mine - base.cpu())
+            expect = base.cpu() + sum(deltas[1:], deltas[0])
+            sync.sync(view, base)
+            torch.cuda.synchronize()
+            got = view.cpu()
+            ok = ok and bool(torch.allclose(got, expect, atol=1e-6)) and bool(torch.equal(base.cpu(), got))
+            ok = ok and float((mine - expect).abs().max()) > 0      # the other rank's updates really arrived
+            u, v = t.get_model()                                     # the library sees the exchanged model
+            ok = ok and np.array_equal(np.concatenate([u.ravel(), v.ravel()]), got.numpy())
+        digest = float(view.double().sum().item())
+        q.put((rank, ok, digest, off, per))
+        t.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_replicas_exchange_through_the_zero_copy_view(gpu):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert res[0][2] == res[1][2]                    # both replicas hold the same model after the last exchange
+    assert [(r[3], r[4]) for r in res] == [(0, 8), (8, 8)]
