@@ -137,7 +137,9 @@ int w2b_epoch_status(w2b_trainer *t, int32_t *finished, int64_t *word_count_actu
                      double *loss_sum);
 
 /* Number of Hogwild workers (-threads) that exactly fills this GPU for the configured shape: the workgroups
- * of the worker kernel that are resident at once.  More workers run in rounds; fewer leave CUs idle. */
+ * of the worker kernel that are resident at once (more workers run in rounds; fewer leave CUs idle) -- but, when
+ * cfg.train_words is known, never more than train_words / 20000: a worker re-computes alpha only after >10000 of
+ * its own words (ref :379-393), so shorter shards would freeze the learning rate for the whole epoch. */
 int w2b_suggested_threads(w2b_trainer *t, int32_t *out);
 
 /* ---- form (ii): explicit tuples (benchmark / single-step parity form) ------------------------

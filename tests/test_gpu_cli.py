@@ -73,12 +73,29 @@ def test_cli_hogwild_many_workers(gpu, tmp_path):
 
 
 def test_cli_threads_zero_fills_the_gpu(gpu, tmp_path):
-    """-threads 0 (GPU extension): as many Hogwild workers as workgroups fit on the device."""
+    """-threads 0 (GPU extension): as many Hogwild workers as workgroups fit on the device -- capped so that every
+    shard is at least two alpha periods long (a worker re-computes alpha only after >10000 of its own words,
+    ref :379-393; with shorter shards the whole epoch would run at the starting alpha)."""
+    import re
     out = str(tmp_path / "o.vec")
     flags = dict(META["b1_d8"]["flags"])
-    txt = run_cli(out, flags, threads=0)
-    import re
+    txt = run_cli(out, flags, threads=0)                 # 4 000-token corpus: one worker
     m = re.search(r"Hogwild workers \(workgroups\): (\d+)", txt)
-    assert m and int(m.group(1)) >= 256
+    assert m and int(m.group(1)) == max(1, META["b1_d8"]["train_words"] // 20000) == 1
     words, M = read_vectors(out, 1)
     assert np.isfinite(M).all() and len(words) == META["b1_d8"]["vocab_size"]
+    # a corpus long enough for the whole device: the cap no longer binds, the resident workgroups decide
+    rng = np.random.default_rng(0)
+    big = str(tmp_path / "big.txt")
+    ids = rng.integers(1, 2000, 12_000_000)
+    with open(big, "w") as f:
+        for i in range(0, len(ids), 1000):
+            f.write(" ".join("w%d" % t for t in ids[i:i + 1000]) + "\n")
+    r = subprocess.run([CLI, "-train", big, "-output", out, "-threads", "0", "-iter", "1", "-size", "64", "-window", "5",
+                        "-negative", "5", "-binary", "1", "-min-count", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    n = int(re.search(r"Hogwild workers \(workgroups\): (\d+)", r.stdout).group(1))
+    tw = int(re.search(r"Words in train file: (\d+)", r.stdout).group(1))
+    assert 256 <= n <= tw // 20000
+    alphas = [float(a) for a in re.findall(r"Alpha: ([0-9.]+)", r.stdout)]
+    assert alphas and min(alphas) < 0.04                  # the learning rate really decays inside the epoch

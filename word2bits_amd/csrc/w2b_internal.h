@@ -52,6 +52,7 @@ struct W2bParams {
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
   int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
   int hot_rows;                   // sentence-resident kernel: keep rows 1 and 2 of v in registers (0 = off)
+  int hot_period;                 // steps between merges of the register-resident hot rows (power of two)
   int exact;                      // serial dot product in the reference's order (plain worker / tuple kernels)
   float starting_alpha, sample, reg;
 };

@@ -257,7 +257,7 @@ __device__ __forceinline__ void window_admit(const W2bParams &P, const Win2 &L, 
 // line (about 7 M read-modify-writes per second); on Zipf-distributed ids the most frequent word alone is a
 // target of 0.3 centre words in every position, which capped the whole GPU at 23 M words/s.  The producer
 // places these rows at slots 0 / 1 of a chunk (prep_lists, hot_first), so only those two slots test for them.
-#define W2B_HOT_PERIOD 32
+#define W2B_HOT_PERIOD 32   // default of W2bParams::hot_period (a power of two; W2B_HOT_PERIOD in the environment overrides)
 template <int VEC> struct HotV { Col<VEC> v0, v1, d0, d1; int on; };
 
 template <int VEC, int MM>
@@ -922,7 +922,7 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
       W2B_TICK(4);
       if (!stop && I.St->cw > 0)
         process_word2<QM, VEC, LOSS, MM>(P, I, qp, NDW, I.St->cw, I.St->nt, I.St->uc_n, I.St->alpha, loss_acc, H);
-      if (stop || (it % W2B_HOT_PERIOD) == W2B_HOT_PERIOD - 1) hot_merge<VEC, MM>(P, L, H, NS, active, col0, lane, wave);
+      if (stop || (it & (P.hot_period - 1)) == P.hot_period - 1) hot_merge<VEC, MM>(P, L, H, NS, active, col0, lane, wave);
       if (deferred) retire_finish<VEC, MM>(P, d_row, d_csum, d_g, d_rw, d_rd, active, col0);
       W2B_TICK(5);
     }

@@ -169,6 +169,11 @@ static W2bParams make_params(const w2b_trainer *t) {
   if (p.exact) p.mem_mode = 0;             // the exact mode exists for coherent rows only
   p.hot_rows = 1;
   if (const char *e = getenv("W2B_HOT_ROWS")) p.hot_rows = atoi(e) != 0;
+  p.hot_period = 32;
+  if (const char *e = getenv("W2B_HOT_PERIOD")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 4096 && (v & (v - 1)) == 0) p.hot_period = v;
+  }
   p.starting_alpha = t->cfg.alpha;
   p.sample = t->cfg.sample;
   p.reg = t->cfg.reg;
@@ -500,7 +505,17 @@ extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
   const int radius = worker_radius(t);
   const int per_cu = radius >= 0 ? w2b_workers2_per_cu(p, radius, t->cfg.compute_loss != 0)
                                  : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
-  *out = per_cu * t->num_cus;
+  long long n = (long long)per_cu * t->num_cus;
+  // A worker adjusts alpha only after >10000 of its own words (ref :379-393): with shards shorter than that no worker
+  // ever does and the whole epoch runs at the starting alpha.  Never suggest more workers than leave every shard
+  // at least two such periods long (train_words here is the job's global number; 0 = unknown, no cap).
+  if (t->cfg.train_words > 0) {
+    const long long total = t->cfg.total_threads > 0 && t->cfg.num_threads > 0
+                                ? (long long)t->cfg.total_threads / t->cfg.num_threads : 1;   // replicas
+    const long long cap = t->cfg.train_words / (20000 * (total > 0 ? total : 1));
+    if (n > cap) n = cap > 1 ? cap : 1;
+  }
+  *out = (int32_t)n;
   return W2B_OK;
 }
 

@@ -145,6 +145,7 @@ int main(int argc, char **argv) {
   if (o.num_threads < 1) {                                   // GPU extension: -threads 0 = fill the device(s)
     w2b_config probe_cfg;
     memset(&probe_cfg, 0, sizeof probe_cfg);
+    probe_cfg.train_words = w2b_corpus_train_words(corpus) / o.gpus;   // per replica: caps workers on small corpora
     probe_cfg.vocab_size = 2; probe_cfg.layer1_size = (int32_t)o.layer1_size; probe_cfg.window = o.window;
     probe_cfg.negative = o.negative; probe_cfg.bitlevel = o.bitlevel; probe_cfg.num_threads = 1;
     probe_cfg.alpha = o.alpha; probe_cfg.compute_loss = 1; probe_cfg.device = o.device;
