@@ -14,7 +14,7 @@
 //     exact fp32 value is stored -- a single worker stays bit-identical to the plain kernel; otherwise
 //     the worker's delta is added to the CURRENT row (merge), so concurrent Hogwild workers do not
 //     erase each other's updates;
-//   * rows are thread-private columns of LDS (a thread only ever touches its own 16 bytes of every
+//   * rows are thread-private columns of LDS (a thread only ever touches its own 8 bytes of every
 //     slot): no barriers, no bank conflicts.
 // The radius R is window when the window fits in LDS next to a second workgroup, else window-1 with
 // the two outermost context rows held in registers for the step; otherwise the launcher falls back
@@ -25,9 +25,9 @@
 #include <cstdio>
 #include <cstdlib>
 
-// target rows per chunk (negative=24 -> 9 + 9 + 7).  Two 5-wavefront workgroups per CU put up to four
-// wavefronts on one SIMD (the dispatcher does not balance a second workgroup around the first one: at 168
-// VGPRs only ONE workgroup per CU was ever resident), so the kernel is held to 128 VGPRs.
+// target rows per chunk (negative=24 -> 13 + 12).  A workgroup is up to 7 data wavefronts (one thread per 8-byte
+// column) + 1 producer wavefront; two workgroups per CU put four wavefronts on every SIMD, so the kernel is held
+// to 128 VGPRs (__launch_bounds__(512, 4)).
 #define W2B_T2MAX 25
 #define W2B_NDWMAX 8   // data wavefronts per worker (stride of the per-wavefront LDS tables)
 template <int VEC> struct T2For { static constexpr int value = 13; };
@@ -40,7 +40,7 @@ struct Win2Lds {          // scalars owned by the producer wavefront (extends Wo
   int clo, chi;           // sentence positions currently resident (empty when chi < clo)
 };
 
-// What the producer wavefront hands to the four data wavefronts for ONE step (double buffered in LDS)
+// What the producer wavefront hands to the data wavefronts for ONE step (double buffered in LDS)
 struct Step2 {
   int stop;               // 1: this pass only empties the window (epoch finished, or end of the launch)
   int cw, nt, uc_n, n_ret, n_adm;
@@ -581,7 +581,7 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
 }
 
 // --------------------------------------------------------------------------------------------------
-// Five wavefronts per worker: wavefronts 0-3 own the embedding columns (data phase); wavefront 4 is the
+// NDW + 1 wavefronts per worker: wavefronts 0..NDW-1 own the embedding columns (data phase); the last one is the
 // PRODUCER: it walks the sentence, the LCG ledger, the window bookkeeping and the negative draws ONE STEP
 // AHEAD and hands the lists over through a double-buffered LDS record.  The data wavefronts never wait for
 // the scalar work of a step (it was 25-30 % of the step time when wavefront 0 did both).
