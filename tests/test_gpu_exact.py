@@ -114,3 +114,32 @@ def test_cli_exact_equals_oracle_on_random_flags(gpu, seed, tmp_path):
     assert r.returncode == 0, r.stdout[-300:] + r.stderr[-300:]
     run_oracle(corpus, ora_out, flags)
     assert open(gpu_out, "rb").read() == open(ora_out, "rb").read(), flags
+
+
+@pytest.mark.parametrize("threads,prefix,flags", [
+    (4, b"", dict(bitlevel=1, size=12, window=5, iter=1, sample=0.0)),
+    (4, b"", dict(bitlevel=0, size=9, window=3, iter=2, sample=1e-2)),
+    (3, b"zz zz\n", dict(bitlevel=2, size=10, window=8, iter=2, sample=0.0)),      # worker starts inside words
+    (7, b"q\n", dict(bitlevel=1, size=8, window=2, iter=1, sample=1e-3)),
+    (16, b"", dict(bitlevel=1, size=200, window=8, iter=2, sample=0.0)),
+])
+def test_multi_worker_shard_logic_bit_exact(gpu, threads, prefix, flags, tmp_path):
+    """Hogwild with SEVERAL workers, still bit-exact: shards with disjoint vocabularies, -negative 0, shards shorter
+    than an alpha period -- no two workers touch the same row, so the run is deterministic (the reference's own
+    -threads N run is, and the oracle is pinned to it on exactly these corpora, tests/test_oracle_golden.py).
+    Checks worker ids as seeds, shard offsets incl. mid-word starts, per-worker quotas and the sentence that crosses
+    the quota (read, not trained) through the command line, in parity mode."""
+    from w2b_testlib import write_disjoint_shard_corpus
+    from test_oracle_golden import run_oracle
+    corpus = write_disjoint_shard_corpus(str(tmp_path / "c.txt"), n_shards=threads, seed=threads, prefix=prefix)
+    f = dict(negative=0, min_count=1, binary=1)
+    f.update(flags)
+    gpu_out, ora_out = str(tmp_path / "g.vec"), str(tmp_path / "o.vec")
+    args = [os.path.join(ROOT, "word2bits"), "-train", corpus, "-output", gpu_out, "-threads", str(threads),
+            "-exact", "1", "-positions", "37"]
+    for k, v in f.items():
+        args += ["-" + k.replace("_", "-"), repr(v) if isinstance(v, float) else str(v)]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-300:] + r.stderr[-300:]
+    run_oracle(corpus, ora_out, f, threads=threads)
+    assert open(gpu_out, "rb").read() == open(ora_out, "rb").read()

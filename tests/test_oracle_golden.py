@@ -125,3 +125,29 @@ def test_oracle_vs_live_reference_random_flags(seed, tmp_path):
     run_ref("word2bits_nofma", corpus, ref_out, threads=1, **flags)
     run_oracle(corpus, ora_out, flags)
     assert open(ref_out, "rb").read() == open(ora_out, "rb").read(), flags
+
+
+@pytest.mark.skipif(ref_binary("word2bits_nofma") is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("threads,prefix,flags", [
+    (4, b"", dict(bitlevel=1, size=12, window=5, iter=1, sample=0.0)),
+    (4, b"", dict(bitlevel=0, size=9, window=3, iter=2, sample=1e-2)),
+    (3, b"zz zz\n", dict(bitlevel=2, size=10, window=8, iter=2, sample=0.0)),      # thread offsets land inside words
+    (7, b"q\n", dict(bitlevel=1, size=8, window=2, iter=1, sample=1e-3)),
+])
+def test_multi_thread_shard_logic_vs_live_reference(threads, prefix, flags, tmp_path):
+    """-threads N on a corpus whose shards use disjoint vocabularies, with -negative 0 and shards shorter than one
+    alpha period: no two threads touch the same row, so the reference itself is deterministic and the oracle's
+    per-thread logic (offsets, mid-word starts, quotas, seeds) must reproduce its file byte for byte."""
+    from w2b_testlib import write_disjoint_shard_corpus
+    corpus = write_disjoint_shard_corpus(str(tmp_path / "c.txt"), n_shards=threads, seed=threads, prefix=prefix)
+    f = dict(negative=0, min_count=1, binary=1)
+    f.update(flags)
+    outs = []
+    for rep in range(2):                                   # the reference really is deterministic here
+        o = str(tmp_path / ("r%d.vec" % rep))
+        run_ref("word2bits_nofma", corpus, o, threads=threads, **f)
+        outs.append(open(o, "rb").read())
+    assert outs[0] == outs[1]
+    ora = str(tmp_path / "o.vec")
+    run_oracle(corpus, ora, f, threads=threads)
+    assert open(ora, "rb").read() == outs[0]

@@ -252,3 +252,28 @@ def write_vectors_file(path, names, M):
         for n, row in zip(names, M):
             f.write(n + b" " + np.asarray(row, "<f4").tobytes() + b"\n")
     return path
+
+
+def write_disjoint_shard_corpus(path, n_shards=4, sentences=60, vocab_per_shard=40, seed=0, prefix=b""):
+    """A corpus on which a MULTI-THREADED run of the reference is deterministic, so that the per-thread logic
+    (fseek offsets ref :377, quotas :414-421, seeds :368, the sentence that crosses the quota being read but not
+    trained) can be compared bit for bit: `n_shards` byte-identical-length shards, each with its own vocabulary
+    (fixed-width words), boundaries on sentence boundaries, every shard well under the 10000 words after which a
+    thread would touch the shared alpha (:379-393).  Train it with -threads n_shards -negative 0: then no two
+    threads ever touch the same row.  `prefix` (e.g. b"zz zz\\n") shifts the thread offsets into the middle of
+    words."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, 30, sentences)
+    shards = []
+    for k in range(n_shards):
+        letter = "abcdefghijklmnop"[k]
+        words = rng.integers(0, vocab_per_shard, int(lens.sum()))
+        out, i = [], 0
+        for ln in lens:
+            out.append(" ".join("%s%02d" % (letter, w) for w in words[i:i + ln]))
+            i += ln
+        shards.append(("\n".join(out) + "\n").encode())
+    assert len({len(s) for s in shards}) == 1
+    with open(path, "wb") as f:
+        f.write(prefix + b"".join(shards))
+    return path
