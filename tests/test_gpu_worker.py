@@ -180,3 +180,25 @@ def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, wind
         assert np.array_equal(out[0][0].view(np.uint32), out[k][0].view(np.uint32))
         assert np.array_equal(out[0][1].view(np.uint32), out[k][1].view(np.uint32))
         assert out[0][2] == pytest.approx(out[k][2], rel=1e-9)
+
+
+@pytest.mark.parametrize("threads,size,window,bitlevel", [(16, 200, 8, 1), (8, 64, 3, 2), (5, 800, 8, 0)])
+def test_sentence_resident_kernel_equals_plain_kernel_many_workers(gpu, threads, size, window, bitlevel, tmp_path):
+    """Several Hogwild workers, deterministic anyway (shards with disjoint vocabularies, -negative 0, shards shorter
+    than an alpha period: no two workers share a row): the sentence-resident kernel -- window slots, fp16 deltas,
+    exact-or-merge write-back, register-resident hot rows, producer wavefront -- must write the same file as the
+    plain kernel, byte for byte."""
+    import os
+    import subprocess
+    from w2b_testlib import ROOT, write_disjoint_shard_corpus
+    corpus = write_disjoint_shard_corpus(str(tmp_path / "c.txt"), n_shards=threads, sentences=80, seed=threads)
+    outs = []
+    for wc in (0, 1):
+        out = str(tmp_path / ("o%d.vec" % wc))
+        r = subprocess.run([os.path.join(ROOT, "word2bits"), "-train", corpus, "-output", out, "-threads", str(threads),
+                            "-window-cache", str(wc), "-bitlevel", str(bitlevel), "-size", str(size), "-window", str(window),
+                            "-negative", "0", "-iter", "2", "-min-count", "1", "-binary", "1", "-sample", "0",
+                            "-positions", "53"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-300:]
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]

@@ -274,6 +274,16 @@ __device__ __forceinline__ void hot_merge(const W2bParams &P, const Win2 &L, Hot
     for (int e = 0; e < VEC; e++) g.e[e] = 0.f;
     if (active) g = load_col<VEC, (MM & 7), ((MM >> 3) & 1)>(P.v, k + 1, P.dim, col0, P.tab_bytes);
     const unsigned now = wave_xor(active ? col_bits(g) : 0u);
+    bool mine = false;                         // did this worker add anything to these columns since the last merge?
+#pragma unroll
+    for (int e = 0; e < VEC; e++) mine = mine || (del.e[e] != 0.f);
+    if (__ballot(active && mine) == 0ull) {
+      // nothing of ours to publish: adopt the current row and do NOT write (a read-modify-write of a row we did
+      // not change could only overwrite somebody else's newer value)
+      if (active) val = g;
+      if (lane == 0) L.csum[(NS + k) * W2B_NDWMAX + wave] = now;
+      continue;
+    }
     const bool untouched = (now == L.csum[(NS + k) * W2B_NDWMAX + wave]);
     if (active) {
 #pragma unroll
