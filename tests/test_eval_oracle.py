@@ -143,3 +143,36 @@ def test_oracle_question_loop_matches_live_reference_fuzz(tmp_path):
         assert E.transcript(om, q) == want, text
 
     run()
+
+
+def test_oracle_vector_reader_matches_live_reference_fuzz(tmp_path):
+    """random vector files through the reference's reader (ref :85-112) vs the oracle's restatement, observed through
+    the transcript of a question stream that asks for every name: names with embedded newlines / tabs, mixed case,
+    more than 50 characters, bytes >= 0x80, duplicates, header variants, -threshold"""
+    from hypothesis import given, settings, strategies as st
+    exe = ref_binary("compute_accuracy")
+    if not exe:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    E = eval_oracle()
+    name_st = st.lists(st.sampled_from(list("abAB\n\t_") + ["\xe9", "x" * 26]), min_size=1, max_size=4).map("".join)
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(name_st, min_size=2, max_size=9), st.integers(1, 5), st.integers(0, 12),
+           st.sampled_from(["%d %d\n", "%d  %d\n", " %d\n%d\n"]), st.integers(0, 3))
+    def run(names, D, threshold, header, seed):
+        rng = np.random.default_rng(seed)
+        V = len(names)
+        M = rng.standard_normal((V, D)).astype(np.float32)
+        p = str(tmp_path / "v.bin")
+        with open(p, "wb") as f:
+            f.write((header % (V, D)).encode())
+            for n, row in zip(names, M):
+                f.write(n.encode("latin1") + b" " + row.tobytes() + b"\n")
+        asks = [n.replace("\n", "") for n in names] + ["ab", "AB", "x" * 50, "x" * 52]
+        q = ": all\n" + "".join("%s %s %s %s\n" % (a, b, a, b) for a in asks for b in asks[:3]
+                                if a.split() == [a] and b.split() == [b])
+        q = q.encode("latin1")
+        want = subprocess.run([exe, p, "0", str(threshold)], input=q, capture_output=True).stdout
+        assert E.transcript(E.EvalModel(p, 0, threshold, fma=True), q) == want, (names, D, threshold)
+
+    run()
