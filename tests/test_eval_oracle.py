@@ -132,7 +132,7 @@ def test_oracle_question_loop_matches_live_reference_fuzz(tmp_path):
     words = [n.decode() for n in names[1:24]] + [":", ":", "EXIT", "exit", "nope", "Aa", "BB"]
     seps = [" ", " ", "\n", "\n", "\t", "  ", "\r\n", " \n "]
 
-    @settings(max_examples=120, deadline=None)
+    @settings(max_examples=120, deadline=None, derandomize=True, database=None)
     @given(st.lists(st.tuples(st.sampled_from(words), st.sampled_from(seps)), min_size=0, max_size=60), st.booleans())
     def run(tokens, trailing):
         text = "".join(w + s for w, s in tokens)
@@ -156,12 +156,20 @@ def test_oracle_vector_reader_matches_live_reference_fuzz(tmp_path):
     E = eval_oracle()
     name_st = st.lists(st.sampled_from(list("abAB\n\t_") + ["\xe9", "x" * 26]), min_size=1, max_size=4).map("".join)
 
-    @settings(max_examples=60, deadline=None)
+    @settings(max_examples=60, deadline=None, derandomize=True, database=None)
     @given(st.lists(name_st, min_size=2, max_size=9), st.integers(1, 5), st.integers(0, 12),
            st.sampled_from(["%d %d\n", "%d  %d\n", " %d\n%d\n"]), st.integers(0, 3))
     def run(names, D, threshold, header, seed):
         rng = np.random.default_rng(seed)
         V = len(names)
+        # The reference's name array is `words * 50` bytes and its reader writes a terminating 0 at index 50 of a row
+        # whose name has 50 or more characters (ref :99-104): in the LAST loaded row that is a heap overflow
+        # (undefined behaviour -- the stock build dies after "Starting eval...").  Keep the last loaded row short
+        # here; the long-last-row case is pinned oracle-only in test_oracle_long_name_in_last_row below.
+        last = (min(V, threshold) if threshold else V) - 1
+        names = list(names)
+        if len(names[last].replace("\n", "")) >= 50:
+            names[last] = names[last].replace("\n", "")[:49]
         M = rng.standard_normal((V, D)).astype(np.float32)
         p = str(tmp_path / "v.bin")
         with open(p, "wb") as f:
@@ -176,3 +184,25 @@ def test_oracle_vector_reader_matches_live_reference_fuzz(tmp_path):
         assert E.transcript(E.EvalModel(p, 0, threshold, fma=True), q) == want, (names, D, threshold)
 
     run()
+
+
+def test_oracle_long_name_in_last_row(tmp_path):
+    """A name of 50+ characters in the LAST row drives the reference into a one-byte heap overflow (ref :99-104: the
+    terminating 0 lands one byte past its `words * 50` name array), so there is no reference behaviour to match.  The
+    restatement (and the product, tests/test_gpu_eval.py::test_vector_file_reader_fuzz) define it as a flat array
+    with one spare byte: the name is its first 50 characters.  (In any other row the same name runs on into the next
+    row's name -- that quirk IS reference behaviour and is pinned by the live fuzz above.)"""
+    E = eval_oracle()
+    names = ["</s>", "ab", "cd", "x" * 52]
+    M = np.random.default_rng(5).standard_normal((4, 3)).astype(np.float32)
+    p = str(tmp_path / "v.bin")
+    with open(p, "wb") as f:
+        f.write(b"4 3\n")
+        for n, row in zip(names, M):
+            f.write(n.encode() + b" " + row.tobytes() + b"\n")
+    m = E.EvalModel(p, 0, 0, fma=True)
+    assert m.names == [b"</S>", b"AB", b"CD", b"X" * 50]
+    q = (": s\nab cd ab cd\n%s ab %s ab\n%s ab %s ab\n" % ("x" * 50, "x" * 50, "x" * 52, "x" * 52)).encode()
+    out = E.transcript(m, q).decode()
+    # the 50-character spelling is found (questions 1 and 2 are seen), the 52-character one is not
+    assert out.endswith("Questions seen / total: 2 3   66.67 % \n") or out.rstrip().endswith("Questions seen / total: 2 3   66.67 %")

@@ -185,7 +185,7 @@ def test_question_stream_state_machine_fuzz(gpu, tmp_path_factory):
     words = [n.decode() for n in names[1:24]] + [":", ":", "EXIT", "exit", "nope", "Aa", "BB"]
     seps = [" ", " ", "\n", "\n", "\t", "  ", "\r\n", " \n "]
 
-    @settings(max_examples=150, deadline=None)
+    @settings(max_examples=150, deadline=None, derandomize=True, database=None)
     @given(st.lists(st.tuples(st.sampled_from(words), st.sampled_from(seps)), min_size=0, max_size=60),
            st.booleans())
     def run(tokens, trailing):
@@ -207,7 +207,7 @@ def test_vector_file_reader_fuzz(gpu, tmp_path_factory):
     d = tmp_path_factory.mktemp("vf")
     name_st = st.lists(st.sampled_from(list("abAB\n\t_") + ["\xe9", "x" * 26]), min_size=1, max_size=4).map("".join)
 
-    @settings(max_examples=60, deadline=None)
+    @settings(max_examples=60, deadline=None, derandomize=True, database=None)
     @given(st.lists(name_st, min_size=1, max_size=9), st.integers(1, 5), st.integers(0, 12), st.integers(0, 40),
            st.sampled_from(["%d %d\n", "%d  %d\n", " %d\n%d\n"]), st.integers(0, 3))
     def run(names, D, threshold, cut, header, seed):
