@@ -1,0 +1,154 @@
+// tools/row_probe.hip -- random-row read-modify-write bandwidth of the MI355X memory system for the access
+// shapes the training kernels can choose from.  Every workgroup repeatedly picks T
+// random 3200-byte rows of a 1.28 GB table, loads them, adds 1, stores them back -- the traffic pattern of
+// phase B of the update (ref src/word2bits.cpp:461-491) without the arithmetic.
+//   shape 0: one thread per  8-byte column, full wavefronts   (buffer_load/store_dwordx2)
+//   shape 1: 8-byte columns in registers, but memory is accessed 16 bytes per lane: rows are handled in pairs,
+//            even lanes move 16 bytes of row A, odd lanes 16 bytes of row B (per-lane row offset), then
+//            neighbouring lanes exchange halves (DPP quad_perm)
+//   shape 2: one thread per 16-byte column (buffer_load/store_dwordx4), 200 of 256 lanes active
+//   shape 3: as 1, but two exec-masked half-wave instructions with wave-uniform row bases (works with per-row
+//            buffer descriptors, i.e. tables >= 4 GiB)
+// x cache policy of loads / stores (0 plain, 16 sc1 = agent scope / write-through) x prefetch (loads of batch
+// i+1 issued before the stores of batch i) x workgroups per CU.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e_), #x); exit(1); } } while (0)
+
+__device__ __forceinline__ unsigned swap_pair(unsigned x) {   // value of the neighbouring lane (lane ^ 1)
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);
+}
+
+template <int SHAPE, int LAUX, int SAUX, int T, bool PF>
+__global__ void __launch_bounds__(512) k_probe(float *tab, unsigned nrows, int dim, int iters, unsigned *sink) {
+  extern __shared__ int pad[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned rowb = (unsigned)dim * 4u;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, (int)(nrows * rowb), 0x27000);
+  unsigned long long s = (blockIdx.x + 1) * 0x9E3779B97F4A7C15ull;
+  const bool odd = lane & 1;
+  constexpr int NV = (SHAPE == 2) ? 4 : 2;          // VGPRs per row and thread
+  unsigned x[2][T][NV];
+  unsigned rows[2][T];
+  const int off8 = tid * 8, off16p = (tid >> 1) * 16, off16 = tid * 16;
+  const bool act = (SHAPE == 2) ? (off16 < (int)rowb) : (off8 < (int)rowb);
+  auto pick = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < T; i++) { s = s * 25214903917ull + 11; rows[b][i] = __builtin_amdgcn_readfirstlane((unsigned)((s >> 20) % nrows)); }
+  };
+  auto load = [&](int b) {
+    if (!act) return;
+    if (SHAPE == 0) {
+#pragma unroll
+      for (int i = 0; i < T; i++) { u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, off8, rows[b][i] * rowb, LAUX); x[b][i][0] = t.x; x[b][i][1] = t.y; }
+    } else if (SHAPE == 2) {
+#pragma unroll
+      for (int i = 0; i < T; i++) { u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, off16, rows[b][i] * rowb, LAUX); x[b][i][0] = t.x; x[b][i][1 % NV] = t.y; x[b][i][2 % NV] = t.z; x[b][i][3 % NV] = t.w; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < T; i += 2) {
+        u32x4 t;
+        if (SHAPE == 1) {
+          t = __builtin_amdgcn_raw_buffer_load_b128(r, (odd ? rows[b][i + 1] : rows[b][i]) * rowb + off16p, 0, LAUX);
+        } else {
+          t = u32x4{0, 0, 0, 0};
+          if (!odd) t = __builtin_amdgcn_raw_buffer_load_b128(r, off16p, rows[b][i] * rowb, LAUX);
+          else t = __builtin_amdgcn_raw_buffer_load_b128(r, off16p, rows[b][i + 1] * rowb, LAUX);
+        }
+        // even lane holds A[2k], A[2k+1]; odd lane holds B[2k], B[2k+1].  Wanted: lane l has A[l] and B[l].
+        const unsigned s0 = odd ? t.x : t.z, s1 = odd ? t.y : t.w;
+        const unsigned r0 = swap_pair(s0), r1 = swap_pair(s1);
+        x[b][i][0] = odd ? r0 : t.x; x[b][i][1] = odd ? r1 : t.y;
+        x[b][i + 1][0] = odd ? t.z : r0; x[b][i + 1][1] = odd ? t.w : r1;
+      }
+    }
+  };
+  auto store = [&](int b) {
+    if (!act) return;
+    if (SHAPE == 0) {
+#pragma unroll
+      for (int i = 0; i < T; i++) { u32x2 t; t.x = x[b][i][0] + 1; t.y = x[b][i][1] + 1; __builtin_amdgcn_raw_buffer_store_b64(t, r, off8, rows[b][i] * rowb, SAUX); }
+    } else if (SHAPE == 2) {
+#pragma unroll
+      for (int i = 0; i < T; i++) { u32x4 t; t.x = x[b][i][0] + 1; t.y = x[b][i][1 % NV] + 1; t.z = x[b][i][2 % NV] + 1; t.w = x[b][i][3 % NV] + 1; __builtin_amdgcn_raw_buffer_store_b128(t, r, off16, rows[b][i] * rowb, SAUX); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < T; i += 2) {
+        const unsigned a0 = x[b][i][0] + 1, a1 = x[b][i][1] + 1, b0 = x[b][i + 1][0] + 1, b1 = x[b][i + 1][1] + 1;
+        const unsigned r0 = swap_pair(odd ? a0 : b0), r1 = swap_pair(odd ? a1 : b1);
+        u32x4 t;
+        t.x = odd ? r0 : a0; t.y = odd ? r1 : a1; t.z = odd ? b0 : r0; t.w = odd ? b1 : r1;
+        if (SHAPE == 1) {
+          __builtin_amdgcn_raw_buffer_store_b128(t, r, (odd ? rows[b][i + 1] : rows[b][i]) * rowb + off16p, 0, SAUX);
+        } else {
+          if (!odd) __builtin_amdgcn_raw_buffer_store_b128(t, r, off16p, rows[b][i] * rowb, SAUX);
+          else __builtin_amdgcn_raw_buffer_store_b128(t, r, off16p, rows[b][i + 1] * rowb, SAUX);
+        }
+      }
+    }
+  };
+  pick(0);
+  load(0);
+  for (int it = 0; it < iters; it += 2) {
+    if (PF) { pick(1); load(1); }
+    store(0);
+    if (!PF) { pick(1); load(1); }
+    if (PF) { pick(0); load(0); }
+    store(1);
+    if (!PF) { pick(0); load(0); }
+  }
+  unsigned acc = 0;
+#pragma unroll
+  for (int i = 0; i < T; i++) acc ^= x[0][i][0];
+  if (acc == 0x12345678u) sink[0] = acc + pad[0];
+}
+
+template <int SHAPE, int LAUX, int SAUX, int T, bool PF>
+static void run(const char *name, float *tab, unsigned nrows, int dim, int wg_per_cu, unsigned *sink) {
+  const int threads = (SHAPE == 2) ? 256 : 448;
+  const size_t lds = (size_t)(160 * 1024 / wg_per_cu) - 1024;
+  const int grid = 256 * wg_per_cu, iters = 400;
+  CK(hipFuncSetAttribute((const void *)k_probe<SHAPE, LAUX, SAUX, T, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_probe<SHAPE, LAUX, SAUX, T, PF>), dim3(grid), dim3(threads), lds, 0, tab, nrows, dim, iters, sink);
+    CK(hipEventRecord(b));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    if (ms < best) best = ms;
+  }
+  const double bytes = 2.0 * grid * (double)iters * T * dim * 4;
+  printf("%-34s T=%2d pf=%d wg/cu=%d: %8.3f ms  %6.2f TB/s (read+write)\n", name, T, (int)PF, wg_per_cu, best, bytes / best / 1e9);
+  fflush(stdout);
+}
+
+int main() {
+  const unsigned nrows = 400000; const int dim = 800;
+  float *tab; unsigned *sink;
+  CK(hipMalloc(&tab, (size_t)nrows * dim * 4)); CK(hipMemset(tab, 0, (size_t)nrows * dim * 4)); CK(hipMalloc(&sink, 64));
+#define ROW(SH, LA, SA, T, W, NAME) run<SH, LA, SA, T, false>(NAME, tab, nrows, dim, W, sink); run<SH, LA, SA, T, true>(NAME, tab, nrows, dim, W, sink);
+  for (int pass = 0; pass < 1; pass++) {
+    ROW(0, 0, 0, 12, 2, "8B/lane plain+plain");
+    ROW(0, 16, 16, 12, 2, "8B/lane sc1+sc1");
+    ROW(0, 16, 0, 12, 2, "8B/lane sc1 loads, plain stores");
+    ROW(0, 0, 16, 12, 2, "8B/lane plain loads, sc1 stores");
+    ROW(1, 0, 0, 12, 2, "paired16 plain+plain");
+    ROW(1, 16, 16, 12, 2, "paired16 sc1+sc1");
+    ROW(1, 16, 0, 12, 2, "paired16 sc1 loads, plain stores");
+    ROW(3, 16, 16, 12, 2, "halfwave16 sc1+sc1");
+    ROW(3, 0, 0, 12, 2, "halfwave16 plain+plain");
+    ROW(2, 0, 0, 8, 4, "16B/lane plain+plain");
+    ROW(2, 16, 16, 8, 4, "16B/lane sc1+sc1");
+    ROW(2, 16, 16, 12, 2, "16B/lane sc1+sc1");
+    ROW(0, 16, 16, 24, 1, "8B/lane sc1+sc1");
+    ROW(1, 16, 16, 24, 1, "paired16 sc1+sc1");
+    ROW(0, 16, 16, 12, 4, "8B/lane sc1+sc1");
+    ROW(1, 16, 16, 12, 4, "paired16 sc1+sc1");
+  }
+  return 0;
+}

@@ -153,6 +153,8 @@ static W2bParams make_params(const w2b_trainer *t) {
   {
     const unsigned long long bytes = (unsigned long long)t->table_elems * sizeof(float);
     p.tab_bytes = bytes < 0x7fffffffull ? (unsigned)bytes : 0u;   // signed 32-bit scalar offsets
+    // test hook: run the large-table form (per-row buffer descriptors, what tables >= 2 GiB use) on any table size
+    if (const char *e = getenv("W2B_FORCE_ROW_DESC")) if (atoi(e) != 0) p.tab_bytes = 0u;
   }
   p.vocab_size = t->cfg.vocab_size;
   p.train_words = t->cfg.train_words;
