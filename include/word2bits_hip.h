@@ -142,6 +142,12 @@ int w2b_epoch_status(w2b_trainer *t, int32_t *finished, int64_t *word_count_actu
  * its own words (ref :379-393), so shorter shards would freeze the learning rate for the whole epoch. */
 int w2b_suggested_threads(w2b_trainer *t, int32_t *out);
 
+/* Which form-(i) kernel w2b_train_step() runs for this trainer: *resident = 1 for the sentence-resident kernel
+ * (*radius = sentence positions on either side of the centre word whose rows stay in LDS, *column_bytes = bytes
+ * of a row owned by one lane), 0 for the plain kernel.  Any pointer may be NULL. */
+int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t *radius, int32_t *column_bytes,
+                           int32_t *workgroups_per_cu);
+
 /* ---- form (ii): explicit tuples (benchmark / single-step parity form) ------------------------
  * n centre words; ctx_off[n+1] CSR into ctx[] (context rows of u, ref :431-447);
  * neg[n*negative] rows of v drawn for d = 1..negative, -1 = skipped draw (ref :458).

@@ -68,6 +68,7 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
 hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s);
 // sentence-resident variant (w2b_kernels_workers2.hip): radius >= 0 when it can run for this shape
 int w2b_window_radius(int dim, int window, int negative);
+int w2b_workers2_vec(int dim);                                         // floats per lane of the sentence-resident kernel
 hipError_t w2b_launch_workers2(const W2bParams &p, long long max_positions, int radius, bool loss, hipStream_t s);
 int w2b_workers_per_cu(const W2bParams &p, bool loss);                  // resident workgroups per CU, plain kernel
 int w2b_workers2_per_cu(const W2bParams &p, int radius, bool loss);     // ... sentence-resident kernel

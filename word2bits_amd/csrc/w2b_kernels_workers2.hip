@@ -476,8 +476,12 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
       float f = 0.f;
       // pairs of 8-byte-column wavefronts first: the same binary tree over the elements as the plain kernel's
       // 16-byte-column wavefronts, so that a single worker reproduces the plain kernel bit for bit
-      for (int w = 0; w < nwaves; w += 2)
-        f += red[lane * W2B_NDWMAX + w] + ((w + 1 < nwaves) ? red[lane * W2B_NDWMAX + w + 1] : 0.f);
+      if (VEC == 4) {      // 16-byte columns: a wavefront covers the same 256 columns as in the plain kernel
+        for (int w = 0; w < nwaves; w++) f += red[lane * W2B_NDWMAX + w];
+      } else {
+        for (int w = 0; w < nwaves; w += 2)
+          f += red[lane * W2B_NDWMAX + w] + ((w + 1 < nwaves) ? red[lane * W2B_NDWMAX + w + 1] : 0.f);
+      }
       // the centre word: entry bit 30 when the producer reorders chunks (hot rows first), else list index 0
       const float label = (H.on ? ((L.tgt[start + lane] >> 30) & 1) : (start + lane == 0)) ? 1.f : 0.f;
       float g;
@@ -597,8 +601,10 @@ __device__ __forceinline__ void process_word2(const W2bParams &P, const Win2 &L,
 // the scalar work of a step (it was 25-30 % of the step time when wavefront 0 did both).
 // Barrier discipline: every wavefront executes the same s_barrier sequence per step: nck barriers inside
 // the data phase (one per target chunk; the producer executes them after its own work) + one at the end.
+// Register budget: 8-byte columns = up to 7 + 1 wavefronts per worker, two workers per CU -> 4 wavefronts per SIMD
+// (128 VGPRs); 16-byte columns = up to 4 + 1 wavefronts per worker, two workers per CU -> at most 3 per SIMD (168).
 template <int QM, int VEC, bool LOSS, int MM>
-__global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, const long long max_positions,
+__global__ void __launch_bounds__(VEC == 4 ? 320 : 512, VEC == 4 ? 3 : 4) k_train_workers2(const W2bParams P, const long long max_positions,
                                                            const int R, const int NDW) {
   extern __shared__ int smem[];
   W2B_LDS int *const smem_lds = (W2B_LDS int *)smem;
@@ -956,11 +962,19 @@ __global__ void __launch_bounds__(512, 4) k_train_workers2(const W2bParams P, co
 
 }  // namespace
 
-static int win2_threads(int dim) { return (((dim / 2) + 63) / 64 + 1) * 64; }
+// Column width of the sentence-resident kernel.  16 bytes per lane whenever the row allows it: measured with
+// tools/row_probe.hip, random 3200-byte rows move at 5.8 TB/s with 16-byte lanes against 4.2 TB/s with 8-byte lanes
+// at the same number of bytes in flight (the texture path is bound by lane-accesses, not bytes).
+static int win2_vec(int dim) {
+  if (const char *e = getenv("W2B_WIN2_VEC")) { const int v = atoi(e); if (v == 2 && dim % 2 == 0) return 2; }
+  return (dim % 4 == 0 && dim / 4 <= 4 * 64) ? 4 : 2;
+}
+int w2b_workers2_vec(int dim) { return win2_vec(dim); }
+static int win2_threads(int dim) { const int vec = win2_vec(dim); return (((dim / vec) + 63) / 64 + 1) * 64; }
 
 // Radius for which the sentence-resident kernel can run with two workgroups per CU (-1: use the plain kernel)
 int w2b_window_radius(int dim, int window, int negative) {
-  if (dim % 2 != 0 || dim > 2 * 64 * 7) return -1;     // 8-byte columns, at most 7 data wavefronts (+1 producer)
+  if (dim % 2 != 0 || dim > 2 * 64 * 7) return -1;     // 8- or 16-byte columns, at most 7 data wavefronts (+1 producer)
   const size_t budget = 80 * 1024;                 // two workgroups per 160 KiB CU
   if (win2_lds_bytes(dim, window, negative, window) <= budget) return window;
   if (window >= 2 && win2_lds_bytes(dim, window, negative, window - 1) <= budget) return window - 1;
@@ -976,6 +990,10 @@ int w2b_workers2_per_cu(const W2bParams &p, int R, bool loss) {
     constexpr int MM = decltype(mm)::value;
     return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
       constexpr int QM = decltype(qm)::value;
+      if (win2_vec(p.dim) == 4) {
+        if (loss) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, 4, true, MM>, win2_threads(p.dim), lds);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, 4, false, MM>, win2_threads(p.dim), lds);
+      }
       if (loss) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, 2, true, MM>, win2_threads(p.dim), lds);
       return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<QM, 2, false, MM>, win2_threads(p.dim), lds);
     });
@@ -991,7 +1009,8 @@ hipError_t w2b_launch_workers2(const W2bParams &p, long long max_positions, int 
   if (!reported && getenv("W2B_DEBUG")) {
     reported = true;
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<1, 2, false, 0>, threads, lds);
+    if (win2_vec(p.dim) == 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<1, 4, false, 0>, threads, lds);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_workers2<1, 2, false, 0>, threads, lds);
     fprintf(stderr, "w2b debug: sentence-resident kernel R=%d lds=%zu B, resident workgroups/CU=%d\n", R, lds, nb);
   }
   return dispatch_mm(p.mem_mode, [&](auto mm) -> hipError_t {
@@ -999,13 +1018,16 @@ hipError_t w2b_launch_workers2(const W2bParams &p, long long max_positions, int 
     return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
       constexpr int QM = decltype(qm)::value;
       // template MM carries the memory mode in bits 0-2 and "tables >= 2 GiB" (per-row descriptors) in bit 3
+#define W2B_LAUNCH_W2(VEC, LOSS, MMV) hipLaunchKernelGGL((k_train_workers2<QM, VEC, LOSS, MMV>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW)
+      const int vec = win2_vec(p.dim);
       if (p.tab_bytes) {
-        if (loss) hipLaunchKernelGGL((k_train_workers2<QM, 2, true, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
-        else hipLaunchKernelGGL((k_train_workers2<QM, 2, false, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
+        if (vec == 4) { if (loss) W2B_LAUNCH_W2(4, true, MM); else W2B_LAUNCH_W2(4, false, MM); }
+        else { if (loss) W2B_LAUNCH_W2(2, true, MM); else W2B_LAUNCH_W2(2, false, MM); }
       } else {
-        if (loss) hipLaunchKernelGGL((k_train_workers2<QM, 2, true, MM + 8>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
-        else hipLaunchKernelGGL((k_train_workers2<QM, 2, false, MM + 8>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW);
+        if (vec == 4) { if (loss) W2B_LAUNCH_W2(4, true, MM + 8); else W2B_LAUNCH_W2(4, false, MM + 8); }
+        else { if (loss) W2B_LAUNCH_W2(2, true, MM + 8); else W2B_LAUNCH_W2(2, false, MM + 8); }
       }
+#undef W2B_LAUNCH_W2
       return hipGetLastError();
     });
   });

@@ -521,6 +521,22 @@ extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
   return W2B_OK;
 }
 
+extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t *radius, int32_t *column_bytes,
+                                      int32_t *workgroups_per_cu) {
+  NEED(t);
+  const W2bParams p = make_params(t);
+  const int r = worker_radius(t);
+  if (resident) *resident = r >= 0;
+  if (radius) *radius = r;
+  int vec = 0;
+  (void)w2b_block_threads(t->cfg.layer1_size, &vec);
+  if (column_bytes) *column_bytes = 4 * (r >= 0 ? w2b_workers2_vec(t->cfg.layer1_size) : vec);
+  if (workgroups_per_cu)
+    *workgroups_per_cu = r >= 0 ? w2b_workers2_per_cu(p, r, t->cfg.compute_loss != 0)
+                                : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
+  return W2B_OK;
+}
+
 extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   NEED(t);
   if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_train_step: corpus/shards not set");

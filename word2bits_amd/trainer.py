@@ -192,6 +192,12 @@ class Trainer:
             if fin:
                 return loss
 
+    def worker_kernel_info(self):
+        """(resident, radius, column_bytes, workgroups_per_cu) of the form-(i) kernel train_step() runs"""
+        a, b, c, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(lib().w2b_worker_kernel_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return bool(a.value), b.value, c.value, d.value
+
     def suggested_threads(self):
         n = C.c_int32(0)
         check(lib().w2b_suggested_threads(self._h, C.byref(n)))
