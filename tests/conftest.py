@@ -24,6 +24,14 @@ def _gpu_count():
 @pytest.fixture(scope="session")
 def gpu():
     """Skips on machines without a GPU; on a GPU box a missing/unloadable library is an ERROR."""
+    # torch (used by a few tests for device-side checks of models too large to download) bundles its own HIP runtime:
+    # it only finds the GPU when it initialises BEFORE the library's runtime does (observed on the MI355X boxes:
+    # "No HIP GPUs are available" otherwise), which is also the order bench.py uses.
+    try:
+        import torch
+        torch.cuda.is_available() and torch.cuda.init()
+    except Exception:
+        pass
     import word2bits_amd
     L = word2bits_amd.lib()          # ImportError here is a hard failure, never a fallback
     if L.w2b_device_count() <= 0:

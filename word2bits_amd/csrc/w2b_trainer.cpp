@@ -201,6 +201,8 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(W2B_EINVAL, "device ordinal out of range");
   HIPCHK(hipSetDevice(cfg->device));
   w2b_trainer *t = new w2b_trainer();
+  // every HIPCHK below returns on failure: the guard releases what was allocated so far
+  struct Guard { w2b_trainer *t; ~Guard() { if (t) w2b_trainer_destroy(t); } } guard{t};
   t->cfg = *cfg;
   t->device = cfg->device;
   hipDeviceProp_t prop;
@@ -241,6 +243,7 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
     HIPCHK(hipMemcpy(t->jump_c, jc.data(), sizeof(unsigned long long) * nj, hipMemcpyHostToDevice));
   }
   HIPCHK(hipStreamSynchronize(t->stream));
+  guard.t = nullptr;
   *out = t;
   return W2B_OK;
 }
@@ -248,8 +251,8 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
 extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
-  (void)hipStreamSynchronize(t->stream);
-  if (getenv("W2B_DEBUG")) {
+  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  if (getenv("W2B_DEBUG") && t->shared) {
     W2bShared sh;
     if (hipMemcpy(&sh, t->shared, sizeof sh, hipMemcpyDeviceToHost) == hipSuccess) {
       fprintf(stderr, "w2b debug: phase ticks (100 MHz wall clock) of workgroup 0:");
@@ -264,7 +267,7 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
                   t->jump_a, t->jump_c, t->st_center, t->st_off, t->st_ctx, t->st_neg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
-  (void)hipStreamDestroy(t->stream);
+  if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
 }
 
@@ -438,6 +441,8 @@ extern "C" int w2b_synchronize(w2b_trainer *t) {
 extern "C" int w2b_set_corpus(w2b_trainer *t, const int32_t *ids, int64_t n) {
   NEED(t);
   if (!ids || n < 0) return fail(W2B_EINVAL, "w2b_set_corpus: bad argument");
+  for (int64_t i = 0; i < n; i++)       // a bad id would be an out-of-bounds row access on the device
+    if (ids[i] < 0 || ids[i] >= t->cfg.vocab_size) return fail(W2B_EINVAL, "w2b_set_corpus: token id out of range");
   HIPCHK(hipStreamSynchronize(t->stream));
   if (t->corpus_owned) HIPCHK(hipFree(t->corpus_owned));
   t->corpus_owned = nullptr;
@@ -462,6 +467,12 @@ extern "C" int w2b_set_corpus_device(w2b_trainer *t, const void *ids_dev, int64_
 extern "C" int w2b_set_shards(w2b_trainer *t, const int64_t *starts, const int32_t *ov) {
   if (!t || !starts) return fail(W2B_EINVAL, "w2b_set_shards: bad argument");
   const int nw = t->cfg.num_threads;
+  for (int i = 0; i < nw; i++) {
+    if (starts[i] < 0 || (t->corpus && starts[i] > t->n_tokens))
+      return fail(W2B_EINVAL, "w2b_set_shards: shard start outside the token stream");
+    if (ov && ov[i] != -2 && ov[i] != -1 && (ov[i] < 0 || ov[i] >= t->cfg.vocab_size))
+      return fail(W2B_EINVAL, "w2b_set_shards: first_override is neither -2, -1 nor a word id");
+  }
   t->shard_start.assign(starts, starts + nw);
   t->shard_override.assign(nw, -2);
   if (ov) t->shard_override.assign(ov, ov + nw);
@@ -472,6 +483,8 @@ extern "C" int w2b_set_shards(w2b_trainer *t, const int64_t *starts, const int32
 extern "C" int w2b_epoch_begin(w2b_trainer *t) {
   NEED(t);
   if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_epoch_begin: corpus/shards not set");
+  for (long long st : t->shard_start)
+    if (st > t->n_tokens) return fail(W2B_EINVAL, "w2b_epoch_begin: shard start outside the token stream");
   if (t->cfg.negative > 0 && !t->table) return fail(W2B_ESTATE, "w2b_epoch_begin: unigram table not set");
   if (t->cfg.sample > 0 && !t->keep) return fail(W2B_ESTATE, "w2b_epoch_begin: vocab counts not set");
   const int nw = t->cfg.num_threads;
@@ -663,9 +676,19 @@ extern "C" int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
   NCCLCHK(ncclCommInitRank(&t->comm, nranks, id, rank));
-  HIPCHK(hipMalloc(&t->base, sizeof(float) * 2 * t->table_elems));
-  HIPCHK(hipMemcpyAsync(t->base, t->uv, sizeof(float) * 2 * t->table_elems, hipMemcpyDeviceToDevice, t->stream));
-  HIPCHK(hipStreamSynchronize(t->stream));
+  hipError_t e = hipMalloc(&t->base, sizeof(float) * 2 * t->table_elems);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(t->base, t->uv, sizeof(float) * 2 * t->table_elems, hipMemcpyDeviceToDevice, t->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  if (e != hipSuccess) {                     // leave the trainer as a single replica, not half-initialised
+    if (t->base) (void)hipFree(t->base);
+    t->base = nullptr;
+    ncclCommDestroy(t->comm);
+    t->comm = nullptr;
+    t->nranks = 1;
+    t->rank = 0;
+    return fail(W2B_EHIP, std::string("w2b_comm_init: ") + hipGetErrorString(e));
+  }
   return W2B_OK;
 }
 

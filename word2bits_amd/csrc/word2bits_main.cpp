@@ -261,7 +261,7 @@ int main(int argc, char **argv) {
       }
     }
     printf("Epoch Loss: %lf\n", epoch_loss);                  // ref :539
-    if (o.save_every_epoch) {                                 // ref :540-557
+    if (o.save_every_epoch && o.classes == 0) {               // ref :540-542 (the per-epoch file only when classes == 0)
       char name[8192];
       snprintf(name, sizeof name, "%s_epoch%d", o.output_file.c_str(), iteration);
       save(o, corpus, reps[0].t, name);
