@@ -144,9 +144,10 @@ int w2b_suggested_threads(w2b_trainer *t, int32_t *out);
 
 /* Which form-(i) kernel w2b_train_step() runs for this trainer: *resident = 1 for the sentence-resident kernel
  * (*radius = sentence positions on either side of the centre word whose rows stay in LDS, *column_bytes = bytes
- * of a row owned by one lane), 0 for the plain kernel.  Any pointer may be NULL. */
+ * of a row owned by one lane, *hot_rows = leading rows of v with a private on-chip copy per worker -- chosen from
+ * the word counts of w2b_set_vocab_counts: 0 on flat distributions), 0 for the plain kernel.  Any pointer may be NULL. */
 int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t *radius, int32_t *column_bytes,
-                           int32_t *workgroups_per_cu);
+                           int32_t *workgroups_per_cu, int32_t *hot_rows);
 
 /* ---- form (ii): explicit tuples (benchmark / single-step parity form) ------------------------
  * n centre words; ctx_off[n+1] CSR into ctx[] (context rows of u, ref :431-447);

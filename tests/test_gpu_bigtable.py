@@ -44,9 +44,10 @@ def test_single_worker_epochs_bit_exact_row_desc(gpu, row_desc, bitlevel, sample
     test_gpu_exact.test_single_worker_epochs_bit_exact(gpu, bitlevel, sample, D, window, negative, iters)
 
 
-@pytest.mark.parametrize("D,window,negative,bitlevel", [(800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0)])
-def test_resident_equals_plain_single_worker_row_desc(gpu, row_desc, D, window, negative, bitlevel):
-    test_gpu_worker.test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, window, negative, bitlevel)
+@pytest.mark.parametrize("D,window,negative,bitlevel", [(800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0), (800, 11, 5, 1)])
+def test_resident_equals_plain_single_worker_row_desc(gpu, row_desc, D, window, negative, bitlevel, monkeypatch):
+    test_gpu_worker.test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, window, negative, bitlevel,
+                                                                                    None, monkeypatch)
 
 
 @pytest.mark.parametrize("threads,size,window,bitlevel", [(16, 200, 8, 1), (5, 800, 8, 0)])
@@ -175,7 +176,6 @@ def big_table_worker_check(V, D, window, negative, bitlevel, positions=2500, see
     ids[40::41] = 0
     cn = np.ones(V, np.int64)
     cn[ids[ids > 0]] += 50
-    os.environ["W2B_HOT_ROWS"] = "0"          # the hot-row placement reorders targets (see test_gpu_worker.py)
     try:
         models = []
         for wc in (True, False):
@@ -198,7 +198,7 @@ def big_table_worker_check(V, D, window, negative, bitlevel, positions=2500, see
         assert same
         assert moved >= 0.9 * len(np.unique(ids[ids > 0]))      # the run really trained rows all over the table
     finally:
-        os.environ.pop("W2B_HOT_ROWS", None)
+        pass
 
 
 # ------------------------------------------------------------------------------- 2. a genuine > 2 GiB table

@@ -147,15 +147,23 @@ def test_shard_override_and_multi_worker_bookkeeping(gpu, window_cache):
     t.close()
 
 
-@pytest.mark.parametrize("D,window,negative,bitlevel", [(800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0), (96, 1, 2, 1)])
-def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, window, negative, bitlevel):
+@pytest.mark.parametrize("D,window,negative,bitlevel", [
+    (800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0), (96, 1, 2, 1),
+    (1000, 8, 12, 1),        # BASELINE configs[4] row length: the whole window still fits next to a second workgroup
+    (800, 11, 5, 1),         # window too wide for LDS: radius window-1, the outermost context rows are register-held
+    (1024, 3, 3, 2),         # the widest row of the 16-byte-column form
+])
+@pytest.mark.parametrize("hot", ["0", None, "8"])
+def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, window, negative, bitlevel, hot, monkeypatch):
     """The LDS-resident window is an optimisation, not a different algorithm: with one worker nobody else
     touches a resident row, so the exact fp32 value is written back and the whole model must come out
-    BIT-IDENTICAL to the plain kernel (same launches, same dot-product reduction tree).  The register-resident
-    hot target rows are switched off here: they reorder the targets of a chunk (hot rows first), which changes
-    the rounding of the error sum -- their parity is covered by the oracle tests above."""
-    import os
-    os.environ["W2B_HOT_ROWS"] = "0"
+    BIT-IDENTICAL to the plain kernel (same launches, same dot-product reduction tree, same target order) --
+    without private hot target rows (W2B_HOT_ROWS=0), with the number the library derives from the word counts
+    (unset) and with as many as fit (8)."""
+    if hot is None:
+        monkeypatch.delenv("W2B_HOT_ROWS", raising=False)
+    else:
+        monkeypatch.setenv("W2B_HOT_ROWS", hot)
     V, n = 300, 6000
     rng = np.random.default_rng(9)
     ids = token_stream(rng, V, n, line=23)          # short sentences: many window fills/flushes
@@ -170,11 +178,14 @@ def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, wind
         t.set_vocab_counts(cn, 50000)
         t.set_corpus(ids)
         t.set_shards(np.zeros(1, np.int64))
+        if wc:
+            resident, radius, colb, _, nh = t.worker_kernel_info()
+            assert resident and colb == 16 and radius == (window - 1 if (D, window) == (800, 11) else window)
+            assert (nh == 0) if (hot == "0" or D >= 1000) else (nh >= 1)     # D >= 1000: the window leaves no room
         loss = t.train_epoch(positions_per_launch=pos)
         u, v = t.get_model()
         out.append((u, v, loss, t.epoch_status()[1]))
         t.close()
-    os.environ.pop("W2B_HOT_ROWS", None)
     for k in (1, 2):
         assert out[0][3] == out[k][3]
         assert np.array_equal(out[0][0].view(np.uint32), out[k][0].view(np.uint32))
@@ -185,8 +196,8 @@ def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, wind
 @pytest.mark.parametrize("threads,size,window,bitlevel", [(16, 200, 8, 1), (8, 64, 3, 2), (5, 800, 8, 0)])
 def test_sentence_resident_kernel_equals_plain_kernel_many_workers(gpu, threads, size, window, bitlevel, tmp_path):
     """Several Hogwild workers, deterministic anyway (shards with disjoint vocabularies, -negative 0, shards shorter
-    than an alpha period: no two workers share a row): the sentence-resident kernel -- window slots, fp16 deltas,
-    exact-or-merge write-back, register-resident hot rows, producer wavefront -- must write the same file as the
+    than an alpha period: no two workers share a row): the sentence-resident kernel -- window slots, scratch entries,
+    exact-or-merge write-back, private hot target rows, producer wavefront -- must write the same file as the
     plain kernel, byte for byte."""
     import os
     import subprocess

@@ -238,7 +238,7 @@ __device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int neg
 // Lane-parallel compares on register copies (v_readlane broadcasts) instead of O(n^2) LDS loops.
 template <int T, typename IP>
 __device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP ctx, IP umult, int cw,
-                                          int lane, bool with_dep = false, bool hot_first = false) {
+                                          int lane) {
   W2B_WAVE_SYNC();
   for (int i0 = 0; i0 < nt; i0 += 64) {
     const int i = i0 + lane;
@@ -275,32 +275,7 @@ __device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP c
       const unsigned long long m = __ballot(hit);
       if (m) { end = i0 + __ffsll((long long)m) - 1; break; }
     }
-    int dep = 0;                   // with_dep: bit 16 = the chunk holds a row that an earlier chunk also holds
-    if (with_dep) {
-      for (int i0 = start; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        dep |= (__ballot((i < end) && (prev[i] >= 0)) != 0ull) ? 1 : 0;
-      }
-    }
-    if (hot_first && end - start <= 64) {
-      // Hot-row placement (sentence-resident kernel): inside a chunk the register-resident rows 1 and 2 of v
-      // move to slots 0 / 1, so the data wavefronts test for them at two compile-time slots only.  Bit 30 of
-      // an entry carries its label (the centre word may move away from list index 0).  A chunk never holds
-      // a row twice, so at most one entry each.
-      const int i = start + lane;
-      const bool in = i < end;
-      int ent = in ? tgt[i] : 0;
-      if (in && i == 0) ent |= 1 << 30;
-      const int row = ent & 0x3fffffff;
-      const bool is1 = in && row == 1, is2 = in && row == 2;
-      const int has1 = __ballot(is1) != 0ull, has2 = __ballot(is2) != 0ull;
-      const unsigned long long mcold = __ballot(in && !is1 && !is2);
-      const int pos = is1 ? 0 : (is2 ? has1 : has1 + has2 + __popcll(mcold & lane_lt_mask(lane)));
-      W2B_WAVE_SYNC();
-      if (in) tgt[start + pos] = ent;
-      W2B_WAVE_SYNC();
-    }
-    if (lane == 0) cend[k] = end | (dep << 16);
+    if (lane == 0) cend[k] = end;
     k++;
     start = end;
   }
@@ -532,6 +507,11 @@ __device__ __forceinline__ unsigned long long fast_mod(unsigned long long n, uns
   if (r >= d) r -= d;
   return r;
 }
+// word_count_actual of ALL replicas for the alpha schedule (ref :391); see W2bShared
+__device__ __forceinline__ long long w2b_global_progress(const W2bParams &P, long long wca_local) {
+  const long long others_per_self = P.total_threads / P.num_threads - 1;        // replicas - 1
+  return wca_local + (long long)P.shared->wca_others + others_per_self * (wca_local - (long long)P.shared->wca_at_sync);
+}
 __device__ __forceinline__ unsigned long long lcg_jump(const W2bParams &P, unsigned long long x, int k) {
   return P.jump_a[k] * x + P.jump_c[k];
 }
@@ -603,6 +583,9 @@ struct WorkerLds {            // scalars of one worker, owned by wavefront 0
 
 template <typename F>
 hipError_t dispatch_q(int bitlevel, F &&f) {
+#ifdef W2B_QUICK_BUILD      // developer builds: only the 1-bit instantiations (register / ISA studies)
+  return f(std::integral_constant<int, 1>());
+#endif
   switch (bitlevel) {
     case 0: return f(std::integral_constant<int, 0>());
     case 1: return f(std::integral_constant<int, 1>());

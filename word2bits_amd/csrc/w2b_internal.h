@@ -18,6 +18,12 @@ struct W2bShared {
   double loss_tuples;   // loss sum of the tuple form (form ii)
   int workers_done;
   int pad1;
+  // replicas (one per GPU): word_count_actual above is LOCAL.  The alpha schedule (ref :391) runs on the global count:
+  // what the other replicas had done at the last exchange + the assumption that each of them has advanced like this
+  // one since (exact at every exchange; single replica: both fields stay 0 and the schedule is the reference's).
+  unsigned long long wca_others;      // sum of the other replicas' word_count_actual at the last exchange
+  unsigned long long wca_at_sync;     // this replica's word_count_actual at the last exchange
+  double loss_epoch;                  // sum of the workers' total_loss of the running epoch (ref :537-538)
   unsigned long long dbg[16];   // phase timers of workgroup 0 (builds with -DW2B_PHASE_TIMERS only)
 };
 
@@ -51,8 +57,8 @@ struct W2bParams {
   int dim, window, negative, bitlevel, num_threads;
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
   int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
-  int hot_rows;                   // sentence-resident kernel: keep rows 1 and 2 of v in registers (0 = off)
-  int hot_period;                 // steps between merges of the register-resident hot rows (power of two)
+  float *entry;                   // sentence-resident kernel: scratch rows [num_threads][2][slots][dim] (see w2b_kernels_resident.hip)
+  int hot_period;                 // sentence-resident kernel: steps between merges of the private hot target rows (power of two)
   int exact;                      // serial dot product in the reference's order (plain worker / tuple kernels)
   float starting_alpha, sample, reg;
 };
@@ -66,12 +72,13 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
                              float alpha, int grid, int num_cus, int per_cu_override, bool loss,
                              hipStream_t s);
 hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s);
-// sentence-resident variant (w2b_kernels_workers2.hip): radius >= 0 when it can run for this shape
-int w2b_window_radius(int dim, int window, int negative);
-int w2b_workers2_vec(int dim);                                         // floats per lane of the sentence-resident kernel
-hipError_t w2b_launch_workers2(const W2bParams &p, long long max_positions, int radius, bool loss, hipStream_t s);
+// sentence-resident variant (w2b_kernels_resident.hip): radius >= 0 when it can run for this shape; *hot_out = how many
+// of the hot_wanted most frequent target rows get a private LDS slot next to the window
+int w2b_resident_plan(int dim, int window, int negative, int hot_wanted, int *hot_out);
+long long w2b_resident_scratch_rows(int radius, int hot);              // scratch rows per worker
+hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int radius, int hot, bool loss, hipStream_t s);
 int w2b_workers_per_cu(const W2bParams &p, bool loss);                  // resident workgroups per CU, plain kernel
-int w2b_workers2_per_cu(const W2bParams &p, int radius, bool loss);     // ... sentence-resident kernel
+int w2b_resident_per_cu(const W2bParams &p, int radius, int hot, bool loss);     // ... sentence-resident kernel
 hipError_t w2b_launch_init_net(float *u, float *v, long long n_per_table, const float *lut,
                                hipStream_t s);
 hipError_t w2b_launch_export(const float *u, const float *v, float *out, long long n, int bitlevel,

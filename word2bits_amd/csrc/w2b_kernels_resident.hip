@@ -1,0 +1,860 @@
+// w2b_kernels_resident.hip -- form (i), SENTENCE-RESIDENT variant of the worker kernel.
+//
+// Consecutive sentence positions share 2*window-1 of their context rows (ref src/word2bits.cpp:431-436
+// walks sen[p-window .. p+window]).  The plain worker kernel (w2b_kernels_workers.hip) reads and writes
+// every context row of every position from/to HBM: 2*cw of the 2*(cw+K+1) row transfers per centre
+// word.  Here a workgroup keeps the fp32 rows of the sliding window [p-R, p+R] RESIDENT IN LDS:
+//   * a row enters the window once (one read) and leaves it once (one read-modify-write), however
+//     many centre words use it in between;  phase A (ref :431-449) and phase C (ref :494-503) become
+//     LDS traffic;
+//   * a word that occurs at several window positions shares ONE slot (reference semantics: a row
+//     that occurs twice is updated twice, in order);
+//   * when a row enters the window its value is also written to a per-worker SCRATCH row in global memory
+//     ("what it looked like when it entered").  When the row leaves and nobody else changed it meanwhile
+//     (wavefront checksum of the row bits), the exact fp32 value is stored -- a single worker stays
+//     bit-identical to the plain kernel; otherwise the worker's own contribution (value - entry, in fp32) is
+//     added to the CURRENT row (merge), so concurrent Hogwild workers do not erase each other's updates.  The
+//     scratch row is read only in that conflict case, and LDS holds nothing but the fp32 values -- the whole
+//     window (R = window) fits next to a second workgroup up to D = 1000;
+//   * the most frequent target rows of v (rows 1..hot_n: the vocabulary is sorted by frequency; hot_n is chosen
+//     by the host from the word counts, 0 on flat distributions) get private LDS slots of the same kind, merged
+//     with memory every hot_period steps.  Coherent accesses to one embedding row serialise at its memory line
+//     (about 7 M read-modify-writes per second); on Zipf-distributed ids the most frequent word alone is a target
+//     of 0.3 centre words in every position;
+//   * rows are thread-private 16-byte columns of LDS (a thread only ever touches its own 16 bytes of every
+//     slot): no barriers, no bank conflicts; memory is accessed 16 bytes per lane (tools/row_probe.hip: random
+//     3200-byte rows move at 5.8 TB/s with 16-byte lanes against 4.2 TB/s with 8-byte lanes at the same number of
+//     bytes in flight).
+// The radius R is window when the window fits in LDS next to a second workgroup, else window-1 with
+// the two outermost context rows held in registers for the step; otherwise the launcher falls back
+// to the plain kernel.
+#include "w2b_device.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+
+#define W2B_RT 13       // target rows per chunk: 13 x 4 VGPRs (negative=24 -> 25 targets = 13 + 12)
+#define W2B_NDWMAX 4    // data wavefronts per worker (one thread per 16-byte column: D <= 1024) + 1 producer wavefront
+#define W2B_RCH 2       // window rows moved per trip when many enter/leave at once (sentence boundaries)
+#define W2B_HOTMAX 8    // most target rows with a private LDS slot
+
+namespace {
+
+struct Win2Lds {          // scalars owned by the producer wavefront (extends WorkerLds)
+  WorkerLds w;
+  int clo, chi;           // sentence positions currently resident (empty when chi < clo)
+};
+
+// What the producer wavefront hands to the data wavefronts for ONE step (double buffered in LDS)
+struct Step2 {
+  int stop;               // 1: this pass only empties the window (epoch finished, or end of the launch)
+  int cw, nt, uc_n, n_ret, n_adm;
+  int next_row;           // row of the position that enters the window at the NEXT step (-1: unknown / none)
+  int nck;                // number of target chunks = number of workgroup barriers inside the data phase
+  float alpha;
+  int pad[3];
+};
+
+// Explicit LDS address space on every pointer of the kernel's LDS record: dereferences compile to ds_*
+// instructions.  (With generic pointers the two step buffers were selected through a struct reference and
+// address-space inference gave up: 250 flat_load/flat_store per step, each tied to vmcnt AND lgkmcnt, so
+// every window access also waited for the target rows in flight.)
+#define W2B_LDS __attribute__((address_space(3)))
+
+struct Win2 {
+  W2B_LDS float *win;             // [S + NH][dim]  current fp32 value of the resident rows (window slots, then hot rows)
+  W2B_LDS unsigned *csum;         // [S + NH][4]    per-wavefront xor checksum of the row bits at entry / last merge
+  W2B_LDS float *red;             // [2][W2B_RT][4]
+  W2B_LDS int *slot_row, *slot_ref, *pos_slot, *slot_gen;                      // [S]
+  W2B_LDS int *ret_slot, *ret_row, *ret_gen, *adm_slot, *adm_row, *adm_gen;    // [S+2]
+  W2B_LDS int *cslot;             // [maxc] slot of every context position; -1-k = k-th register-held row
+  W2B_LDS int *uc_row;            // [2]   rows of the (at most two) context positions outside the radius
+  W2B_LDS int *tgt, *prev, *cend; // [maxt]
+  W2B_LDS int *sen;               // [1000]
+  W2B_LDS unsigned long long *ja, *jc;   // [nj] LCG jump-ahead table (copy of P.jump_a / P.jump_c)
+  W2B_LDS Win2Lds *S;
+  W2B_LDS Step2 *St;              // per-step scalars (this struct exists twice: one per step buffer)
+};
+
+__host__ __device__ inline int w2_round4(int x) { return (x + 3) & ~3; }
+
+// LDS bytes of the sentence-resident kernel for radius R and NH hot target rows
+__host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negative, int R, int NH) {
+  const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
+  size_t b = (size_t)(S + NH) * dim * 4;                           // win
+  b = (b + 15) & ~(size_t)15;
+  b += (size_t)(S + NH) * W2B_NDWMAX * 4;                          // csum
+  b += 2 * W2B_RT * W2B_NDWMAX * 4;                                // red
+  b += (size_t)(4 * w2_round4(S) + maxt + w2_round4(W2B_MAX_SEN)) * 4;               // slot tables, prev, sen
+  b += 2 * ((size_t)(6 * w2_round4(S + 2) + maxc + 4 + 2 * maxt) * 4 + sizeof(Step2));  // step lists x 2
+  b += sizeof(Win2Lds) + 16;
+  b += (size_t)2 * 8 * (negative + 2 > 66 ? negative + 2 : 66) + 16;   // LCG jump tables
+  return b;
+}
+
+__device__ __forceinline__ Win2 carve_win2(W2B_LDS int *base, int dim, int window, int negative, int R, int NH, int buf) {
+  const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
+  Win2 L;
+  W2B_LDS char *p = (W2B_LDS char *)base;
+  L.win = (W2B_LDS float *)p; p += (size_t)(S + NH) * dim * 4;
+  p = (W2B_LDS char *)(((unsigned)(size_t)p + 15u) & ~15u);
+  L.csum = (W2B_LDS unsigned *)p; p += (size_t)(S + NH) * W2B_NDWMAX * 4;
+  L.red = (W2B_LDS float *)p; p += 2 * W2B_RT * W2B_NDWMAX * 4;
+  W2B_LDS int *q = (W2B_LDS int *)p;
+  L.slot_row = q; q += w2_round4(S);
+  L.slot_ref = q; q += w2_round4(S);
+  L.pos_slot = q; q += w2_round4(S);
+  L.slot_gen = q; q += w2_round4(S);
+  L.prev = q; q += maxt;
+  L.sen = q; q += w2_round4(W2B_MAX_SEN);
+  const int per_buf = 6 * w2_round4(S + 2) + maxc + 4 + 2 * maxt + (int)(sizeof(Step2) / 4);
+  q += buf * per_buf;                                  // the per-step lists exist twice
+  L.ret_slot = q; q += w2_round4(S + 2);
+  L.ret_row = q; q += w2_round4(S + 2);
+  L.ret_gen = q; q += w2_round4(S + 2);
+  L.adm_slot = q; q += w2_round4(S + 2);
+  L.adm_row = q; q += w2_round4(S + 2);
+  L.adm_gen = q; q += w2_round4(S + 2);
+  L.cslot = q; q += maxc;
+  L.uc_row = q; q += 4;
+  L.tgt = q; q += maxt;
+  L.cend = q; q += maxt;
+  L.St = (W2B_LDS Step2 *)q; q += sizeof(Step2) / 4;
+  q += (1 - buf) * per_buf;
+  L.S = (W2B_LDS Win2Lds *)(((unsigned)(size_t)q + 15u) & ~15u);
+  const int nj = negative + 2 > 66 ? negative + 2 : 66;
+  L.ja = (W2B_LDS unsigned long long *)(((unsigned)(size_t)(L.S + 1) + 15u) & ~15u);
+  L.jc = L.ja + nj;
+  return L;
+}
+
+typedef Col<4> Col4;
+__device__ __forceinline__ unsigned col_bits(const Col4 &c) {
+  unsigned h = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++) h ^= __float_as_uint(c.e[e]) * (2u * e + 3u);
+  return h;
+}
+__device__ __forceinline__ Col4 col_zero() {
+  Col4 c;
+#pragma unroll
+  for (int e = 0; e < 4; e++) c.e[e] = 0.f;
+  return c;
+}
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// LDS accesses of a thread's own 16-byte column of a resident row
+__device__ __forceinline__ Col4 lds_ld(const W2B_LDS float *p) {
+  const f32x4_t t = *(const W2B_LDS f32x4_t *)p;
+  Col4 c;
+  c.e[0] = t.x; c.e[1] = t.y; c.e[2] = t.z; c.e[3] = t.w;
+  return c;
+}
+__device__ __forceinline__ void lds_st(W2B_LDS float *p, const Col4 &c) {
+  f32x4_t t;
+  t.x = c.e[0]; t.y = c.e[1]; t.z = c.e[2]; t.w = c.e[3];
+  *(W2B_LDS f32x4_t *)p = t;
+}
+
+// Everything a data thread needs to address the tables, its scratch rows and its columns
+template <int MM>
+struct Rows {
+  static constexpr int M = MM & 7, TB = (MM >> 3) & 1;     // memory mode, table form (1 = per-row descriptors)
+  const W2bParams &P;
+  long long scratch0;      // first scratch row of this worker
+  int nsh;                 // scratch rows per generation = window slots + hot rows
+  int dim, col0;
+  bool active;
+  __device__ __forceinline__ Col4 ld_u(int row) const { return load_col<4, M, TB>(P.u, row, dim, col0, P.tab_bytes); }
+  __device__ __forceinline__ Col4 ld_v(int row) const { return load_col<4, M, TB>(P.v, row, dim, col0, P.tab_bytes); }
+  __device__ __forceinline__ void st_u(int row, const Col4 &c) const { store_col<4, M, TB>(P.u, row, dim, col0, c, P.tab_bytes); }
+  __device__ __forceinline__ void st_v(int row, const Col4 &c) const { store_col<4, M, TB>(P.v, row, dim, col0, c, P.tab_bytes); }
+  // scratch ("entry") rows: written with plain stores, read back (rarely) past the L1
+  __device__ __forceinline__ Col4 ld_entry(int gen, int slot) const {
+    return load_col<4, 0, 1>(P.entry, scratch0 + (long long)gen * nsh + slot, dim, col0, 0u);
+  }
+  __device__ __forceinline__ void st_entry(int gen, int slot, const Col4 &c) const {
+    store_col<4, 1, 1>(P.entry, scratch0 + (long long)gen * nsh + slot, dim, col0, c, 0u);
+  }
+};
+
+// ---- write-back of one leaving row: exact value if nobody else changed the row, else merge our contribution
+template <int MM>
+__device__ __forceinline__ void retire_finish(const Rows<MM> &A, int row, int gen, int slot, unsigned csum_at_entry,
+                                              const Col4 &g, const Col4 &rw) {
+  const unsigned now = wave_xor(A.active ? col_bits(g) : 0u);
+  const bool untouched = (now == csum_at_entry);                          // wave-uniform
+  if (untouched) {
+    if (A.active) A.st_u(row, rw);
+  } else {
+    if (A.active) {
+      const Col4 en = A.ld_entry(gen, slot);
+      Col4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) o.e[e] = g.e[e] + (rw.e[e] - en.e[e]);
+      A.st_u(row, o);
+    }
+  }
+}
+
+// ---- rows leaving the window (sentence boundaries: many at once)
+template <int MM>
+__device__ __forceinline__ void window_retire(const Rows<MM> &A, const Win2 &L, int n_ret, int wave) {
+  for (int i0 = 0; i0 < n_ret; i0 += W2B_RCH) {
+    Col4 rw[W2B_RCH], g[W2B_RCH];
+#pragma unroll
+    for (int i = 0; i < W2B_RCH; i++) {
+      rw[i] = col_zero(); g[i] = col_zero();
+      if (i0 + i < n_ret && A.active) {
+        rw[i] = lds_ld(L.win + L.ret_slot[i0 + i] * A.dim + A.col0);
+        g[i] = A.ld_u(L.ret_row[i0 + i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W2B_RCH; i++)
+      if (i0 + i < n_ret) {
+        const int s = L.ret_slot[i0 + i];
+        retire_finish<MM>(A, L.ret_row[i0 + i], L.ret_gen[i0 + i], s, L.csum[s * W2B_NDWMAX + wave], g[i], rw[i]);
+      }
+  }
+}
+
+// ---- rows entering the window
+template <int MM>
+__device__ __forceinline__ void window_admit(const Rows<MM> &A, const Win2 &L, int n_adm, int lane, int wave) {
+  for (int i0 = 0; i0 < n_adm; i0 += W2B_RCH) {
+    Col4 a[W2B_RCH];
+#pragma unroll
+    for (int i = 0; i < W2B_RCH; i++) {
+      a[i] = col_zero();
+      if (i0 + i < n_adm && A.active) a[i] = A.ld_u(L.adm_row[i0 + i]);
+    }
+#pragma unroll
+    for (int i = 0; i < W2B_RCH; i++)
+      if (i0 + i < n_adm) {
+        const int s = L.adm_slot[i0 + i];
+        const unsigned cs = wave_xor(A.active ? col_bits(a[i]) : 0u);
+        if (lane == 0) L.csum[s * W2B_NDWMAX + wave] = cs;
+        if (A.active) {
+          lds_st(L.win + s * A.dim + A.col0, a[i]);
+          A.st_entry(L.adm_gen[i0 + i], s, a[i]);
+        }
+      }
+  }
+}
+
+// ---- the private copies of the hottest target rows meet memory: exact value if nobody else changed the row since
+// the last merge, else our contribution since then is added to the current row.  Only workers that actually added
+// something write (a read-modify-write by a worker with nothing to publish could only overwrite a newer value).
+template <int MM>
+__device__ __forceinline__ void hot_merge(const Rows<MM> &A, const Win2 &L, int NS, int NH, unsigned &dirty, int lane, int wave) {
+  for (int k = 0; k < NH; k++) {
+    const int slot = NS + k;
+    Col4 g = col_zero();
+    if (A.active) g = A.ld_v(k + 1);
+    const unsigned now = wave_xor(A.active ? col_bits(g) : 0u);
+    if (!((dirty >> k) & 1u)) {                      // nothing of ours: adopt the current row
+      if (A.active) {
+        lds_st(L.win + slot * A.dim + A.col0, g);
+        A.st_entry(0, slot, g);
+      }
+      if (lane == 0) L.csum[slot * W2B_NDWMAX + wave] = now;
+      continue;
+    }
+    const bool untouched = (now == L.csum[slot * W2B_NDWMAX + wave]);
+    Col4 val = col_zero();
+    if (A.active) {
+      val = lds_ld(L.win + slot * A.dim + A.col0);
+      if (!untouched) {
+        const Col4 en = A.ld_entry(0, slot);
+#pragma unroll
+        for (int e = 0; e < 4; e++) val.e[e] = g.e[e] + (val.e[e] - en.e[e]);
+        lds_st(L.win + slot * A.dim + A.col0, val);
+      }
+      A.st_v(k + 1, val);
+      A.st_entry(0, slot, val);
+    }
+    const unsigned cs = wave_xor(A.active ? col_bits(val) : 0u);
+    if (lane == 0) L.csum[slot * W2B_NDWMAX + wave] = cs;
+  }
+  dirty = 0u;
+}
+
+// --------------------------------------------------------------------------------------------------
+// NDW + 1 wavefronts per worker: wavefronts 0..NDW-1 own the embedding columns (data phase); the last one is the
+// PRODUCER: it walks the sentence, the LCG ledger, the window bookkeeping and the negative draws ONE STEP
+// AHEAD and hands the lists over through a double-buffered LDS record.  The data wavefronts never wait for
+// the scalar work of a step (it was 25-30 % of the step time when wavefront 0 did both).
+// Barrier discipline: every wavefront executes the same s_barrier sequence per step: nck barriers inside
+// the data phase (one per target chunk; the producer executes them after its own work) + one at the end.
+// Register budget: two workers per CU = at most 3 wavefronts per SIMD -> 168 VGPRs.
+// UC: the radius is window-1 (the two outermost context rows of a step are register-held).
+template <int QM, bool LOSS, int MM, bool UC>
+__global__ void __launch_bounds__(320, 3) k_train_resident(const W2bParams P, const long long max_positions,
+                                                           const int R, const int NDW, const int NH) {
+  extern __shared__ int smem[];
+  W2B_LDS int *const smem_lds = (W2B_LDS int *)smem;
+  const Win2 L0 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, NH, 0);
+  const Win2 L1 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, NH, 1);
+  const Win2 &L = L0;                                   // everything that is not double buffered
+  W2B_LDS WorkerLds *S = &L.S->w;
+  W2B_LDS int *s_sen = L.sen;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = (wave == NDW);
+  const int wid = blockIdx.x;
+  if (wid >= P.num_threads) return;
+  W2bWorker *G = P.workers + wid;
+  if (G->done) return;
+  QParam qp;
+  qp.bitlevel = P.bitlevel;
+  qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
+  qp.steps_f = (float)qp.steps_i;
+  const int NS = 2 * R + 1;
+  const Rows<MM> A{P, (long long)wid * 2 * (NS + NH), NS + NH, P.dim, tid * 4, !producer && tid * 4 < P.dim};
+  const bool active = A.active;
+  for (int i = tid; i < G->sen_len; i += blockDim.x) s_sen[i] = G->sen[i];
+  for (int i = tid; i < NS; i += blockDim.x) { L.slot_row[i] = -1; L.slot_ref[i] = 0; L.pos_slot[i] = 0; L.slot_gen[i] = 0; }
+  for (int i = tid; i < (P.negative + 2 > 66 ? P.negative + 2 : 66); i += blockDim.x) { L.ja[i] = P.jump_a[i]; L.jc[i] = P.jump_c[i]; }
+  if (tid == 0) {
+    S->rng = G->rng; S->cursor = G->cursor; S->wc = G->word_count; S->last_wc = G->last_word_count;
+    S->sen_len = G->sen_len; S->sen_pos = G->sen_pos; S->override_ = G->first_override;
+    S->eof = 0; S->done = 0; S->cw = 0; S->nt = 0; S->alpha = 0.f;
+    L.S->clo = 0; L.S->chi = -1;
+  }
+  __syncthreads();
+  double loss_acc = 0.0;
+  const int W = P.window, K = P.negative;
+  // producer registers: the unigram-table gather and the alpha load of the NEXT step are issued at the end
+  // of a preparation, so that their latency is not on the producer's critical path either
+  int t_pref = 0;
+  bool pref_ok = false;
+  float alpha_pref = P.starting_alpha;
+  bool alpha_pref_ok = false;
+  // data-wavefront registers: the row that enters the window at the next step, loaded one step early
+  Col4 apre = col_zero();
+  int apre_row = -1;
+  // data-wavefront registers: the target rows of the current chunk
+  Col4 x[W2B_RT];
+  int rows[W2B_RT];
+#pragma unroll
+  for (int i = 0; i < W2B_RT; i++) { x[i] = col_zero(); rows[i] = 0; }
+  // data wavefronts: private copies of the hottest target rows (LDS slots NS .. NS+NH-1); bit k of `dirty` = this
+  // worker has updated hot row k since the last merge (wave-uniform)
+  unsigned dirty = 0u;
+  if (!producer) {
+    for (int k = 0; k < NH; k++) {
+      Col4 h = col_zero();
+      if (active) {
+        h = A.ld_v(k + 1);
+        lds_st(L.win + (NS + k) * P.dim + A.col0, h);
+        A.st_entry(0, NS + k, h);
+      }
+      const unsigned c = wave_xor(active ? col_bits(h) : 0u);
+      if (lane == 0) L.csum[(NS + k) * W2B_NDWMAX + wave] = c;
+    }
+  }
+
+  // ---- the preparation of one pass (producer wavefront only; all 64 lanes, wave-uniform control flow)
+  auto prepare = [&](const Win2 &O, const bool last) {
+      unsigned long long rng = S->rng;
+      long long cursor = S->cursor, wc = S->wc, last_wc = S->last_wc;
+      int sen_len = S->sen_len, sen_pos = S->sen_pos, ovr = S->override_, eof = S->eof;
+      int done = 0, cw = 0, nt = 0, uc_n = 0, nck = 0, next_row = -1;
+      float alpha = 0.f, alpha_own = 0.f;
+      bool new_sentence = false, alpha_set = false;
+      int lo = 0, hi = -1;                               // window wanted for this step (empty = flush)
+      int p = 0, b = 0, word = 0;
+      bool train = false;
+      if (!last) {
+        if (wc - last_wc > 10000) {                                    // ref :379-393
+          if (lane == 0) {
+            const unsigned long long d = (unsigned long long)(wc - last_wc);
+            const unsigned long long wca = atomicAdd(&P.shared->word_count_actual, d) + d;
+            const long long wca_all = w2b_global_progress(P, (long long)wca);
+            float a = P.starting_alpha * (1.f - (float)wca_all / (float)(P.iter * P.train_words + 1));
+            if ((double)a < (double)P.starting_alpha * 0.0001) a = (float)((double)P.starting_alpha * 0.0001);
+            __hip_atomic_store(&P.shared->alpha, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alpha_own = a;
+          }
+          alpha_own = __shfl(alpha_own, 0, 64);
+          alpha_set = true;                              // this worker's own write is the newest value it may see
+          last_wc = wc;
+        }
+        if (sen_len == 0) {                                            // ref :394-413
+          read_sentence(P, (int *)s_sen, rng, cursor, wc, ovr, eof, sen_len, lane);
+          sen_pos = 0;
+          new_sentence = true;
+          W2B_WAVE_SYNC();
+        }
+        if (eof || wc > P.train_words / P.total_threads) {            // ref :414-423
+          if (lane == 0) atomicAdd(&P.shared->word_count_actual, (unsigned long long)(wc - last_wc));
+          last_wc = wc;
+          done = 1;
+        } else {
+          train = true;
+          p = sen_pos;
+          word = (sen_len > 0) ? s_sen[p] : 0;                          // ref :424
+          rng = rng * W2B_LCG_A + W2B_LCG_C;                            // ref :428-429
+          b = (int)fast_mod(rng, (unsigned long long)W, P.window_magic);
+          if (sen_len > 0) { lo = max(0, p - R); hi = min(sen_len - 1, p + R); }
+        }
+      }
+      // ---------------- window bookkeeping: make the resident range [lo, hi]
+      int clo = L.S->clo, chi = L.S->chi, n_ret = 0, n_adm = 0;
+      if (new_sentence || !train) {
+        if (lane < NS) L.slot_ref[lane] = 0;              // every resident position belonged to the old sentence
+        clo = 0; chi = -1;
+        W2B_WAVE_SYNC();
+      } else {
+        for (int q = clo; q <= chi; q++) {                // positions that leave: [clo, lo) and (hi, chi]
+          if (q >= lo && q <= hi) { q = hi; continue; }
+          if (lane == 0) L.slot_ref[L.pos_slot[q % NS]]--;
+          W2B_WAVE_SYNC();
+        }
+      }
+      // Positions entering the window.  Pass 1 re-uses rows that are still resident (also rows of
+      // positions that just left: they are revived instead of being written back and re-read).  Pass 2
+      // gives the remaining words a slot; only then may a leaving row's slot be recycled, so a row that is
+      // wanted again in this very step is never reloaded before its write-back.
+      for (int pass = 0; pass < 2; pass++) {
+        for (int q = lo; q <= hi; q++) {
+          if (q >= clo && q <= chi) { q = chi; continue; }                 // already resident
+          if (pass == 1 && L.pos_slot[q % NS] >= 0) continue;             // resolved in pass 1
+          const int w = s_sen[q];
+          const bool match = (lane < NS) && (L.slot_row[lane] == w);
+          const unsigned long long mm = __ballot(match);
+          int s = -1;
+          if (mm) {                                                       // the word is resident: share its slot
+            s = __ffsll((long long)mm) - 1;
+            if (lane == 0) L.slot_ref[s]++;
+          } else if (pass == 1) {
+            const unsigned long long fr = __ballot((lane < NS) && (L.slot_row[lane] == -1));
+            if (fr) s = __ffsll((long long)fr) - 1;
+            else {                                                         // recycle the slot of a leaving row
+              const unsigned long long pend = __ballot((lane < NS) && (L.slot_ref[lane] == 0));
+              s = __ffsll((long long)pend) - 1;
+              if (lane == 0) { O.ret_slot[n_ret] = s; O.ret_row[n_ret] = L.slot_row[s]; O.ret_gen[n_ret] = L.slot_gen[s]; }
+              n_ret++;
+            }
+            if (lane == 0) {
+              const int gen = L.slot_gen[s] ^ 1;          // the scratch row of the previous tenant stays readable
+              L.slot_gen[s] = gen;
+              L.slot_row[s] = w; L.slot_ref[s] = 1;
+              O.adm_slot[n_adm] = s; O.adm_row[n_adm] = w; O.adm_gen[n_adm] = gen;
+            }
+            n_adm++;
+          }
+          if (lane == 0) L.pos_slot[q % NS] = s;
+          W2B_WAVE_SYNC();
+        }
+      }
+      {                                                                  // whatever is unreferenced leaves
+        const bool leaving = (lane < NS) && (L.slot_row[lane] != -1) && (L.slot_ref[lane] == 0);
+        const unsigned long long ml = __ballot(leaving);
+        if (leaving) {
+          const int k = n_ret + __popcll(ml & lane_lt_mask(lane));
+          O.ret_slot[k] = lane; O.ret_row[k] = L.slot_row[lane]; O.ret_gen[k] = L.slot_gen[lane];
+          L.slot_row[lane] = -1;
+        }
+        n_ret += __popcll(ml);
+        W2B_WAVE_SYNC();
+      }
+      if (train) {
+        const int hiA = 2 * W + 1 - b;
+        for (int a0 = b; a0 < hiA; a0 += 64) {                          // ref :431-436
+          const int a = a0 + lane;
+          const int c = p - W + a;
+          const bool ok = (a < hiA) && (a != W) && (c >= 0) && (c < sen_len);
+          const unsigned long long m = __ballot(ok);
+          int slot = 0;
+          if (ok) {
+            if (c >= lo && c <= hi) slot = L.pos_slot[c % NS];
+            else {                                     // outside the radius (|c - p| == window): resident anyway?
+              const int w = s_sen[c];
+              slot = (c < p) ? -1 : -2;                // provisional: register-held row (left / right)
+              for (int s2 = 0; s2 < NS; s2++) slot = (L.slot_row[s2] == w) ? s2 : slot;
+            }
+          }
+          if (ok) O.cslot[cw + __popcll(m & lane_lt_mask(lane))] = slot;
+          cw += __popcll(m);
+        }
+        W2B_WAVE_SYNC();
+        if (cw > 0 && R < W) {
+          // The radius is window-1: the two outermost context positions (only present when b == 0) are
+          // not resident.  They are the first / last entry of the context list; each one that is not
+          // resident through another position becomes a register-held row of this step.
+          const int first = O.cslot[0], lastc = O.cslot[cw - 1];
+          int wl = -1;
+          if (first == -1) { wl = s_sen[p - W]; if (lane == 0) O.uc_row[0] = wl; uc_n = 1; }
+          if (lastc == -2) {
+            const int wr = s_sen[p + W];
+            if (uc_n == 1 && wr == wl) { if (lane == 0) O.cslot[cw - 1] = -1; }       // same word on both ends
+            else {
+              if (lane == 0) { O.uc_row[uc_n] = wr; O.cslot[cw - 1] = -1 - uc_n; }
+              uc_n++;
+            }
+          }
+          W2B_WAVE_SYNC();
+        }
+        if (cw > 0) {                                                    // ref :450-460
+          int cnt = 0;
+          for (int d0 = 1; d0 <= K; d0 += 64) {
+            const int d = d0 + lane;
+            bool keep = false;
+            int t = 0;
+            if (d <= K) {
+              const unsigned long long x = (L.ja[d] * rng + L.jc[d]);
+              t = (pref_ok && d0 == 1) ? t_pref : P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
+              if (t == 0) t = (int)(x % (unsigned long long)(P.vocab_size - 1)) + 1;
+              keep = (t != word);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) O.tgt[1 + cnt + __popcll(m & lane_lt_mask(lane))] = t;
+            cnt += __popcll(m);
+          }
+          if (lane == 0) O.tgt[0] = word;
+          nt = 1 + cnt;
+          rng = (L.ja[K] * rng + L.jc[K]);
+          alpha = alpha_set ? alpha_own
+                            : (alpha_pref_ok ? alpha_pref
+                                             : __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT));
+          nck = prep_lists<W2B_RT, W2B_LDS int *>(O.tgt, L.prev, O.cend, nt, (W2B_LDS int *)nullptr, (W2B_LDS int *)nullptr, 0, lane);
+        }
+        const int nq = p + 1 + R;                                        // enters the window at the next step
+        next_row = (p + 1 < sen_len && nq < sen_len) ? s_sen[nq] : -1;
+        sen_pos++;                                                       // ref :505-509
+        if (sen_pos >= sen_len) sen_len = 0;
+        // ---- prefetch for the next step (valid unless the next step starts with a sentence read, whose
+        // sub-sampling draws come first in the LCG ledger)
+        pref_ok = (sen_len != 0);
+        if (pref_ok && lane < K) {                                       // lane l serves draw d = l + 1
+          const unsigned long long xb = rng * W2B_LCG_A + W2B_LCG_C;     // the next step's window draw
+          const unsigned long long x = (L.ja[lane + 1] * xb + L.jc[lane + 1]);
+          t_pref = P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
+        }
+        alpha_pref = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        alpha_pref_ok = true;
+      } else {
+        pref_ok = false;
+      }
+      if (lane == 0) {
+        S->rng = rng; S->cursor = cursor; S->wc = wc; S->last_wc = last_wc;
+        S->sen_len = sen_len; S->sen_pos = sen_pos; S->override_ = ovr; S->eof = eof;
+        L.S->clo = lo; L.S->chi = hi;
+        O.St->stop = (done || last) ? 1 : 0; O.St->cw = cw; O.St->nt = nt; O.St->uc_n = uc_n;
+        O.St->n_ret = n_ret; O.St->n_adm = n_adm; O.St->next_row = next_row; O.St->nck = (cw > 0) ? nck : 0;
+        O.St->alpha = alpha;
+        if (done) S->done = 1;
+      }
+  };
+
+  if (producer) prepare(L0, max_positions == 0);
+  __syncthreads();
+  for (long long it = 0;; ++it) {
+    const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
+    const bool stop = I.St->stop != 0;
+    const int nck = I.St->nck;
+    if (producer) {
+      if (!stop) prepare((it & 1) ? L0 : L1, it + 1 == max_positions);
+      for (int i = 0; i < nck; i++) __syncthreads();
+    } else {
+      // ---------------- data phase.  cslot[j] >= 0: LDS slot; -1-k: register-held row k.
+      const W2B_LDS int *const tgt = I.tgt, *const cend = I.cend, *const cslot = I.cslot;
+      const bool word_step = !stop && I.St->cw > 0;
+      const int nt = I.St->nt, cw = I.St->cw, dim = P.dim, col0 = A.col0;
+      const int uc_n = UC ? I.St->uc_n : 0;
+      const float alpha = I.St->alpha;
+      const float ar2 = (2.f * alpha) * P.reg;
+      const int n_ret = I.St->n_ret, n_adm = I.St->n_adm;
+      bool deferred = false;                    // steady state: the leaving row is merged back AFTER the step
+      int d_row = -1, d_gen = 0, d_slot = 0;
+      unsigned d_csum = 0;
+      Col4 d_g = col_zero(), d_rw = col_zero();
+      Col4 avg = col_zero(), err = col_zero(), ur0 = col_zero(), ur1 = col_zero();
+      float regsq = 0.f;
+      int start = 0, chunk = 0, end = word_step ? cend[0] : 0, par = 0;
+      // ONE loop over the target chunks with ONE load site (the rows of a chunk live in the same registers every
+      // time); what happens once per step -- window exchange, phase A -- sits behind the first chunk's loads, which
+      // have the longest way to go.
+      for (;;) {
+        if (word_step) {
+          // a row repeated from an earlier chunk is re-read after that chunk's store (program order)
+          const int mine = tgt[min(start + lane, nt - 1)];
+#pragma unroll
+          for (int i = 0; i < W2B_RT; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
+          if (active) {
+#pragma unroll
+            for (int i = 0; i < W2B_RT; i++) {
+              if (start + i < end) {
+                const unsigned hk = (unsigned)(rows[i] - 1);
+                if (hk < (unsigned)NH) x[i] = lds_ld(L.win + (NS + (int)hk) * dim + col0);
+                else x[i] = A.ld_v(rows[i]);
+              }
+            }
+          }
+        }
+        int first = chunk;
+        asm volatile("" : "+s"(first));          // opaque: keeps the compiler from peeling the first trip (two load sites)
+        if (first == 0) {
+          // ---- window exchange
+          if (n_ret <= 1 && n_adm <= 1) {
+            if (n_ret == 1) {
+              d_slot = I.ret_slot[0];
+              d_row = I.ret_row[0];
+              d_gen = I.ret_gen[0];
+              d_csum = L.csum[d_slot * W2B_NDWMAX + wave];
+              if (active) {
+                d_rw = lds_ld(L.win + d_slot * dim + col0);
+                d_g = A.ld_u(d_row);                                               // consumed after the step: no stall
+              }
+              deferred = true;
+            }
+            if (n_adm == 1) {
+              const int s = I.adm_slot[0], row = I.adm_row[0];
+              Col4 a = apre;                                                       // loaded during the previous step
+              if (row != apre_row) {
+                a = col_zero();
+                if (active) a = A.ld_u(row);
+              }
+              const unsigned cs = wave_xor(active ? col_bits(a) : 0u);
+              if (lane == 0) L.csum[s * W2B_NDWMAX + wave] = cs;
+              if (active) {
+                lds_st(L.win + s * dim + col0, a);
+                A.st_entry(I.adm_gen[0], s, a);
+              }
+            }
+            // a register-held outer row of this step that is the row leaving right now must see the merge
+            if (UC && deferred && ((uc_n > 0 && I.uc_row[0] == d_row) || (uc_n > 1 && I.uc_row[1] == d_row))) {
+              retire_finish<MM>(A, d_row, d_gen, d_slot, d_csum, d_g, d_rw);
+              deferred = false;
+            }
+            // prefetch the row that enters at the next step (never one whose store is still ahead of us)
+            const int nr = I.St->next_row;
+            const bool is_uc = UC && ((uc_n > 0 && I.uc_row[0] == nr) || (uc_n > 1 && I.uc_row[1] == nr));
+            apre_row = (nr >= 0 && !(deferred && nr == d_row) && !is_uc) ? nr : -1;
+            if (apre_row >= 0 && active) apre = A.ld_u(apre_row);
+          } else {
+            if (n_ret) window_retire<MM>(A, I, n_ret, wave);
+            if (n_adm) window_admit<MM>(A, I, n_adm, lane, wave);
+            apre_row = -1;
+          }
+          if (word_step) {
+            // the (at most two) context rows outside the radius live in registers for this step
+            if (UC && active && uc_n > 0) ur0 = A.ld_u(I.uc_row[0]);
+            if (UC && active && uc_n > 1) ur1 = A.ld_u(I.uc_row[1]);
+            // ---- phase A from LDS (ref :431-449), window order
+            if (active) {
+              for (int j = 0; j < cw; j++) {
+                const int s = cslot[j];
+                Col4 r;
+                if (!UC || s >= 0) {
+                  r = lds_ld(L.win + s * dim + col0);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; e++) r.e[e] = (s == -1) ? ur0.e[e] : ur1.e[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  const float q = quant<QM>(r.e[e], qp);
+                  avg.e[e] += q;
+                  if (LOSS) regsq += q * q;
+                }
+              }
+              const float cwf = (float)cw;
+#pragma unroll
+              for (int e = 0; e < 4; e++) avg.e[e] = avg.e[e] / cwf;
+            }
+          }
+        }
+        if (!word_step) break;
+
+        // ---- phase B (ref :450-492): the W2B_RT rows of this chunk are in registers
+        const int n = end - start;
+        float p[W2B_RT];
+#pragma unroll
+        for (int i = 0; i < W2B_RT; i++) {
+          float t[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) t[e] = avg.e[e] * quant<QM>(x[i].e[e], qp);       // ref :466, re-associated as a tree
+          const float s = (t[0] + t[1]) + (t[2] + t[3]);
+          p[i] = (active && i < n) ? s : 0.f;      // slots beyond the chunk hold stale rows: never written (no register
+                                                   // hazard in front of the next loads), masked here
+        }
+        W2B_LDS float *red = L.red + par * (W2B_RT * W2B_NDWMAX);
+#pragma unroll
+        for (int i = 0; i < W2B_RT; i++) p[i] = wave_sum(p[i]);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < W2B_RT; i++)
+            if (i < n) red[i * W2B_NDWMAX + wave] = p[i];
+        }
+        __syncthreads();
+        float gl = 0.f;
+        if (lane < n) {
+          float f = 0.f;
+          for (int w = 0; w < NDW; w++) f += red[lane * W2B_NDWMAX + w];       // the plain kernel's order over wavefronts
+          const float label = (start + lane == 0) ? 1.f : 0.f;                 // target 0 is the centre word
+          float g;
+          if (f > 6.f) g = (label - 1.f) * alpha;
+          else if (f < -6.f) g = label * alpha;
+          else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
+          gl = g;
+          if (LOSS && wave == 0) {                                             // ref :480-483
+            const float dp = (label != 0.f) ? f : -f;
+            float sg;
+            if (dp > 6.f) sg = 1.f;
+            else if (dp < -6.f) sg = 1e-9f;
+            else sg = 1.f / (1.f + expf(-dp));
+            loss_acc += (double)logf(sg);
+          }
+        }
+        if (LOSS && P.reg != 0.f) {            // reg * sum q^2 of every target row, re-derived from the rows in registers
+#pragma unroll
+          for (int i = 0; i < W2B_RT; i++)
+            if (i < n) {
+              float s2 = 0.f;
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float q = quant<QM>(x[i].e[e], qp);
+                s2 += q * q;
+              }
+              s2 = wave_sum(active ? s2 : 0.f);
+              if (lane == 0) loss_acc -= (double)(P.reg * s2);
+            }
+        }
+        // error accumulation + row update, in target order (ref :486-491)
+#pragma unroll
+        for (int i = 0; i < W2B_RT; i++) {
+          if (i < n) {
+            const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
+            const unsigned hk = (unsigned)(rows[i] - 1);
+            if (hk < (unsigned)NH) dirty |= 1u << hk;
+            if (active) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                float xv = x[i].e[e];
+                // opaque copy: re-derive the quantized value here instead of keeping 4 extra registers per row alive
+                if (QM != 0) asm volatile("" : "+v"(xv));
+                err.e[e] += g * quant<QM>(xv, qp);
+                x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
+              }
+              if (hk < (unsigned)NH) lds_st(L.win + (NS + (int)hk) * dim + col0, x[i]);
+              else A.st_v(rows[i], x[i]);
+            }
+          }
+        }
+        start = end;
+        if (start >= nt) break;
+        end = cend[++chunk];
+        par ^= 1;
+      }
+
+      if (word_step) {
+        // ---- phase C on the resident rows (ref :494-503), window order; duplicates hit the same slot twice
+        if (active) {
+          for (int j = 0; j < cw; j++) {
+            const int s = cslot[j];
+            if (!UC || s >= 0) {
+              Col4 w0 = lds_ld(L.win + s * dim + col0);
+#pragma unroll
+              for (int e = 0; e < 4; e++) w0.e[e] = w0.e[e] + (err.e[e] - ar2 * w0.e[e]);
+              lds_st(L.win + s * dim + col0, w0);
+            } else if (s == -1) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) ur0.e[e] = ur0.e[e] + (err.e[e] - ar2 * ur0.e[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; e++) ur1.e[e] = ur1.e[e] + (err.e[e] - ar2 * ur1.e[e]);
+            }
+          }
+          if (UC && uc_n > 0) A.st_u(I.uc_row[0], ur0);
+          if (UC && uc_n > 1) A.st_u(I.uc_row[1], ur1);
+        }
+        if (LOSS && P.reg != 0.f) {
+          const float s = wave_sum(regsq);
+          if (lane == 0) loss_acc -= (double)(P.reg * s);             // ref :437-445 (summed over the window)
+        }
+      }
+      if (NH > 0 && (stop || (it & (P.hot_period - 1)) == P.hot_period - 1)) hot_merge<MM>(A, L, NS, NH, dirty, lane, wave);
+      if (deferred) retire_finish<MM>(A, d_row, d_gen, d_slot, d_csum, d_g, d_rw);
+    }
+    __syncthreads();                                     // lists of the next step are published; this step is done
+    if (stop) break;
+  }
+  const int sl = S->sen_len;
+  for (int i = tid; i < sl; i += blockDim.x) G->sen[i] = s_sen[i];
+  double lsum = 0.0;
+  if (LOSS) {
+    if (wave == 0) lsum = wave_sum_d(loss_acc);
+    else if (lane == 0 && loss_acc != 0.0) atomicAdd(&G->loss, loss_acc);
+  }
+  if (tid == 0) {
+    G->rng = S->rng; G->cursor = S->cursor; G->word_count = S->wc; G->last_word_count = S->last_wc;
+    G->sen_len = S->sen_len; G->sen_pos = S->sen_pos; G->first_override = S->override_;
+    if (LOSS) atomicAdd(&G->loss, lsum);
+    if (S->done) { G->done = 1; atomicAdd(&P.shared->workers_done, 1); }
+  }
+}
+
+}  // namespace
+
+static int win2_threads(int dim) { return (((dim / 4) + 63) / 64 + 1) * 64; }
+
+// Geometry of the sentence-resident kernel for a shape: radius (-1: use the plain kernel) and how many of the
+// `hot_wanted` hottest target rows get an LDS slot.  Two workgroups share the 160 KiB of a CU.
+int w2b_resident_plan(int dim, int window, int negative, int hot_wanted, int *hot_out) {
+  if (hot_out) *hot_out = 0;
+  if (dim % 4 != 0 || dim > 4 * 64 * W2B_NDWMAX) return -1;     // 16-byte columns, at most 4 data wavefronts
+  const size_t budget = 80 * 1024;
+  int R = -1;
+  if (win2_lds_bytes(dim, window, negative, window, 0) <= budget) R = window;
+  else if (window >= 2 && win2_lds_bytes(dim, window, negative, window - 1, 0) <= budget) R = window - 1;
+  if (R < 0) return -1;
+  int nh = hot_wanted < 0 ? 0 : (hot_wanted > W2B_HOTMAX ? W2B_HOTMAX : hot_wanted);
+  while (nh > 0 && win2_lds_bytes(dim, window, negative, R, nh) > budget) nh--;
+  if (hot_out) *hot_out = nh;
+  return R;
+}
+
+// rows of scratch ("entry") memory per worker
+long long w2b_resident_scratch_rows(int R, int NH) { return 2ll * (2 * R + 1 + NH); }
+
+// workgroups of the sentence-resident kernel that are resident per CU (occupancy query of the instantiation
+// that would run)
+int w2b_resident_per_cu(const W2bParams &p, int R, int NH, bool loss) {
+  const size_t lds = win2_lds_bytes(p.dim, p.window, p.negative, R, NH);
+  int nb = 0;
+  (void)dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
+    constexpr int QM = decltype(qm)::value;
+    // (the table-form / radius variants share the register budget)
+    if (loss) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<QM, true, 0, false>, win2_threads(p.dim), lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<QM, false, 0, false>, win2_threads(p.dim), lds);
+  });
+  return nb > 0 ? nb : 1;
+}
+
+// Coherent rows only (memory mode 0): with relaxed rows the launcher of the trainer picks the plain kernel.
+hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int R, int NH, bool loss, hipStream_t s) {
+  const int threads = win2_threads(p.dim);   // data wavefronts (one thread per 16-byte column) + 1 producer wavefront
+  const int NDW = threads / 64 - 1;
+  const size_t lds = win2_lds_bytes(p.dim, p.window, p.negative, R, NH);
+  static bool reported = false;
+  if (!reported && getenv("W2B_DEBUG")) {
+    reported = true;
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<1, false, 0, false>, threads, lds);
+    fprintf(stderr, "w2b debug: sentence-resident kernel R=%d hot=%d lds=%zu B threads=%d, resident workgroups/CU=%d\n", R, NH, lds, threads, nb);
+  }
+  return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
+    constexpr int QM = decltype(qm)::value;
+    // template MM carries the memory mode in bits 0-2 (0: agent-scope rows) and "tables >= 2 GiB" (per-row descriptors) in bit 3
+#define W2B_LAUNCH_R(LOSS, MMV, UCV) hipLaunchKernelGGL((k_train_resident<QM, LOSS, MMV, UCV>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW, NH)
+#define W2B_LAUNCH_R2(MMV, UCV) do { if (loss) W2B_LAUNCH_R(true, MMV, UCV); else W2B_LAUNCH_R(false, MMV, UCV); } while (0)
+    if (R < p.window) { if (p.tab_bytes) W2B_LAUNCH_R2(0, true); else W2B_LAUNCH_R2(8, true); }
+    else { if (p.tab_bytes) W2B_LAUNCH_R2(0, false); else W2B_LAUNCH_R2(8, false); }
+#undef W2B_LAUNCH_R2
+#undef W2B_LAUNCH_R
+    return hipGetLastError();
+  });
+}

@@ -42,8 +42,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
         if (lane == 0) {
           const unsigned long long d = (unsigned long long)(wc - last_wc);
           const unsigned long long wca = atomicAdd(&P.shared->word_count_actual, d) + d;
-          // other replicas are assumed to progress at the same pace (exact for a single replica)
-          const long long wca_all = (long long)wca * (P.total_threads / P.num_threads);
+          const long long wca_all = w2b_global_progress(P, (long long)wca);
           float a = P.starting_alpha * (1.f - (float)wca_all / (float)(P.iter * P.train_words + 1));
           if ((double)a < (double)P.starting_alpha * 0.0001) a = (float)((double)P.starting_alpha * 0.0001);
           __hip_atomic_store(&P.shared->alpha, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

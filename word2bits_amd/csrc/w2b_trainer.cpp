@@ -45,6 +45,9 @@ struct w2b_trainer {
   int32_t *table = nullptr;
   long long table_size = 0;
   float *keep = nullptr;
+  float *entry = nullptr;       // scratch rows of the sentence-resident kernel
+  size_t entry_floats = 0;
+  int hot_wanted = 0;           // leading rows of v whose target rate justifies a private on-chip copy (from the counts)
   const int32_t *corpus = nullptr;
   int32_t *corpus_owned = nullptr;
   long long n_tokens = 0;
@@ -169,8 +172,7 @@ static W2bParams make_params(const w2b_trainer *t) {
   if (const char *e = getenv("W2B_MEM_MODE")) p.mem_mode = atoi(e);
   p.exact = t->cfg.exact_reduction != 0;
   if (p.exact) p.mem_mode = 0;             // the exact mode exists for coherent rows only
-  p.hot_rows = 1;
-  if (const char *e = getenv("W2B_HOT_ROWS")) p.hot_rows = atoi(e) != 0;
+  p.entry = t->entry;
   p.hot_period = 32;
   if (const char *e = getenv("W2B_HOT_PERIOD")) {
     const int v = atoi(e);
@@ -263,7 +265,7 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   if (t->comm) ncclCommDestroy(t->comm);
   for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : t->ev_pool) (void)hipEventDestroy(e);
-  void *ptrs[] = {t->uv, t->base, t->exp_table, t->table, t->keep, t->corpus_owned, t->workers, t->shared,
+  void *ptrs[] = {t->uv, t->base, t->exp_table, t->table, t->keep, t->entry, t->corpus_owned, t->workers, t->shared,
                   t->jump_a, t->jump_c, t->st_center, t->st_off, t->st_ctx, t->st_neg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -370,6 +372,21 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
   if (t->cfg.sample > 0) w2b_build_keep_prob(cn, V, t->cfg.sample, t->cfg.train_words, keep.data());
   if (!t->keep) HIPCHK(hipMalloc(&t->keep, sizeof(float) * V));
   HIPCHK(hipMemcpy(t->keep, keep.data(), sizeof(float) * V, hipMemcpyHostToDevice));
+  {
+    // How often is row i of v a target (ref :450-460)?  Per centre word: negative * cn_i^0.75 / sum cn^0.75 (the
+    // unigram table) + cn_i / train_words (as the centre word itself).  The vocabulary is sorted by count, so the
+    // rows worth a private on-chip copy in the sentence-resident kernel are a prefix 1..hot_wanted: those that are
+    // a target of at least one centre word in 25 (a coherent row sustains ~7 M read-modify-writes per second).
+    double pw = 0, tot = 0;
+    for (int64_t a = 0; a < V; a++) { pw += pow((double)cn[a], 0.75); tot += (double)cn[a]; }
+    int n = 0;
+    for (int64_t a = 1; a < V && a <= 8; a++) {
+      const double rate = (pw > 0 ? t->cfg.negative * pow((double)cn[a], 0.75) / pw : 0) + (tot > 0 ? cn[a] / tot : 0);
+      if (rate < 0.04) break;
+      n++;
+    }
+    t->hot_wanted = n;
+  }
   if (table_size > 0) {
     std::vector<int32_t> tab((size_t)table_size);
     int rc = w2b_build_unigram_table(cn, V, tab.data(), table_size);
@@ -504,21 +521,28 @@ extern "C" int w2b_epoch_begin(w2b_trainer *t) {
 
 // Which worker kernel runs: plain_worker_kernel 0 = automatic (sentence-resident kernel for coherent rows when
 // the window fits in LDS; plain kernel for relaxed rows, where caching in L2 already absorbs the re-reads and
-// four workgroups per CU win), 1 = plain, 2 = sentence-resident whenever it fits.
-static int worker_radius(const w2b_trainer *t) {
+// four workgroups per CU win), 1 = plain, 2 = sentence-resident whenever it fits.  Returns the radius (-1 = plain
+// kernel) and the number of private hot target rows.
+static int worker_plan(const w2b_trainer *t, int *hot) {
+  if (hot) *hot = 0;
   int mode = t->cfg.plain_worker_kernel;
   if (const char *e = getenv("W2B_WORKER_KERNEL")) mode = atoi(e);
   if (mode == 1 || t->cfg.exact_reduction) return -1;   // the serial reduction lives in the plain kernel
-  if (mode == 0 && t->cfg.relaxed_coherence) return -1;
-  return w2b_window_radius(t->cfg.layer1_size, t->cfg.window, t->cfg.negative);
+  if (t->cfg.relaxed_coherence) return -1;              // the sentence-resident kernel exists for coherent rows only
+  if (const char *e = getenv("W2B_MEM_MODE")) if (atoi(e) != 0) return -1;
+  int want = t->hot_wanted;
+  if (const char *e = getenv("W2B_HOT_ROWS")) want = atoi(e);          // test hook: explicit number (0 = off)
+  if (want > t->cfg.vocab_size - 1) want = (int)t->cfg.vocab_size - 1;
+  return w2b_resident_plan(t->cfg.layer1_size, t->cfg.window, t->cfg.negative, want, hot);
 }
 
 extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
   NEED(t);
   if (!out) return fail(W2B_EINVAL, "w2b_suggested_threads: null");
   const W2bParams p = make_params(t);
-  const int radius = worker_radius(t);
-  const int per_cu = radius >= 0 ? w2b_workers2_per_cu(p, radius, t->cfg.compute_loss != 0)
+  int hot = 0;
+  const int radius = worker_plan(t, &hot);
+  const int per_cu = radius >= 0 ? w2b_resident_per_cu(p, radius, hot, t->cfg.compute_loss != 0)
                                  : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
   long long n = (long long)per_cu * t->num_cus;
   // A worker adjusts alpha only after >10000 of its own words (ref :379-393): with shards shorter than that no worker
@@ -535,17 +559,19 @@ extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
 }
 
 extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t *radius, int32_t *column_bytes,
-                                      int32_t *workgroups_per_cu) {
+                                      int32_t *workgroups_per_cu, int32_t *hot_rows) {
   NEED(t);
   const W2bParams p = make_params(t);
-  const int r = worker_radius(t);
+  int hot = 0;
+  const int r = worker_plan(t, &hot);
   if (resident) *resident = r >= 0;
   if (radius) *radius = r;
+  if (hot_rows) *hot_rows = hot;
   int vec = 0;
   (void)w2b_block_threads(t->cfg.layer1_size, &vec);
-  if (column_bytes) *column_bytes = 4 * (r >= 0 ? w2b_workers2_vec(t->cfg.layer1_size) : vec);
+  if (column_bytes) *column_bytes = 4 * (r >= 0 ? 4 : vec);
   if (workgroups_per_cu)
-    *workgroups_per_cu = r >= 0 ? w2b_workers2_per_cu(p, r, t->cfg.compute_loss != 0)
+    *workgroups_per_cu = r >= 0 ? w2b_resident_per_cu(p, r, hot, t->cfg.compute_loss != 0)
                                 : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
   return W2B_OK;
 }
@@ -554,10 +580,22 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   NEED(t);
   if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_train_step: corpus/shards not set");
   if (max_positions <= 0) return fail(W2B_EINVAL, "w2b_train_step: max_positions must be positive");
+  int hot = 0;
+  const int radius = worker_plan(t, &hot);
+  if (radius >= 0) {                       // scratch rows of the sentence-resident kernel (grown on demand)
+    const size_t need = (size_t)t->cfg.num_threads * (size_t)w2b_resident_scratch_rows(radius, hot) * t->cfg.layer1_size;
+    if (need > t->entry_floats) {
+      HIPCHK(hipStreamSynchronize(t->stream));
+      if (t->entry) HIPCHK(hipFree(t->entry));
+      t->entry = nullptr;
+      t->entry_floats = 0;
+      HIPCHK(hipMalloc(&t->entry, sizeof(float) * need));
+      t->entry_floats = need;
+    }
+  }
   const W2bParams p = make_params(t);
-  const int radius = worker_radius(t);
   HIPCHK(timing_begin(t));
-  if (radius >= 0) HIPCHK(w2b_launch_workers2(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream));
+  if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, hot, t->cfg.compute_loss != 0, t->stream));
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));
   return W2B_OK;

@@ -193,10 +193,10 @@ class Trainer:
                 return loss
 
     def worker_kernel_info(self):
-        """(resident, radius, column_bytes, workgroups_per_cu) of the form-(i) kernel train_step() runs"""
-        a, b, c, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        check(lib().w2b_worker_kernel_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return bool(a.value), b.value, c.value, d.value
+        """(resident, radius, column_bytes, workgroups_per_cu, hot_rows) of the form-(i) kernel train_step() runs"""
+        a, b, c, d, e = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(lib().w2b_worker_kernel_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
+        return bool(a.value), b.value, c.value, d.value, e.value
 
     def suggested_threads(self):
         n = C.c_int32(0)
