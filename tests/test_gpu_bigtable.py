@@ -44,7 +44,7 @@ def test_single_worker_epochs_bit_exact_row_desc(gpu, row_desc, bitlevel, sample
     test_gpu_exact.test_single_worker_epochs_bit_exact(gpu, bitlevel, sample, D, window, negative, iters)
 
 
-@pytest.mark.parametrize("D,window,negative,bitlevel", [(800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0), (800, 11, 5, 1)])
+@pytest.mark.parametrize("D,window,negative,bitlevel", [(800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0), (800, 12, 5, 1)])
 def test_resident_equals_plain_single_worker_row_desc(gpu, row_desc, D, window, negative, bitlevel, monkeypatch):
     test_gpu_worker.test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, window, negative, bitlevel,
                                                                                     None, monkeypatch)
@@ -141,8 +141,8 @@ def big_table_tuple_check(V, D, window, negative, bitlevel, exact, n=48, seed=0)
     c_center = (vinv[:n] + 1).astype(np.int32)
     c_neg = (vinv[n:] + 1).reshape(n, negative).astype(np.int32)
     c_ctx = (uinv + 1).astype(np.int32)
-    for rep in range(2):
-        o.train_tuples(c_center, ctx_off, c_ctx, c_neg, 0.05)
+    for rep in range(2 if exact else 1):     # (fast mode: one step, as in tests/test_gpu_parity.py -- a flipped sigmoid
+        o.train_tuples(c_center, ctx_off, c_ctx, c_neg, 0.05)     # bin would compound over a second one)
         t.train_tuples(center, ctx_off, ctx, neg, 0.05)
     du, dv = device_tables(t, V, D)
     gu = du[torch.from_numpy(uu).to(du.device)].cpu().numpy()
@@ -154,7 +154,7 @@ def big_table_tuple_check(V, D, window, negative, bitlevel, exact, n=48, seed=0)
     else:
         # two updates of the same rows with the dot product re-associated: a neighbouring sigmoid bin moves g by one
         # table step (tests/test_gpu_parity.py); everything else agrees to rounding
-        tol = 2 * (3 * 1.6e-4 * {0: 0.6, 1: 1.0 / 3, 2: 0.75}[bitlevel] + 2e-6)
+        tol = 3 * 1.6e-4 * {0: 0.6, 1: 1.0 / 3, 2: 0.75}[bitlevel] + 2e-6
         assert np.abs(gu - wu).max() <= tol and np.abs(gv - wv).max() <= tol
         assert np.mean(np.abs(gv - wv).max(axis=1) <= 4e-6) > 0.9
     # every row the batch did not name still holds its InitNet bits; the named ones moved

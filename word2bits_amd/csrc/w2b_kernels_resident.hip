@@ -33,7 +33,13 @@
 #include <cstdio>
 #include <cstdlib>
 
-#define W2B_RT 13       // target rows per chunk: 13 x 4 VGPRs (negative=24 -> 25 targets = 13 + 12)
+#ifndef W2B_RT
+#define W2B_RT 25       // target rows per chunk: 25 x 4 VGPRs -- negative=24 is ONE chunk: one memory round trip per centre word
+#endif
+#ifndef W2B_RES_WAVES
+#define W2B_RES_WAVES 3
+#endif
+#define W2B_RB 5        // rows whose partial dot products are formed and reduced together (bounds the live temporaries)
 #define W2B_NDWMAX 4    // data wavefronts per worker (one thread per 16-byte column: D <= 1024) + 1 producer wavefront
 #define W2B_RCH 2       // window rows moved per trip when many enter/leave at once (sentence boundaries)
 #define W2B_HOTMAX 8    // most target rows with a private LDS slot
@@ -290,7 +296,7 @@ __device__ __forceinline__ void hot_merge(const Rows<MM> &A, const Win2 &L, int 
 // Register budget: two workers per CU = at most 3 wavefronts per SIMD -> 168 VGPRs.
 // UC: the radius is window-1 (the two outermost context rows of a step are register-held).
 template <int QM, bool LOSS, int MM, bool UC>
-__global__ void __launch_bounds__(320, 3) k_train_resident(const W2bParams P, const long long max_positions,
+__global__ void __launch_bounds__(320, W2B_RES_WAVES) k_train_resident(const W2bParams P, const long long max_positions,
                                                            const int R, const int NDW, const int NH) {
   extern __shared__ int smem[];
   W2B_LDS int *const smem_lds = (W2B_LDS int *)smem;
@@ -333,11 +339,6 @@ __global__ void __launch_bounds__(320, 3) k_train_resident(const W2bParams P, co
   // data-wavefront registers: the row that enters the window at the next step, loaded one step early
   Col4 apre = col_zero();
   int apre_row = -1;
-  // data-wavefront registers: the target rows of the current chunk
-  Col4 x[W2B_RT];
-  int rows[W2B_RT];
-#pragma unroll
-  for (int i = 0; i < W2B_RT; i++) { x[i] = col_zero(); rows[i] = 0; }
   // data wavefronts: private copies of the hottest target rows (LDS slots NS .. NS+NH-1); bit k of `dirty` = this
   // worker has updated hot row k since the last merge (wave-uniform)
   unsigned dirty = 0u;
@@ -549,16 +550,46 @@ __global__ void __launch_bounds__(320, 3) k_train_resident(const W2bParams P, co
       }
   };
 
-  if (producer) prepare(L0, max_positions == 0);
-  __syncthreads();
-  for (long long it = 0;; ++it) {
-    const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
-    const bool stop = I.St->stop != 0;
-    const int nck = I.St->nck;
-    if (producer) {
+  // Two role-specific step loops instead of one loop with a role branch inside: a wavefront has ONE register
+  // allocation, and inside a common loop whatever one role carries around the loop is live in the other role's
+  // branch too (the producer's bookkeeping cost the data path 20 VGPRs and vice versa).  Both loops execute the
+  // same s_barrier sequence per step.
+  if (producer) {
+    prepare(L0, max_positions == 0);
+    __syncthreads();
+    for (long long it = 0;; ++it) {
+      const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
+      const bool stop = I.St->stop != 0;
+      const int nck = I.St->nck;
       if (!stop) prepare((it & 1) ? L0 : L1, it + 1 == max_positions);
-      for (int i = 0; i < nck; i++) __syncthreads();
-    } else {
+      for (int i = 0; i < nck; i++) {
+        __syncthreads();
+        if (LOSS) {
+          // The log-sigmoid bookkeeping of chunk i (ref :480-483) happens HERE, off the data wavefronts' registers
+          // (expf/logf cost them ~40 VGPRs): after the chunk's barrier its partial dot products sit in red[i & 1]
+          // until the data wavefronts have passed the NEXT barrier, which waits for this wavefront.
+          const int cs = i ? I.cend[i - 1] : 0, n = I.cend[i] - cs;
+          if (lane < n) {
+            const W2B_LDS float *red = L.red + (i & 1) * (W2B_RT * W2B_NDWMAX);
+            float f = 0.f;
+            for (int w = 0; w < NDW; w++) f += red[lane * W2B_NDWMAX + w];
+            const float dp = (cs + lane == 0) ? f : -f;               // target 0 is the centre word (label 1)
+            float sg;
+            if (dp > 6.f) sg = 1.f;
+            else if (dp < -6.f) sg = 1e-9f;
+            else sg = 1.f / (1.f + expf(-dp));
+            loss_acc += (double)logf(sg);
+          }
+        }
+      }
+      __syncthreads();                                   // lists of the next step are published; this step is done
+      if (stop) break;
+    }
+  } else {
+    __syncthreads();
+    for (long long it = 0;; ++it) {
+      const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
+      const bool stop = I.St->stop != 0;
       // ---------------- data phase.  cslot[j] >= 0: LDS slot; -1-k: register-held row k.
       const W2B_LDS int *const tgt = I.tgt, *const cend = I.cend, *const cslot = I.cslot;
       const bool word_step = !stop && I.St->cw > 0;
@@ -574,6 +605,19 @@ __global__ void __launch_bounds__(320, 3) k_train_resident(const W2bParams P, co
       Col4 avg = col_zero(), err = col_zero(), ur0 = col_zero(), ur1 = col_zero();
       float regsq = 0.f;
       int start = 0, chunk = 0, end = word_step ? cend[0] : 0, par = 0;
+      // The target rows of the current chunk.  Deliberately "defined" by an empty asm: the registers hold whatever
+      // they held (slots beyond a chunk are masked out below), there is no instruction in front of the loads that
+      // could make them wait (a zero-fill would be a write-after-write hazard against outstanding memory
+      // operations), and -- not being carried around the step loop -- they cost the producer wavefront's branch
+      // nothing (one register allocation serves both roles).
+      Col4 x[W2B_RT];
+      int rows[W2B_RT];
+#pragma unroll
+      for (int i = 0; i < W2B_RT; i++) {
+        rows[i] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) asm volatile("" : "=v"(x[i].e[e]));
+      }
       // ONE loop over the target chunks with ONE load site (the rows of a chunk live in the same registers every
       // time); what happens once per step -- window exchange, phase A -- sits behind the first chunk's loads, which
       // have the longest way to go.
@@ -666,28 +710,40 @@ __global__ void __launch_bounds__(320, 3) k_train_resident(const W2bParams P, co
               for (int e = 0; e < 4; e++) avg.e[e] = avg.e[e] / cwf;
             }
           }
+          // The row that left the window is merged back here: its current value was requested before the admit
+          // above and has had phase A to arrive (memory returns in order, the target rows are needed next anyway),
+          // and its registers are free before the dot products need room.
+          if (deferred) retire_finish<MM>(A, d_row, d_gen, d_slot, d_csum, d_g, d_rw);
+          deferred = false;
         }
         if (!word_step) break;
 
         // ---- phase B (ref :450-492): the W2B_RT rows of this chunk are in registers
         const int n = end - start;
-        float p[W2B_RT];
-#pragma unroll
-        for (int i = 0; i < W2B_RT; i++) {
-          float t[4];
-#pragma unroll
-          for (int e = 0; e < 4; e++) t[e] = avg.e[e] * quant<QM>(x[i].e[e], qp);       // ref :466, re-associated as a tree
-          const float s = (t[0] + t[1]) + (t[2] + t[3]);
-          p[i] = (active && i < n) ? s : 0.f;      // slots beyond the chunk hold stale rows: never written (no register
-                                                   // hazard in front of the next loads), masked here
-        }
         W2B_LDS float *red = L.red + par * (W2B_RT * W2B_NDWMAX);
+        // partial dot products, W2B_RB rows at a time: W2B_RB independent reduction chains interleave, and the
+        // scheduling barrier keeps the compiler from forming all W2B_RT x 4 products first (that is 100 live VGPRs)
 #pragma unroll
-        for (int i = 0; i < W2B_RT; i++) p[i] = wave_sum(p[i]);
-        if (lane == 0) {
+        for (int i0 = 0; i0 < W2B_RT; i0 += W2B_RB) {
+          float p[W2B_RB];
 #pragma unroll
-          for (int i = 0; i < W2B_RT; i++)
-            if (i < n) red[i * W2B_NDWMAX + wave] = p[i];
+          for (int k = 0; k < W2B_RB; k++) {
+            const int i = i0 + k < W2B_RT ? i0 + k : W2B_RT - 1;
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) t[e] = avg.e[e] * quant<QM>(x[i].e[e], qp);       // ref :466, re-associated as a tree
+            const float s = (t[0] + t[1]) + (t[2] + t[3]);
+            p[k] = (active && i < n) ? s : 0.f;    // slots beyond the chunk hold stale rows: never written (no register
+                                                   // hazard in front of the next loads), masked here
+          }
+#pragma unroll
+          for (int k = 0; k < W2B_RB; k++) p[k] = wave_sum(p[k]);
+          if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < W2B_RB; k++)
+              if (i0 + k < n && i0 + k < W2B_RT) red[(i0 + k) * W2B_NDWMAX + wave] = p[k];
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         float gl = 0.f;
@@ -699,29 +755,23 @@ __global__ void __launch_bounds__(320, 3) k_train_resident(const W2bParams P, co
           if (f > 6.f) g = (label - 1.f) * alpha;
           else if (f < -6.f) g = label * alpha;
           else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
-          gl = g;
-          if (LOSS && wave == 0) {                                             // ref :480-483
-            const float dp = (label != 0.f) ? f : -f;
-            float sg;
-            if (dp > 6.f) sg = 1.f;
-            else if (dp < -6.f) sg = 1e-9f;
-            else sg = 1.f / (1.f + expf(-dp));
-            loss_acc += (double)logf(sg);
-          }
+          gl = g;                      // (LOSS: the log-sigmoid term of this target is booked by the producer wavefront)
         }
-        if (LOSS && P.reg != 0.f) {            // reg * sum q^2 of every target row, re-derived from the rows in registers
+        if (LOSS && P.reg != 0.f) {            // reg * sum q^2 over the chunk's target rows (ref :469,481), re-derived
+          float s2 = 0.f;                      // from the rows in registers: one running sum, one reduction per chunk
 #pragma unroll
           for (int i = 0; i < W2B_RT; i++)
             if (i < n) {
-              float s2 = 0.f;
 #pragma unroll
               for (int e = 0; e < 4; e++) {
-                const float q = quant<QM>(x[i].e[e], qp);
+                float xv = x[i].e[e];
+                if (QM >= 2) asm volatile("" : "+v"(xv));     // opaque: do not keep the dot product's quantized rows alive
+                const float q = quant<QM>(xv, qp);
                 s2 += q * q;
               }
-              s2 = wave_sum(active ? s2 : 0.f);
-              if (lane == 0) loss_acc -= (double)(P.reg * s2);
             }
+          s2 = wave_sum(active ? s2 : 0.f);
+          if (lane == 0) loss_acc -= (double)(P.reg * s2);
         }
         // error accumulation + row update, in target order (ref :486-491)
 #pragma unroll
@@ -777,22 +827,24 @@ __global__ void __launch_bounds__(320, 3) k_train_resident(const W2bParams P, co
         }
       }
       if (NH > 0 && (stop || (it & (P.hot_period - 1)) == P.hot_period - 1)) hot_merge<MM>(A, L, NS, NH, dirty, lane, wave);
-      if (deferred) retire_finish<MM>(A, d_row, d_gen, d_slot, d_csum, d_g, d_rw);
+      __syncthreads();                                   // lists of the next step are published; this step is done
+      if (stop) break;
     }
-    __syncthreads();                                     // lists of the next step are published; this step is done
-    if (stop) break;
   }
   const int sl = S->sen_len;
   for (int i = tid; i < sl; i += blockDim.x) G->sen[i] = s_sen[i];
-  double lsum = 0.0;
   if (LOSS) {
-    if (wave == 0) lsum = wave_sum_d(loss_acc);
-    else if (lane == 0 && loss_acc != 0.0) atomicAdd(&G->loss, loss_acc);
+    // producer lanes hold the log-sigmoid terms, lane 0 of every data wavefront the regularisation terms
+    if (producer) {
+      const double lsum = wave_sum_d(loss_acc);
+      if (lane == 0) atomicAdd(&G->loss, lsum);
+    } else if (lane == 0 && loss_acc != 0.0) {
+      atomicAdd(&G->loss, loss_acc);
+    }
   }
   if (tid == 0) {
     G->rng = S->rng; G->cursor = S->cursor; G->word_count = S->wc; G->last_word_count = S->last_wc;
     G->sen_len = S->sen_len; G->sen_pos = S->sen_pos; G->first_override = S->override_;
-    if (LOSS) atomicAdd(&G->loss, lsum);
     if (S->done) { G->done = 1; atomicAdd(&P.shared->workers_done, 1); }
   }
 }
