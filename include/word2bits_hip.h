@@ -176,6 +176,8 @@ int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id12
 /* mode 0: delta-sum  W = base + sum_r (W_r - base);  mode 1: average  W = mean_r W_r.
  * A communicator of size 1 (or none) is a no-op that leaves the model bit-identical. */
 int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
+/* exchanges since the last call and (when w2b_timing_enable is on) their summed device time; resets both */
+int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
 
 #ifdef __cplusplus
 }

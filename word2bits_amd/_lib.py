@@ -72,6 +72,7 @@ SIGNATURES = {
     "w2b_comm_unique_id": (C.c_int, [vp]),
     "w2b_comm_init": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
     "w2b_sync_replicas": (C.c_int, [vp, C.c_int32]),
+    "w2b_sync_stats": (C.c_int, [vp, i64p, f64p]),
     # include/word2bits_corpus.h
     "w2b_corpus_load": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(vp)]),
     "w2b_corpus_free": (None, [vp]),

@@ -17,30 +17,64 @@ __global__ void k_init_net(float *u, float *v, long long n, const float *__restr
 template <int QM>
 __global__ void k_export(const float *__restrict__ u, const float *__restrict__ v, float *__restrict__ out,
                          long long n, QParam qp) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+  const bool aligned = ((((size_t)u) | ((size_t)v) | ((size_t)out)) & 15) == 0;
+  const long long n4 = aligned ? (n >> 2) : 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f4 a = reinterpret_cast<const f4 *>(u)[i], b = reinterpret_cast<const f4 *>(v)[i];
+    f4 o;
+    o.x = quant<QM>(a.x + b.x, qp); o.y = quant<QM>(a.y + b.y, qp);
+    o.z = quant<QM>(a.z + b.z, qp); o.w = quant<QM>(a.w + b.w, qp);
+    reinterpret_cast<f4 *>(out)[i] = o;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     out[i] = quant<QM>(u[i] + v[i], qp);
 }
 
-__global__ void k_sub(float *w, const float *__restrict__ base, long long n) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] -= base[i];
+// ---- replica exchange (delta-sum), 16 bytes per lane; n4 = number of float4 (the tables are float4-aligned and
+// their length is padded by the callers' tail loop below)
+typedef float w2b_f4 __attribute__((ext_vector_type(4)));
+__global__ void k_sub(float *w, const float *__restrict__ base, long long n) {          // w -= base
+  const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
+  w2b_f4 *w4 = reinterpret_cast<w2b_f4 *>(w);
+  const w2b_f4 *b4 = reinterpret_cast<const w2b_f4 *>(base);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) w4[i] = w4[i] - b4[i];
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] -= base[i];
 }
-__global__ void k_add_snap(float *w, float *base, long long n) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+__global__ void k_add_snap(float *w, float *base, long long n) {                          // w += base; base = w
+  const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
+  w2b_f4 *w4 = reinterpret_cast<w2b_f4 *>(w), *b4 = reinterpret_cast<w2b_f4 *>(base);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const w2b_f4 x = w4[i] + b4[i];
+    w4[i] = x;
+    b4[i] = x;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float x = w[i] + base[i];
     w[i] = x;
     base[i] = x;
   }
 }
-__global__ void k_scale_snap(float *w, float *base, float s, long long n) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+__global__ void k_scale_snap(float *w, float *base, float s, long long n) {               // w *= s; base = w
+  const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
+  w2b_f4 *w4 = reinterpret_cast<w2b_f4 *>(w), *b4 = reinterpret_cast<w2b_f4 *>(base);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const w2b_f4 x = w4[i] * s;
+    w4[i] = x;
+    if (base) b4[i] = x;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float x = w[i] * s;
     w[i] = x;
     if (base) base[i] = x;
   }
+}
+// progress counters of the replicas (alpha schedule on the GLOBAL word count, ref :391; see W2bShared)
+__global__ void k_wca_pack(const W2bShared *sh, unsigned long long *buf) { buf[0] = sh->word_count_actual; }
+__global__ void k_wca_unpack(W2bShared *sh, const unsigned long long *buf) {
+  sh->wca_others = buf[1] - buf[0];       // buf[1] = sum over all replicas
+  sh->wca_at_sync = buf[0];
 }
 
 }  // namespace
@@ -86,6 +120,14 @@ hipError_t w2b_launch_export(const float *u, const float *v, float *out, long lo
   });
 }
 
+hipError_t w2b_launch_wca_pack(const W2bShared *sh, unsigned long long *buf, hipStream_t s) {
+  hipLaunchKernelGGL(k_wca_pack, dim3(1), dim3(1), 0, s, sh, buf);
+  return hipGetLastError();
+}
+hipError_t w2b_launch_wca_unpack(W2bShared *sh, const unsigned long long *buf, hipStream_t s) {
+  hipLaunchKernelGGL(k_wca_unpack, dim3(1), dim3(1), 0, s, sh, buf);
+  return hipGetLastError();
+}
 hipError_t w2b_launch_sub(float *w, const float *base, long long n, hipStream_t s) {
   hipLaunchKernelGGL(k_sub, dim3(2048), dim3(256), 0, s, w, base, n);
   return hipGetLastError();

@@ -33,11 +33,16 @@
 #include <cstdio>
 #include <cstdlib>
 
+// Register budget.  A worker is 4 data wavefronts + 1 producer wavefront; the hardware places wavefront i of a
+// workgroup on SIMD i mod 4, so SIMD 0 carries TWO wavefronts of every worker and a second worker fits on the CU only
+// if four wavefronts fit on one SIMD: 128 VGPRs.  (Measured: with 168 VGPRs -- 25 target rows in registers, one
+// memory round trip per centre word -- 256 and 512 workers run at the same speed: one workgroup per CU, although the
+// occupancy API answers 2.)  13 target rows x 4 VGPRs per chunk is what fits in 128 with nothing spilled.
 #ifndef W2B_RT
-#define W2B_RT 25       // target rows per chunk: 25 x 4 VGPRs -- negative=24 is ONE chunk: one memory round trip per centre word
+#define W2B_RT 13       // target rows per chunk (negative=24 -> 25 targets = 13 + 12)
 #endif
 #ifndef W2B_RES_WAVES
-#define W2B_RES_WAVES 3
+#define W2B_RES_WAVES 4 // wavefronts per SIMD the kernel is register-allocated for
 #endif
 #define W2B_RB 5        // rows whose partial dot products are formed and reduced together (bounds the live temporaries)
 #define W2B_NDWMAX 4    // data wavefronts per worker (one thread per 16-byte column: D <= 1024) + 1 producer wavefront

@@ -67,6 +67,10 @@ struct w2b_trainer {
   // RCCL
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
+  unsigned long long *wca_buf = nullptr;   // [2]: this replica's word_count_actual, the sum over all replicas
+  hipEvent_t sync_a = nullptr, sync_b = nullptr;
+  double sync_ms = 0;                       // device time of the replica exchanges since the last w2b_sync_stats
+  long long sync_count = 0;
   int grid_per_cu = 0;
 };
 
@@ -265,7 +269,9 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   if (t->comm) ncclCommDestroy(t->comm);
   for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : t->ev_pool) (void)hipEventDestroy(e);
-  void *ptrs[] = {t->uv, t->base, t->exp_table, t->table, t->keep, t->entry, t->corpus_owned, t->workers, t->shared,
+  if (t->sync_a) (void)hipEventDestroy(t->sync_a);
+  if (t->sync_b) (void)hipEventDestroy(t->sync_b);
+  void *ptrs[] = {t->uv, t->base, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->corpus_owned, t->workers, t->shared,
                   t->jump_a, t->jump_c, t->st_center, t->st_off, t->st_ctx, t->st_neg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -612,10 +618,11 @@ extern "C" int w2b_epoch_status(w2b_trainer *t, int32_t *finished, int64_t *wca,
   if (alpha) *alpha = sh.alpha;
   if (loss_sum) {
     const int nw = t->cfg.num_threads;
-    std::vector<W2bWorker> w((size_t)nw);
-    HIPCHK(hipMemcpy(w.data(), t->workers, sizeof(W2bWorker) * nw, hipMemcpyDeviceToHost));
+    std::vector<double> w((size_t)nw);              // only the 8-byte loss field of every worker travels
+    HIPCHK(hipMemcpy2D(w.data(), sizeof(double), &t->workers[0].loss, sizeof(W2bWorker), sizeof(double), nw,
+                       hipMemcpyDeviceToHost));
     double s = 0;
-    for (int i = 0; i < nw; i++) s += w[i].loss;   // ref :537-538
+    for (int i = 0; i < nw; i++) s += w[i];         // ref :537-538, in worker order
     *loss_sum = s;
   }
   return W2B_OK;
@@ -715,12 +722,17 @@ extern "C" int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const
   memcpy(&id, id128, sizeof id);
   NCCLCHK(ncclCommInitRank(&t->comm, nranks, id, rank));
   hipError_t e = hipMalloc(&t->base, sizeof(float) * 2 * t->table_elems);
+  if (e == hipSuccess) e = hipMalloc(&t->wca_buf, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipEventCreate(&t->sync_a);
+  if (e == hipSuccess) e = hipEventCreate(&t->sync_b);
   if (e == hipSuccess)
     e = hipMemcpyAsync(t->base, t->uv, sizeof(float) * 2 * t->table_elems, hipMemcpyDeviceToDevice, t->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
   if (e != hipSuccess) {                     // leave the trainer as a single replica, not half-initialised
     if (t->base) (void)hipFree(t->base);
     t->base = nullptr;
+    if (t->wca_buf) (void)hipFree(t->wca_buf);
+    t->wca_buf = nullptr;
     ncclCommDestroy(t->comm);
     t->comm = nullptr;
     t->nranks = 1;
@@ -733,7 +745,14 @@ extern "C" int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const
 extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
   NEED(t);
   if (t->nranks <= 1 || !t->comm) return W2B_OK;
+  if (mode != 0 && mode != 1) return fail(W2B_EINVAL, "w2b_sync_replicas: unknown mode");
   const long long n = 2 * t->table_elems;
+  HIPCHK(hipEventRecord(t->sync_a, t->stream));
+  // progress first (16 bytes): every replica learns the global word count -- the alpha schedule (ref :391) is exact
+  // at every exchange and extrapolates in between (W2bShared::wca_others)
+  HIPCHK(w2b_launch_wca_pack(t->shared, t->wca_buf, t->stream));
+  NCCLCHK(ncclAllReduce(t->wca_buf, t->wca_buf + 1, 1, ncclUint64, ncclSum, t->comm, t->stream));
+  HIPCHK(w2b_launch_wca_unpack(t->shared, t->wca_buf, t->stream));
   // one all-reduce over [u || v]; chunked so that each RCCL call stays below 2^31 elements
   const long long chunk = 1ll << 30;
   if (mode == 0) {
@@ -749,8 +768,23 @@ extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
       NCCLCHK(ncclAllReduce(t->uv + o, t->uv + o, (size_t)m, ncclFloat, ncclSum, t->comm, t->stream));
     }
     HIPCHK(w2b_launch_scale_snap(t->uv, t->base, 1.f / (float)t->nranks, n, t->stream));
-  } else {
-    return fail(W2B_EINVAL, "w2b_sync_replicas: unknown mode");
   }
+  HIPCHK(hipEventRecord(t->sync_b, t->stream));
+  t->sync_count++;
+  if (t->timing) {                      // device time of the exchange (bench.py reports the cost per exchange)
+    HIPCHK(hipEventSynchronize(t->sync_b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, t->sync_a, t->sync_b));
+    t->sync_ms += ms;
+  }
+  return W2B_OK;
+}
+
+extern "C" int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms) {
+  if (!t) return fail(W2B_EINVAL, "null trainer");
+  if (exchanges) *exchanges = t->sync_count;
+  if (device_ms) *device_ms = t->sync_ms;
+  t->sync_count = 0;
+  t->sync_ms = 0;
   return W2B_OK;
 }

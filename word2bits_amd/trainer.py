@@ -237,6 +237,12 @@ class Trainer:
     def sync_replicas(self, mode=0):
         check(lib().w2b_sync_replicas(self._h, int(mode)))
 
+    def sync_stats(self):
+        """(exchanges, summed device ms) since the last call"""
+        n, ms = C.c_int64(0), C.c_double(0)
+        check(lib().w2b_sync_stats(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def close(self):
         if self._h:
             lib().w2b_trainer_destroy(self._h)
