@@ -33,16 +33,20 @@
 #include <cstdio>
 #include <cstdlib>
 
-// Register budget.  A worker is 4 data wavefronts + 1 producer wavefront; the hardware places wavefront i of a
-// workgroup on SIMD i mod 4, so SIMD 0 carries TWO wavefronts of every worker and a second worker fits on the CU only
-// if four wavefronts fit on one SIMD: 128 VGPRs.  (Measured: with 168 VGPRs -- 25 target rows in registers, one
-// memory round trip per centre word -- 256 and 512 workers run at the same speed: one workgroup per CU, although the
-// occupancy API answers 2.)  13 target rows x 4 VGPRs per chunk is what fits in 128 with nothing spilled.
+// Register budget and workgroup shape.  A worker is up to 4 data wavefronts + 1 producer wavefront.  The hardware
+// places wavefront i of a workgroup on SIMD i mod 4, so as a workgroup of its own a worker puts TWO of its five
+// wavefronts on SIMD 0, and a second such workgroup fits on the CU only within 128 VGPRs (measured: at 168 VGPRs 256
+// and 512 one-worker workgroups run at the same speed although the occupancy API answers 2 per CU).  128 VGPRs hold
+// 13 target rows: two memory round trips per centre word at negative = 24.  So a workgroup carries W2B_WPG = 2
+// INDEPENDENT workers: ten wavefronts land 3/3/2/2 on the SIMDs, 168 VGPRs each, all 25 target rows of a centre word
+// in registers -- one round trip per word AND two workers per CU.  The workers of a workgroup never wait for each
+// other: their wavefronts synchronise through per-worker counters in LDS (worker_barrier), not s_barrier.
+#define W2B_WPG 2       // workers per workgroup
 #ifndef W2B_RT
-#define W2B_RT 13       // target rows per chunk (negative=24 -> 25 targets = 13 + 12)
+#define W2B_RT 25       // target rows per chunk: 25 x 4 VGPRs (negative=24 is ONE chunk)
 #endif
 #ifndef W2B_RES_WAVES
-#define W2B_RES_WAVES 4 // wavefronts per SIMD the kernel is register-allocated for
+#define W2B_RES_WAVES 3 // wavefronts per SIMD the kernel is register-allocated for
 #endif
 #define W2B_RB 5        // rows whose partial dot products are formed and reduced together (bounds the live temporaries)
 #define W2B_NDWMAX 4    // data wavefronts per worker (one thread per 16-byte column: D <= 1024) + 1 producer wavefront
@@ -51,10 +55,31 @@
 
 namespace {
 
+// Explicit LDS address space on every pointer of the kernel's LDS record: dereferences compile to ds_*
+// instructions.  (With generic pointers the two step buffers were selected through a struct reference and
+// address-space inference gave up: 250 flat_load/flat_store per step, each tied to vmcnt AND lgkmcnt, so
+// every window access also waited for the target rows in flight.)
+#define W2B_LDS __attribute__((address_space(3)))
+
 struct Win2Lds {          // scalars owned by the producer wavefront (extends WorkerLds)
   WorkerLds w;
   int clo, chi;           // sentence positions currently resident (empty when chi < clo)
+  unsigned bar_step, bar_chunk;   // arrival counters of the worker's two barriers (monotonic within a launch)
 };
+
+// A barrier among the wavefronts of ONE worker.  Monotonic LDS counter: every arriving wavefront adds 1, everybody
+// polls until `target` arrivals have been counted.  LDS operations of a wavefront execute in order and the CU's LDS
+// serves all of them in arrival order, so what a wavefront wrote to LDS before its arrival is visible to whoever has
+// seen the count -- no s_waitcnt on outstanding GLOBAL memory operations is involved (the row stores of a step stay
+// in flight across the barrier; __syncthreads() would drain them).  The wavefront-scope fences only stop the compiler
+// from moving LDS accesses across the barrier.
+__device__ __forceinline__ void worker_barrier(W2B_LDS unsigned *cnt, unsigned target, int lane, bool arrive = true) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (arrive && lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0)
+    __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // What the producer wavefront hands to the data wavefronts for ONE step (double buffered in LDS)
 struct Step2 {
@@ -66,11 +91,6 @@ struct Step2 {
   int pad[3];
 };
 
-// Explicit LDS address space on every pointer of the kernel's LDS record: dereferences compile to ds_*
-// instructions.  (With generic pointers the two step buffers were selected through a struct reference and
-// address-space inference gave up: 250 flat_load/flat_store per step, each tied to vmcnt AND lgkmcnt, so
-// every window access also waited for the target rows in flight.)
-#define W2B_LDS __attribute__((address_space(3)))
 
 struct Win2 {
   W2B_LDS float *win;             // [S + NH][dim]  current fp32 value of the resident rows (window slots, then hot rows)
@@ -296,26 +316,30 @@ __device__ __forceinline__ void hot_merge(const Rows<MM> &A, const Win2 &L, int 
 // PRODUCER: it walks the sentence, the LCG ledger, the window bookkeeping and the negative draws ONE STEP
 // AHEAD and hands the lists over through a double-buffered LDS record.  The data wavefronts never wait for
 // the scalar work of a step (it was 25-30 % of the step time when wavefront 0 did both).
-// Barrier discipline: every wavefront executes the same s_barrier sequence per step: nck barriers inside
-// the data phase (one per target chunk; the producer executes them after its own work) + one at the end.
-// Register budget: two workers per CU = at most 3 wavefronts per SIMD -> 168 VGPRs.
+// Barrier discipline (worker_barrier): per step the data wavefronts meet once per target chunk (the cross-wavefront
+// sum of the dot products; with LOSS the producer waits there too, without arriving, to book the loss terms) and all
+// wavefronts of the worker meet once at the end of the step.
 // UC: the radius is window-1 (the two outermost context rows of a step are register-held).
 template <int QM, bool LOSS, int MM, bool UC>
-__global__ void __launch_bounds__(320, W2B_RES_WAVES) k_train_resident(const W2bParams P, const long long max_positions,
-                                                           const int R, const int NDW, const int NH) {
+__global__ void __launch_bounds__(W2B_WPG * 64 * (W2B_NDWMAX + 1), W2B_RES_WAVES)
+k_train_resident(const W2bParams P, const long long max_positions, const int R, const int NDW, const int NH,
+                 const int lds_ints_per_worker) {
   extern __shared__ int smem[];
-  W2B_LDS int *const smem_lds = (W2B_LDS int *)smem;
+  const int WPT = (NDW + 1) * 64;                        // threads per worker
+  // which worker of this workgroup: the same for all lanes of a wavefront (WPT is a multiple of 64) -- said so with
+  // readfirstlane, or every LDS address and with it the whole control flow would count as divergent
+  const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / WPT);
+  W2B_LDS int *const smem_lds = (W2B_LDS int *)smem + half * lds_ints_per_worker;
   const Win2 L0 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, NH, 0);
   const Win2 L1 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, NH, 1);
   const Win2 &L = L0;                                   // everything that is not double buffered
   W2B_LDS WorkerLds *S = &L.S->w;
   W2B_LDS int *s_sen = L.sen;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = (int)threadIdx.x - half * WPT, lane = tid & 63, wave = tid >> 6;
   const bool producer = (wave == NDW);
-  const int wid = blockIdx.x;
-  if (wid >= P.num_threads) return;
-  W2bWorker *G = P.workers + wid;
-  if (G->done) return;
+  const int wid = (int)blockIdx.x * W2B_WPG + half;
+  W2bWorker *G = P.workers + (wid < P.num_threads ? wid : 0);
+  const bool valid = wid < P.num_threads && !G->done;
   QParam qp;
   qp.bitlevel = P.bitlevel;
   qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
@@ -323,16 +347,22 @@ __global__ void __launch_bounds__(320, W2B_RES_WAVES) k_train_resident(const W2b
   const int NS = 2 * R + 1;
   const Rows<MM> A{P, (long long)wid * 2 * (NS + NH), NS + NH, P.dim, tid * 4, !producer && tid * 4 < P.dim};
   const bool active = A.active;
-  for (int i = tid; i < G->sen_len; i += blockDim.x) s_sen[i] = G->sen[i];
-  for (int i = tid; i < NS; i += blockDim.x) { L.slot_row[i] = -1; L.slot_ref[i] = 0; L.pos_slot[i] = 0; L.slot_gen[i] = 0; }
-  for (int i = tid; i < (P.negative + 2 > 66 ? P.negative + 2 : 66); i += blockDim.x) { L.ja[i] = P.jump_a[i]; L.jc[i] = P.jump_c[i]; }
-  if (tid == 0) {
-    S->rng = G->rng; S->cursor = G->cursor; S->wc = G->word_count; S->last_wc = G->last_word_count;
-    S->sen_len = G->sen_len; S->sen_pos = G->sen_pos; S->override_ = G->first_override;
-    S->eof = 0; S->done = 0; S->cw = 0; S->nt = 0; S->alpha = 0.f;
-    L.S->clo = 0; L.S->chi = -1;
+  if (valid) {
+    for (int i = tid; i < G->sen_len; i += WPT) s_sen[i] = G->sen[i];
+    for (int i = tid; i < NS; i += WPT) { L.slot_row[i] = -1; L.slot_ref[i] = 0; L.pos_slot[i] = 0; L.slot_gen[i] = 0; }
+    for (int i = tid; i < (P.negative + 2 > 66 ? P.negative + 2 : 66); i += WPT) { L.ja[i] = P.jump_a[i]; L.jc[i] = P.jump_c[i]; }
+    if (tid == 0) {
+      S->rng = G->rng; S->cursor = G->cursor; S->wc = G->word_count; S->last_wc = G->last_word_count;
+      S->sen_len = G->sen_len; S->sen_pos = G->sen_pos; S->override_ = G->first_override;
+      S->eof = 0; S->done = 0; S->cw = 0; S->nt = 0; S->alpha = 0.f;
+      L.S->clo = 0; L.S->chi = -1;
+      L.S->bar_step = 0u; L.S->bar_chunk = 0u;
+    }
   }
-  __syncthreads();
+  __syncthreads();            // the only workgroup-wide barrier: every wavefront of both workers is still here
+  if (!valid) return;
+  W2B_LDS unsigned *const bar_step = &L.S->bar_step, *const bar_chunk = &L.S->bar_chunk;
+  unsigned n_step = 0u, n_chunk = 0u;       // barriers passed so far (identical in every wavefront of the worker)
   double loss_acc = 0.0;
   const int W = P.window, K = P.negative;
   // producer registers: the unigram-table gather and the alpha load of the NEXT step are issued at the end
@@ -561,18 +591,20 @@ __global__ void __launch_bounds__(320, W2B_RES_WAVES) k_train_resident(const W2b
   // same s_barrier sequence per step.
   if (producer) {
     prepare(L0, max_positions == 0);
-    __syncthreads();
+    worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);
     for (long long it = 0;; ++it) {
       const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
       const bool stop = I.St->stop != 0;
       const int nck = I.St->nck;
       if (!stop) prepare((it & 1) ? L0 : L1, it + 1 == max_positions);
       for (int i = 0; i < nck; i++) {
-        __syncthreads();
+        ++n_chunk;
         if (LOSS) {
+          worker_barrier(bar_chunk, (unsigned)NDW * n_chunk, lane, false);    // wait for the data wavefronts' sums
           // The log-sigmoid bookkeeping of chunk i (ref :480-483) happens HERE, off the data wavefronts' registers
           // (expf/logf cost them ~40 VGPRs): after the chunk's barrier its partial dot products sit in red[i & 1]
-          // until the data wavefronts have passed the NEXT barrier, which waits for this wavefront.
+          // until the data wavefronts have passed the end-of-step barrier, which waits for this wavefront (two
+          // chunks later at the earliest: red is double buffered).
           const int cs = i ? I.cend[i - 1] : 0, n = I.cend[i] - cs;
           if (lane < n) {
             const W2B_LDS float *red = L.red + (i & 1) * (W2B_RT * W2B_NDWMAX);
@@ -587,11 +619,11 @@ __global__ void __launch_bounds__(320, W2B_RES_WAVES) k_train_resident(const W2b
           }
         }
       }
-      __syncthreads();                                   // lists of the next step are published; this step is done
+      worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);   // lists of the next step are published; this step is done
       if (stop) break;
     }
   } else {
-    __syncthreads();
+    worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);
     for (long long it = 0;; ++it) {
       const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
       const bool stop = I.St->stop != 0;
@@ -633,13 +665,19 @@ __global__ void __launch_bounds__(320, W2B_RES_WAVES) k_train_resident(const W2b
 #pragma unroll
           for (int i = 0; i < W2B_RT; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
           if (active) {
+            // private hot rows first, from LDS: nothing is in flight towards these registers yet, so the reads need no
+            // memory wait (issued after the loads below they would have to drain every outstanding load first)
+            if (NH > 0) {
+#pragma unroll
+              for (int i = 0; i < W2B_RT; i++) {
+                const unsigned hk = (unsigned)(rows[i] - 1);
+                if (start + i < end && hk < (unsigned)NH) x[i] = lds_ld(L.win + (NS + (int)hk) * dim + col0);
+              }
+            }
 #pragma unroll
             for (int i = 0; i < W2B_RT; i++) {
-              if (start + i < end) {
-                const unsigned hk = (unsigned)(rows[i] - 1);
-                if (hk < (unsigned)NH) x[i] = lds_ld(L.win + (NS + (int)hk) * dim + col0);
-                else x[i] = A.ld_v(rows[i]);
-              }
+              const unsigned hk = (unsigned)(rows[i] - 1);
+              if (start + i < end && !(hk < (unsigned)NH)) x[i] = A.ld_v(rows[i]);
             }
           }
         }
@@ -750,7 +788,7 @@ __global__ void __launch_bounds__(320, W2B_RES_WAVES) k_train_resident(const W2b
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        worker_barrier(bar_chunk, (unsigned)NDW * ++n_chunk, lane);
         float gl = 0.f;
         if (lane < n) {
           float f = 0.f;
@@ -832,12 +870,12 @@ __global__ void __launch_bounds__(320, W2B_RES_WAVES) k_train_resident(const W2b
         }
       }
       if (NH > 0 && (stop || (it & (P.hot_period - 1)) == P.hot_period - 1)) hot_merge<MM>(A, L, NS, NH, dirty, lane, wave);
-      __syncthreads();                                   // lists of the next step are published; this step is done
+      worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);   // lists of the next step are published; this step is done
       if (stop) break;
     }
   }
   const int sl = S->sen_len;
-  for (int i = tid; i < sl; i += blockDim.x) G->sen[i] = s_sen[i];
+  for (int i = tid; i < sl; i += WPT) G->sen[i] = s_sen[i];
   if (LOSS) {
     // producer lanes hold the log-sigmoid terms, lane 0 of every data wavefront the regularisation terms
     if (producer) {
@@ -859,7 +897,7 @@ __global__ void __launch_bounds__(320, W2B_RES_WAVES) k_train_resident(const W2b
 static int win2_threads(int dim) { return (((dim / 4) + 63) / 64 + 1) * 64; }
 
 // Geometry of the sentence-resident kernel for a shape: radius (-1: use the plain kernel) and how many of the
-// `hot_wanted` hottest target rows get an LDS slot.  Two workgroups share the 160 KiB of a CU.
+// `hot_wanted` hottest target rows get an LDS slot.  Two workers (one workgroup) share the 160 KiB of a CU.
 int w2b_resident_plan(int dim, int window, int negative, int hot_wanted, int *hot_out) {
   if (hot_out) *hot_out = 0;
   if (dim % 4 != 0 || dim > 4 * 64 * W2B_NDWMAX) return -1;     // 16-byte columns, at most 4 data wavefronts
@@ -879,34 +917,44 @@ long long w2b_resident_scratch_rows(int R, int NH) { return 2ll * (2 * R + 1 + N
 
 // workgroups of the sentence-resident kernel that are resident per CU (occupancy query of the instantiation
 // that would run)
+static size_t win2_lds_per_worker(const W2bParams &p, int R, int NH) {
+  return (win2_lds_bytes(p.dim, p.window, p.negative, R, NH) + 15) & ~(size_t)15;
+}
+
+// WORKERS of the sentence-resident kernel that are resident per CU (occupancy query of the instantiation that would
+// run: workgroups per CU x W2B_WPG workers per workgroup)
 int w2b_resident_per_cu(const W2bParams &p, int R, int NH, bool loss) {
-  const size_t lds = win2_lds_bytes(p.dim, p.window, p.negative, R, NH);
+  const size_t lds = W2B_WPG * win2_lds_per_worker(p, R, NH);
+  const int threads = W2B_WPG * win2_threads(p.dim);
   int nb = 0;
   (void)dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
     constexpr int QM = decltype(qm)::value;
     // (the table-form / radius variants share the register budget)
-    if (loss) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<QM, true, 0, false>, win2_threads(p.dim), lds);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<QM, false, 0, false>, win2_threads(p.dim), lds);
+    if (loss) return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<QM, true, 0, false>, threads, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<QM, false, 0, false>, threads, lds);
   });
-  return nb > 0 ? nb : 1;
+  return (nb > 0 ? nb : 1) * W2B_WPG;
 }
 
 // Coherent rows only (memory mode 0): with relaxed rows the launcher of the trainer picks the plain kernel.
 hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int R, int NH, bool loss, hipStream_t s) {
-  const int threads = win2_threads(p.dim);   // data wavefronts (one thread per 16-byte column) + 1 producer wavefront
-  const int NDW = threads / 64 - 1;
-  const size_t lds = win2_lds_bytes(p.dim, p.window, p.negative, R, NH);
+  const int wthreads = win2_threads(p.dim);  // data wavefronts (one thread per 16-byte column) + 1 producer wavefront
+  const int NDW = wthreads / 64 - 1;
+  const size_t wlds = win2_lds_per_worker(p, R, NH);
+  const int threads = W2B_WPG * wthreads, grid = (p.num_threads + W2B_WPG - 1) / W2B_WPG;
+  const size_t lds = W2B_WPG * wlds;
+  const int lds_ints = (int)(wlds / 4);
   static bool reported = false;
   if (!reported && getenv("W2B_DEBUG")) {
     reported = true;
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<1, false, 0, false>, threads, lds);
-    fprintf(stderr, "w2b debug: sentence-resident kernel R=%d hot=%d lds=%zu B threads=%d, resident workgroups/CU=%d\n", R, NH, lds, threads, nb);
+    fprintf(stderr, "w2b debug: sentence-resident kernel R=%d hot=%d lds=%zu B/worker threads=%d/worker, %d workers per workgroup, resident workgroups/CU=%d\n", R, NH, wlds, wthreads, W2B_WPG, nb);
   }
   return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
     constexpr int QM = decltype(qm)::value;
     // template MM carries the memory mode in bits 0-2 (0: agent-scope rows) and "tables >= 2 GiB" (per-row descriptors) in bit 3
-#define W2B_LAUNCH_R(LOSS, MMV, UCV) hipLaunchKernelGGL((k_train_resident<QM, LOSS, MMV, UCV>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions, R, NDW, NH)
+#define W2B_LAUNCH_R(LOSS, MMV, UCV) hipLaunchKernelGGL((k_train_resident<QM, LOSS, MMV, UCV>), dim3(grid), dim3(threads), lds, s, p, max_positions, R, NDW, NH, lds_ints)
 #define W2B_LAUNCH_R2(MMV, UCV) do { if (loss) W2B_LAUNCH_R(true, MMV, UCV); else W2B_LAUNCH_R(false, MMV, UCV); } while (0)
     if (R < p.window) { if (p.tab_bytes) W2B_LAUNCH_R2(0, true); else W2B_LAUNCH_R2(8, true); }
     else { if (p.tab_bytes) W2B_LAUNCH_R2(0, false); else W2B_LAUNCH_R2(8, false); }
