@@ -58,18 +58,25 @@ def parse():
     ap.add_argument("--positions", type=int, default=0,
                     help="sentence positions per worker per step (0: --batch / workers)")
     ap.add_argument("--ids", choices=["zipf", "uniform"], default="zipf")
+    ap.add_argument("--zipf-shift", type=int, default=0,
+                    help="experiment: Zipf weights 1/(rank + N) instead of 1/rank (a Zipf stream without its N hottest words)")
     ap.add_argument("--sync-every", type=int, default=16)
     ap.add_argument("--sync-mode", type=int, default=0)
-    ap.add_argument("--sync-impl", choices=["lib", "torch"], default="torch",
-                    help="replica exchange: torch = torch.distributed all_reduce (RCCL) on a zero-copy view of the "
-                         "library's [u||v] buffer (default: the process group the launcher already set up); "
-                         "lib = the library's own RCCL communicator (w2b_comm_init / w2b_sync_replicas, what the "
-                         "CLI uses)")
+    ap.add_argument("--sync-impl", choices=["lib", "torch"], default="lib",
+                    help="replica exchange: lib = the library's own RCCL communicator (w2b_comm_init / "
+                         "w2b_sync_replicas: what the CLI uses; falls back to torch if its initialisation fails on any "
+                         "rank); torch = torch.distributed all_reduce (RCCL) on a zero-copy view of the library's "
+                         "[u||v] buffer")
     ap.add_argument("--cpu-baseline", choices=["reference", "port", "none"], default="reference")
     ap.add_argument("--cpu-tokens", type=int, default=6_000_000)
     ap.add_argument("--also-relaxed", type=int, default=1,
                     help="N=1 only: after the headline (coherent) run, time the same steps with relaxed row "
                          "coherence and report it as an extra object")
+    ap.add_argument("--also-legs", type=int, default=1,
+                    help="N=1, worker form only: after the headline, time the same steps (a) with the loss bookkeeping "
+                         "on (the instantiation ./word2bits runs: it prints 'Epoch Loss') and (b) at bitlevel 2, and "
+                         "report both as extra objects")
+    ap.add_argument("--loss", type=int, default=0, help="1: headline run with the loss bookkeeping on")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--window-cache", type=int, default=-1,
                     help="worker form: -1 = automatic, 1 = sentence-resident kernel (context window rows stay in "
@@ -87,11 +94,11 @@ def algorithmic_bytes_per_word(D, cw, K):
     return 8 * D * (cw + K + 1) + 4 * (1 + cw + K)
 
 
-def zipf_cdf(torch, V, device, uniform):
+def zipf_cdf(torch, V, device, uniform, shift=0):
     if uniform:
         w = torch.ones(V - 1, dtype=torch.float64, device=device)
     else:
-        w = 1.0 / torch.arange(1, V, dtype=torch.float64, device=device)
+        w = 1.0 / (torch.arange(1, V, dtype=torch.float64, device=device) + shift)
     cdf = torch.cumsum(w, 0)
     return cdf / cdf[-1]
 
@@ -303,7 +310,7 @@ def main():
 
     # ---- synthetic corpus resident in HBM (untimed)
     per_rank_tokens = args.tokens                 # weak scaling: the same stream length per GPU
-    cdf = zipf_cdf(torch, V, dev, args.ids == "uniform")
+    cdf = zipf_cdf(torch, V, dev, args.ids == "uniform", args.zipf_shift)
     stream = draw_ids(torch, cdf, per_rank_tokens, gen)
     stream[999::1000] = 0                        # "</s>" every 1000 tokens
     counts_t = torch.bincount(stream.long(), minlength=V)
@@ -325,10 +332,10 @@ def main():
     nw_local = workers if args.form == "worker" else 1
     worker_offset, _ = replicas.worker_plan(nw_local * world, world, rank)   # global Hogwild worker ids
 
-    def make_trainer(relaxed):
-        tr = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=nw_local,
+    def make_trainer(relaxed, loss=bool(args.loss), bitlevel=args.bitlevel):
+        tr = w2b.Trainer(V, D, W, K, bitlevel, num_threads=nw_local,
                          iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words * world,
-                         compute_loss=False, device=local_rank, worker_offset=worker_offset,
+                         compute_loss=loss, device=local_rank, worker_offset=worker_offset,
                          total_threads=nw_local * world, relaxed_coherence=relaxed,
                          window_cache=wcache)
         tr.init_net()                                  # InitNet values (LCG seed 1), ref :343-361
@@ -360,6 +367,7 @@ def main():
             sync_impl = "library RCCL communicator (w2b_sync_replicas)"
 
     nsteps = args.steps + args.warmup
+    kinfo = None
     if args.form == "tuples":
         B = args.batch
         need = nsteps * B
@@ -404,6 +412,7 @@ def main():
             tr.epoch_begin()
 
         prepare(t)
+        kinfo = t.worker_kernel_info()
         positions = args.positions if args.positions > 0 else max(1, args.batch // workers)
         words_per_step = workers * positions
 
@@ -455,6 +464,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, launches = t.timing_read()
+    sync_n, sync_ms = t.sync_stats() if (world > 1 and torch_sync is None) else (0, 0.0)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -480,28 +490,69 @@ def main():
                                     "agent scope (sc1): Hogwild coherent across the 8 XCD L2s",
                    "replica_sync": ("%s every %d steps, mode %d (0 = delta-sum)" %
                                     (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl,
-                   "exchanges_in_timed_region": n_syncs[0]},
+                   "exchanges_in_timed_region": n_syncs[0],
+                   "worker_kernel": (dict(zip(("sentence_resident", "radius", "column_bytes", "workers_per_cu",
+                                               "private_hot_rows"), kinfo)) if kinfo else None),
+                   "workers": workers if args.form == "worker" else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
                      "kernel": "k_train_tuples" if args.form == "tuples" else
-                               ("k_train_workers" if (args.window_cache == 0 or (args.window_cache < 0 and args.relaxed))
-                                else "k_train_workers2"),
+                               ("k_train_resident" if kinfo and kinfo[0] else "k_train_workers"),
                      "algorithmic_bytes_per_word": bpw, "avg_launch_ms": avg_launch_s * 1e3,
                      "launches": launches},
     }
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.form)
+    result["roofline"]["algorithmic_bytes_per_launch"] = words_per_step * bpw
+    # HBM bytes per launch from the counters: collected by tools/gpu_profile_session.sh with rocprofv3 --pmc (separate
+    # FETCH_SIZE / WRITE_SIZE passes of this same command) and committed; quoted only for the shape they were measured on
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.form)
     if world == 1 and os.path.exists(pmc) and args.ids == "zipf" and not args.relaxed:
         try:
             pj = json.load(open(pmc))
-            if pj.get("words_per_launch") == words_per_step:
-                result["roofline"]["traffic"] = pj["hbm_bytes_per_launch"]
+            same = (pj.get("vocab"), pj.get("dim"), pj.get("negative"), pj.get("bitlevel")) == (V, D, K, args.bitlevel)
+            if same and pj.get("words_per_launch"):
+                per_word = pj["hbm_bytes_per_launch"] / pj["words_per_launch"]
+                result["roofline"]["traffic"] = per_word * words_per_step
+                result["roofline"]["traffic_GBps"] = per_word * words_per_step / avg_launch_s / 1e9
                 result["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
-                                                        "passes, FETCH x2 gfx950 correction) on this command" %
-                                                        os.path.basename(pmc))
-                result["roofline"]["algorithmic_bytes_per_launch"] = words_per_step * bpw
+                                                        "passes, FETCH x2 gfx950 correction) on this command, %d centre "
+                                                        "words per launch there" %
+                                                        (os.path.basename(pmc), pj["words_per_launch"]))
         except Exception:
             pass
+    if world > 1:
+        result["replica_exchange"] = {
+            "every_steps": args.sync_every, "mode": "delta-sum" if args.sync_mode == 0 else "average",
+            "implementation": sync_impl, "exchanges": n_syncs[0],
+            "bytes_all_reduced_per_exchange": 8 * V * D,
+            "device_ms_per_exchange": (sync_ms / sync_n) if sync_n else None}
     t.close()
+
+    def timed_leg(tr, wps):
+        prepare(tr)
+        for i in range(args.warmup):
+            step(i, tr)
+        tr.synchronize()
+        tr.timing_enable(True)
+        tr.timing_read()
+        r0 = time.perf_counter()
+        for i in range(args.warmup, nsteps):
+            step(i, tr)
+        tr.synchronize()
+        rdt = time.perf_counter() - r0
+        rms, rl = tr.timing_read()
+        tr.close()
+        return {"value": wps * args.steps / rdt, "unit": "words/s", "ms_per_step": rdt / args.steps * 1e3,
+                "roofline_frac": wps * bpw / ((rms / 1e3) / max(1, rl)) / HBM_PEAK}
+
+    if world == 1 and args.also_legs and args.form == "worker" and not args.relaxed and not args.loss:
+        # the path ./word2bits runs (it always prints "Epoch Loss", ref :539): the LOSS instantiation of the same kernel
+        leg = timed_leg(make_trainer(False, loss=True), words_per_step)
+        leg["note"] = "same steps with compute_loss = 1 (log-sigmoid terms booked by the producer wavefront)"
+        result["with_loss_bookkeeping"] = leg
+        if args.bitlevel != 2:
+            leg = timed_leg(make_trainer(False, bitlevel=2), words_per_step)
+            leg["note"] = "same steps at bitlevel 2 (BASELINE configs[2] quantizer)"
+            result["bitlevel2"] = leg
     if world == 1 and args.also_relaxed and not args.relaxed:
         # same steps, same data, relaxed row coherence -- reported beside the headline
         if args.form == "worker":          # relaxed rows run the plain worker kernel with its own residency

@@ -44,7 +44,7 @@ def test_single_worker_epochs_bit_exact_row_desc(gpu, row_desc, bitlevel, sample
     test_gpu_exact.test_single_worker_epochs_bit_exact(gpu, bitlevel, sample, D, window, negative, iters)
 
 
-@pytest.mark.parametrize("D,window,negative,bitlevel", [(800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0), (800, 12, 5, 1)])
+@pytest.mark.parametrize("D,window,negative,bitlevel", [(800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0), (768, 12, 5, 1)])
 def test_resident_equals_plain_single_worker_row_desc(gpu, row_desc, D, window, negative, bitlevel, monkeypatch):
     test_gpu_worker.test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, window, negative, bitlevel,
                                                                                     None, monkeypatch)

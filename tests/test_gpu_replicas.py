@@ -87,3 +87,100 @@ def test_two_replicas_exchange_through_the_zero_copy_view(gpu):
     assert all(r[1] for r in res)
     assert res[0][2] == res[1][2]                    # both replicas hold the same model after the last exchange
     assert [(r[3], r[4]) for r in res] == [(0, 8), (8, 8)]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The library's OWN exchange (w2b_comm_init / w2b_sync_replicas over RCCL) needs one GPU per rank: these tests run
+# whenever at least two devices are visible and skip on the 1-GPU boxes of this pool.
+
+def _lib_rank(rank, world, uid, out, barrier):
+    import word2bits_amd as w2b
+    from word2bits_amd import replicas
+    V, D, W, K, nw = 3000, 64, 5, 5, 8
+    rng = np.random.default_rng(100 + rank)
+    ids = (rng.zipf(1.3, 40000) % (V - 1) + 1).astype(np.int32)
+    ids[49::50] = 0
+    allc = np.zeros(V, np.int64)
+    for r in range(world):                                        # the same global counts on every rank
+        rr = np.random.default_rng(100 + r)
+        x = (rr.zipf(1.3, 40000) % (V - 1) + 1).astype(np.int32)
+        x[49::50] = 0
+        allc += np.bincount(x, minlength=V)
+    counts = np.maximum(allc, 1)
+    off, per = replicas.worker_plan(nw * world, world, rank)
+    t = w2b.Trainer(V, D, W, K, 1, num_threads=nw, iter=1, sample=0.0, train_words=int(counts.sum()),
+                    compute_loss=False, device=rank, worker_offset=off, total_threads=nw * world)
+    t.init_net()
+    t.set_vocab_counts(counts, 100000)
+    t.set_corpus(ids)
+    t.set_shards(replicas.token_shard_starts(len(ids), nw, 0, nw))
+    t.comm_init(world, rank, uid)
+    t.epoch_begin()
+    res = []
+    for mode in (0, 1):
+        base = np.concatenate([x.ravel() for x in t.get_model()])      # replicas are identical at this point
+        for _ in range(3):
+            t.train_step(150)
+        mine = np.concatenate([x.ravel() for x in t.get_model()])
+        _, wca, _, _ = t.epoch_status(want_loss=False)
+        out[rank] = (mine, wca)
+        barrier.wait()
+        every = [out[r][0] for r in range(world)]
+        expect = base + sum(m - base for m in every) if mode == 0 else sum(every) / np.float32(world)
+        barrier.wait()
+        t.sync_replicas(mode)
+        t.synchronize()
+        got = np.concatenate([x.ravel() for x in t.get_model()])
+        res.append((float(np.abs(got - expect).max()), float(np.abs(mine - expect).max())))
+    n, ms = t.sync_stats()
+    t.close()
+    out[rank] = (res, n)
+
+
+def test_library_exchange_over_rccl_two_gpus(gpu):
+    """w2b_comm_init + w2b_sync_replicas on two GPUs (one thread per replica, as ./word2bits -gpus 2 drives them):
+    delta-sum (mode 0) and average (mode 1) against the same arithmetic on the host copies of both replicas."""
+    import threading
+    import word2bits_amd as w2b
+    if gpu.w2b_device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL does not put two ranks on one device)")
+    world = 2
+    uid = w2b.comm_unique_id()
+    out = [None] * world
+    barrier = threading.Barrier(world)
+    errs = []
+
+    def run(r):
+        try:
+            _lib_rank(r, world, uid, out, barrier)
+        except Exception as e:            # a failing rank must not leave the other one waiting in RCCL forever
+            errs.append((r, repr(e)))
+            barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=600)
+    assert not errs, errs
+    for r in range(world):
+        res, n = out[r]
+        assert n == 2
+        for err, moved in res:
+            assert err <= 1e-6 and moved > 0          # exchanged model == host arithmetic; the other replica's work arrived
+
+
+def test_cli_two_gpus(gpu, tmp_path):
+    """./word2bits -gpus 2: corpus shards <-> replicas, exchange every 2 launches and at every epoch end"""
+    import subprocess
+    from w2b_testlib import GOLDEN, ROOT, read_vectors
+    if gpu.w2b_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    out = str(tmp_path / "o.vec")
+    r = subprocess.run([os.path.join(ROOT, "word2bits"), "-train", os.path.join(GOLDEN, "corpus_small.txt"), "-output", out,
+                        "-gpus", "2", "-threads", "8", "-sync-every", "2", "-positions", "100", "-size", "32", "-window", "5",
+                        "-negative", "5", "-iter", "2", "-min-count", "3", "-binary", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-300:] + r.stderr[-300:]
+    assert r.stdout.count("Epoch Loss:") == 2
+    words, M = read_vectors(out, 1)
+    assert len(words) == 60 and np.isfinite(M).all()
+    assert set(np.unique(M.view(np.uint32)).tolist()) <= {0x3EAAAAAB, 0xBEAAAAAB}

@@ -150,7 +150,7 @@ def test_shard_override_and_multi_worker_bookkeeping(gpu, window_cache):
 @pytest.mark.parametrize("D,window,negative,bitlevel", [
     (800, 8, 24, 1), (200, 8, 24, 2), (64, 2, 3, 0), (96, 1, 2, 1),
     (1000, 8, 12, 1),        # BASELINE configs[4] row length: the whole window still fits next to a second workgroup
-    (800, 12, 5, 1),         # window too wide for LDS: radius window-1, the outermost context rows are register-held
+    (768, 12, 5, 1),         # window too wide for LDS: radius window-1, the outermost context rows are register-held
     (1024, 3, 3, 2),         # the widest row of the 16-byte-column form
 ])
 @pytest.mark.parametrize("hot", ["0", None, "8"])
@@ -180,7 +180,7 @@ def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, wind
         t.set_shards(np.zeros(1, np.int64))
         if wc:
             resident, radius, colb, _, nh = t.worker_kernel_info()
-            assert resident and colb == 16 and radius == (window - 1 if (D, window) == (800, 12) else window)
+            assert resident and colb == 16 and radius == (window - 1 if (D, window) == (768, 12) else window)
             if hot == "0":
                 assert nh == 0
             elif D <= 200:

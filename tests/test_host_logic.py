@@ -5,6 +5,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -189,3 +190,21 @@ def test_text_writer_equals_printf_lf(tmp_path):
             assert toks[1 + b] == want, (k, v, toks[1 + b], want)
             k += 1
     c.close()
+
+
+def test_integration_patch_applies_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """INTEGRATION.md's reference-side patch, applied to a scratch copy of the reference source and linked against
+    libword2bits_hip.so (oracle/make_integration_build.py): it must apply to the mounted reference, compile, and --
+    here, without a GPU -- stop with the library's W2B_ENOGPU text instead of training on some CPU path."""
+    import subprocess
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("no /root/reference here")
+    import word2bits_amd as w2b
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "oracle", "make_integration_build.py")], stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "oracle", "_ref", "word2bits_hipseam")
+    assert os.path.exists(exe)
+    if w2b.lib().w2b_device_count() > 0:
+        pytest.skip("a GPU is visible: covered by tests/test_gpu_integration.py")
+    r = subprocess.run([exe, "-train", os.path.join(ROOT, "tests", "golden", "corpus_small.txt"), "-output", str(tmp_path / "o"),
+                        "-min-count", "3"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Vocab size: 60" in r.stdout and "no HIP device visible" in r.stdout

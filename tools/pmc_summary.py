@@ -8,7 +8,9 @@ HBM bytes per launch of the training kernel:
                                             buffer_load_dwordx4 of 1 KiB per wavefront)
     write = WRITE_SIZE [KB] * 1024         (uncalibrated in the guide; compared against the algorithmic
                                             write bytes below as a plausibility check)
-usage: pmc_summary.py <fetch.csv> <write.csv> <l2.csv> <out.json> [kernel substring]
+usage: pmc_summary.py <fetch.csv> <write.csv> <l2.csv> <out.json> [kernel substring] [bench.json of the profiled command]
+The bench line of the profiled command supplies the shape (vocab, dim, negative, bitlevel) and the centre words per
+launch, so that bench.py can scale the measured bytes to its own launch size (roofline.traffic).
 """
 import csv
 import json
@@ -29,6 +31,7 @@ def per_dispatch(path, kernel_sub):
 def main():
     fetch, write, l2, out = sys.argv[1:5]
     ksub = sys.argv[5] if len(sys.argv) > 5 else "k_train_tuples"
+    bench = sys.argv[6] if len(sys.argv) > 6 else None
     f = per_dispatch(fetch, ksub)
     w = per_dispatch(write, ksub)
     l = per_dispatch(l2, ksub) if l2 != "-" else {}
@@ -47,6 +50,17 @@ def main():
     if l:
         hit, miss = l["TCC_HIT_sum"][0], l["TCC_MISS_sum"][0]
         res["l2_hit_rate"] = hit / (hit + miss)
+    if bench:
+        for line in open(bench):
+            if line.startswith("{"):
+                b = json.loads(line)
+                c = b["config"]
+                res.update({"words_per_launch": c["words_per_step_per_gpu"], "vocab": c["vocab"], "dim": c["dim"],
+                            "negative": c["negative"], "bitlevel": c["bitlevel"], "ids": c["ids"],
+                            "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
+                            "avg_launch_ms_unprofiled": b["roofline"]["avg_launch_ms"]})
+                res["hbm_bytes_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+                res["counter_GBps_at_unprofiled_launch_time"] = res["hbm_bytes_per_launch"] / (b["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 

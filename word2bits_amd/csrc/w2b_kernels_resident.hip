@@ -34,19 +34,24 @@
 #include <cstdlib>
 
 // Register budget and workgroup shape.  A worker is up to 4 data wavefronts + 1 producer wavefront.  The hardware
-// places wavefront i of a workgroup on SIMD i mod 4, so as a workgroup of its own a worker puts TWO of its five
+// places wavefront i of a workgroup on SIMD i mod 4, so a worker that is a workgroup of its own puts TWO of its five
 // wavefronts on SIMD 0, and a second such workgroup fits on the CU only within 128 VGPRs (measured: at 168 VGPRs 256
 // and 512 one-worker workgroups run at the same speed although the occupancy API answers 2 per CU).  128 VGPRs hold
-// 13 target rows: two memory round trips per centre word at negative = 24.  So a workgroup carries W2B_WPG = 2
-// INDEPENDENT workers: ten wavefronts land 3/3/2/2 on the SIMDs, 168 VGPRs each, all 25 target rows of a centre word
-// in registers -- one round trip per word AND two workers per CU.  The workers of a workgroup never wait for each
-// other: their wavefronts synchronise through per-worker counters in LDS (worker_barrier), not s_barrier.
-#define W2B_WPG 2       // workers per workgroup
+// 13 target rows: two memory round trips per centre word at negative = 24.
+// Default: W2B_WPG = 1 worker per workgroup, W2B_RT = 13, 128 VGPRs, s_barrier.
+// Alternative (measured, kept selectable at build time): W2B_WPG = 2 INDEPENDENT workers per workgroup -- ten
+// wavefronts land 3/3/2/2 on the SIMDs, 168 VGPRs each, W2B_RT = 25: all target rows of a centre word in registers, one
+// round trip per word AND two workers per CU; the workers synchronise their own wavefronts through LDS counters
+// (worker_barrier) because s_barrier would couple them.  On MI355X it is +2 % at negative = 24 and -10 % at negative =
+// 12 (25-row code for 13-row chunks), and the counter barrier itself costs 2 % against s_barrier: not the default.
+#ifndef W2B_WPG
+#define W2B_WPG 1       // workers per workgroup
+#endif
 #ifndef W2B_RT
-#define W2B_RT 25       // target rows per chunk: 25 x 4 VGPRs (negative=24 is ONE chunk)
+#define W2B_RT (W2B_WPG == 1 ? 13 : 25)       // target rows per chunk (x 4 VGPRs)
 #endif
 #ifndef W2B_RES_WAVES
-#define W2B_RES_WAVES 3 // wavefronts per SIMD the kernel is register-allocated for
+#define W2B_RES_WAVES (W2B_WPG == 1 ? 4 : 3)  // wavefronts per SIMD the kernel is register-allocated for
 #endif
 #define W2B_RB 5        // rows whose partial dot products are formed and reduced together (bounds the live temporaries)
 #define W2B_NDWMAX 4    // data wavefronts per worker (one thread per 16-byte column: D <= 1024) + 1 producer wavefront
@@ -54,6 +59,20 @@
 #define W2B_HOTMAX 8    // most target rows with a private LDS slot
 
 namespace {
+
+// Phase timers (builds with -DW2B_PHASE_TIMERS; worker 0 only; shader clocks; printed by w2b_trainer_destroy under
+// W2B_DEBUG):  producer wavefront: [0] prepare, [1] waiting at the end-of-step barrier, [2] loss bookkeeping
+//   data wavefront 0  : [4] loads issued -> window exchange + phase A done, [5] partial dots (+ wait for the rows),
+//                       [6] chunk barrier wait, [7] g + updates + stores, [8] phase C + hot merge,
+//                       [9] end-of-step barrier wait, [10] steps
+#ifdef W2B_PHASE_TIMERS
+#define W2B_TICK(k) do { if (timing_) { const unsigned long long n_ = __builtin_readcyclecounter(); \
+    atomicAdd(&P.shared->dbg[k], n_ - tick_); tick_ = n_; } } while (0)
+#define W2B_COUNT(k) do { if (timing_) atomicAdd(&P.shared->dbg[k], 1ull); } while (0)
+#else
+#define W2B_TICK(k) do { } while (0)
+#define W2B_COUNT(k) do { } while (0)
+#endif
 
 // Explicit LDS address space on every pointer of the kernel's LDS record: dereferences compile to ds_*
 // instructions.  (With generic pointers the two step buffers were selected through a struct reference and
@@ -65,15 +84,21 @@ struct Win2Lds {          // scalars owned by the producer wavefront (extends Wo
   WorkerLds w;
   int clo, chi;           // sentence positions currently resident (empty when chi < clo)
   unsigned bar_step, bar_chunk;   // arrival counters of the worker's two barriers (monotonic within a launch)
+  double loss_reg;                // regularisation terms of the loss booked by the data wavefronts (reg != 0 only)
 };
 
-// A barrier among the wavefronts of ONE worker.  Monotonic LDS counter: every arriving wavefront adds 1, everybody
+// A barrier among the wavefronts of ONE worker (W2B_WPG > 1; with one worker per workgroup it is s_barrier).
+// Monotonic LDS counter: every arriving wavefront adds 1, everybody
 // polls until `target` arrivals have been counted.  LDS operations of a wavefront execute in order and the CU's LDS
 // serves all of them in arrival order, so what a wavefront wrote to LDS before its arrival is visible to whoever has
 // seen the count -- no s_waitcnt on outstanding GLOBAL memory operations is involved (the row stores of a step stay
 // in flight across the barrier; __syncthreads() would drain them).  The wavefront-scope fences only stop the compiler
 // from moving LDS accesses across the barrier.
 __device__ __forceinline__ void worker_barrier(W2B_LDS unsigned *cnt, unsigned target, int lane, bool arrive = true) {
+#if W2B_WPG == 1           // the workgroup IS the worker: the hardware barrier (the producer executes the chunk barriers too)
+  __syncthreads();
+  return;
+#endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   if (arrive && lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0)
@@ -101,6 +126,7 @@ struct Win2 {
   W2B_LDS int *cslot;             // [maxc] slot of every context position; -1-k = k-th register-held row
   W2B_LDS int *uc_row;            // [2]   rows of the (at most two) context positions outside the radius
   W2B_LDS int *tgt, *prev, *cend; // [maxt]
+  W2B_LDS float *lossf;           // [maxt] dot products f of this step's targets, for the loss bookkeeping (per step buffer)
   W2B_LDS int *sen;               // [1000]
   W2B_LDS unsigned long long *ja, *jc;   // [nj] LCG jump-ahead table (copy of P.jump_a / P.jump_c)
   W2B_LDS Win2Lds *S;
@@ -117,7 +143,7 @@ __host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negati
   b += (size_t)(S + NH) * W2B_NDWMAX * 4;                          // csum
   b += 2 * W2B_RT * W2B_NDWMAX * 4;                                // red
   b += (size_t)(4 * w2_round4(S) + maxt + w2_round4(W2B_MAX_SEN)) * 4;               // slot tables, prev, sen
-  b += 2 * ((size_t)(6 * w2_round4(S + 2) + maxc + 4 + 2 * maxt) * 4 + sizeof(Step2));  // step lists x 2
+  b += 2 * ((size_t)(6 * w2_round4(S + 2) + maxc + 4 + 3 * maxt) * 4 + sizeof(Step2));  // step lists x 2
   b += sizeof(Win2Lds) + 16;
   b += (size_t)2 * 8 * (negative + 2 > 66 ? negative + 2 : 66) + 16;   // LCG jump tables
   return b;
@@ -138,7 +164,7 @@ __device__ __forceinline__ Win2 carve_win2(W2B_LDS int *base, int dim, int windo
   L.slot_gen = q; q += w2_round4(S);
   L.prev = q; q += maxt;
   L.sen = q; q += w2_round4(W2B_MAX_SEN);
-  const int per_buf = 6 * w2_round4(S + 2) + maxc + 4 + 2 * maxt + (int)(sizeof(Step2) / 4);
+  const int per_buf = 6 * w2_round4(S + 2) + maxc + 4 + 3 * maxt + (int)(sizeof(Step2) / 4);
   q += buf * per_buf;                                  // the per-step lists exist twice
   L.ret_slot = q; q += w2_round4(S + 2);
   L.ret_row = q; q += w2_round4(S + 2);
@@ -150,6 +176,7 @@ __device__ __forceinline__ Win2 carve_win2(W2B_LDS int *base, int dim, int windo
   L.uc_row = q; q += 4;
   L.tgt = q; q += maxt;
   L.cend = q; q += maxt;
+  L.lossf = (W2B_LDS float *)q; q += maxt;
   L.St = (W2B_LDS Step2 *)q; q += sizeof(Step2) / 4;
   q += (1 - buf) * per_buf;
   L.S = (W2B_LDS Win2Lds *)(((unsigned)(size_t)q + 15u) & ~15u);
@@ -317,7 +344,7 @@ __device__ __forceinline__ void hot_merge(const Rows<MM> &A, const Win2 &L, int 
 // AHEAD and hands the lists over through a double-buffered LDS record.  The data wavefronts never wait for
 // the scalar work of a step (it was 25-30 % of the step time when wavefront 0 did both).
 // Barrier discipline (worker_barrier): per step the data wavefronts meet once per target chunk (the cross-wavefront
-// sum of the dot products; with LOSS the producer waits there too, without arriving, to book the loss terms) and all
+// sum of the dot products; with s_barrier the producer has to execute those too, after its own work) and all
 // wavefronts of the worker meet once at the end of the step.
 // UC: the radius is window-1 (the two outermost context rows of a step are register-held).
 template <int QM, bool LOSS, int MM, bool UC>
@@ -357,13 +384,18 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
       S->eof = 0; S->done = 0; S->cw = 0; S->nt = 0; S->alpha = 0.f;
       L.S->clo = 0; L.S->chi = -1;
       L.S->bar_step = 0u; L.S->bar_chunk = 0u;
+      L.S->loss_reg = 0.0;
     }
   }
   __syncthreads();            // the only workgroup-wide barrier: every wavefront of both workers is still here
   if (!valid) return;
   W2B_LDS unsigned *const bar_step = &L.S->bar_step, *const bar_chunk = &L.S->bar_chunk;
   unsigned n_step = 0u, n_chunk = 0u;       // barriers passed so far (identical in every wavefront of the worker)
-  double loss_acc = 0.0;
+#ifdef W2B_PHASE_TIMERS
+  const bool timing_ = (wid == 0) && (wave == 0 || wave == NDW) && lane == 0;
+  unsigned long long tick_ = __builtin_readcyclecounter();
+#endif
+  double loss_acc = 0.0;     // producer wavefront only: log-sigmoid terms (the data wavefronts carry nothing around their loop)
   const int W = P.window, K = P.negative;
   // producer registers: the unigram-table gather and the alpha load of the NEXT step are issued at the end
   // of a preparation, so that their latency is not on the producer's critical path either
@@ -595,38 +627,39 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
     for (long long it = 0;; ++it) {
       const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
       const bool stop = I.St->stop != 0;
-      const int nck = I.St->nck;
-      if (!stop) prepare((it & 1) ? L0 : L1, it + 1 == max_positions);
-      for (int i = 0; i < nck; i++) {
-        ++n_chunk;
-        if (LOSS) {
-          worker_barrier(bar_chunk, (unsigned)NDW * n_chunk, lane, false);    // wait for the data wavefronts' sums
-          // The log-sigmoid bookkeeping of chunk i (ref :480-483) happens HERE, off the data wavefronts' registers
-          // (expf/logf cost them ~40 VGPRs): after the chunk's barrier its partial dot products sit in red[i & 1]
-          // until the data wavefronts have passed the end-of-step barrier, which waits for this wavefront (two
-          // chunks later at the earliest: red is double buffered).
-          const int cs = i ? I.cend[i - 1] : 0, n = I.cend[i] - cs;
-          if (lane < n) {
-            const W2B_LDS float *red = L.red + (i & 1) * (W2B_RT * W2B_NDWMAX);
-            float f = 0.f;
-            for (int w = 0; w < NDW; w++) f += red[lane * W2B_NDWMAX + w];
-            const float dp = (cs + lane == 0) ? f : -f;               // target 0 is the centre word (label 1)
-            float sg;
-            if (dp > 6.f) sg = 1.f;
-            else if (dp < -6.f) sg = 1e-9f;
-            else sg = 1.f / (1.f + expf(-dp));
-            loss_acc += (double)logf(sg);
-          }
+      W2B_TICK(1);
+      if (LOSS && it > 0) {
+        // The log-sigmoid bookkeeping (ref :480-483) of the PREVIOUS step happens here, off the data wavefronts'
+        // registers (expf/logf cost them ~40 VGPRs): wavefront 0 left the dot products f of that step's targets in the
+        // step buffer, which nobody writes again before this wavefront has passed the next end-of-step barrier.
+        const Win2 &Q = (it & 1) ? L0 : L1;               // the previous step's lists
+        const int ntp = Q.St->cw > 0 ? Q.St->nt : 0;
+        for (int i = lane; i < ntp; i += 64) {
+          const float f = Q.lossf[i];
+          const float dp = (i == 0) ? f : -f;                           // target 0 is the centre word (label 1)
+          float sg;
+          if (dp > 6.f) sg = 1.f;
+          else if (dp < -6.f) sg = 1e-9f;
+          else sg = 1.f / (1.f + expf(-dp));
+          loss_acc += (double)logf(sg);
         }
       }
+      W2B_TICK(2);
+      if (!stop) prepare((it & 1) ? L0 : L1, it + 1 == max_positions);
+      W2B_TICK(0);
+#if W2B_WPG == 1
+      for (int i = 0; i < I.St->nck; i++) __syncthreads();               // s_barrier counts every wavefront: the chunk barriers too
+#endif
       worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);   // lists of the next step are published; this step is done
-      if (stop) break;
+      if (stop) break;                                    // (a stop pass trains nothing: no loss terms are left over)
     }
   } else {
     worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);
     for (long long it = 0;; ++it) {
       const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
       const bool stop = I.St->stop != 0;
+      W2B_TICK(9);
+      W2B_COUNT(10);
       // ---------------- data phase.  cslot[j] >= 0: LDS slot; -1-k: register-held row k.
       const W2B_LDS int *const tgt = I.tgt, *const cend = I.cend, *const cslot = I.cslot;
       const bool word_step = !stop && I.St->cw > 0;
@@ -760,6 +793,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           deferred = false;
         }
         if (!word_step) break;
+        W2B_TICK(4);
 
         // ---- phase B (ref :450-492): the W2B_RT rows of this chunk are in registers
         const int n = end - start;
@@ -788,7 +822,9 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        W2B_TICK(5);
         worker_barrier(bar_chunk, (unsigned)NDW * ++n_chunk, lane);
+        W2B_TICK(6);
         float gl = 0.f;
         if (lane < n) {
           float f = 0.f;
@@ -798,7 +834,8 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           if (f > 6.f) g = (label - 1.f) * alpha;
           else if (f < -6.f) g = label * alpha;
           else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
-          gl = g;                      // (LOSS: the log-sigmoid term of this target is booked by the producer wavefront)
+          gl = g;
+          if (LOSS && wave == 0) I.lossf[start + lane] = f;     // the producer wavefront books log(sigmoid) next step
         }
         if (LOSS && P.reg != 0.f) {            // reg * sum q^2 over the chunk's target rows (ref :469,481), re-derived
           float s2 = 0.f;                      // from the rows in registers: one running sum, one reduction per chunk
@@ -814,7 +851,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
               }
             }
           s2 = wave_sum(active ? s2 : 0.f);
-          if (lane == 0) loss_acc -= (double)(P.reg * s2);
+          if (lane == 0) __hip_atomic_fetch_add(&L.S->loss_reg, -(double)(P.reg * s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         // error accumulation + row update, in target order (ref :486-491)
 #pragma unroll
@@ -837,6 +874,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
             }
           }
         }
+        W2B_TICK(7);
         start = end;
         if (start >= nt) break;
         end = cend[++chunk];
@@ -866,24 +904,21 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
         }
         if (LOSS && P.reg != 0.f) {
           const float s = wave_sum(regsq);
-          if (lane == 0) loss_acc -= (double)(P.reg * s);             // ref :437-445 (summed over the window)
+          if (lane == 0)                                              // ref :437-445 (summed over the window)
+            __hip_atomic_fetch_add(&L.S->loss_reg, -(double)(P.reg * s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
       if (NH > 0 && (stop || (it & (P.hot_period - 1)) == P.hot_period - 1)) hot_merge<MM>(A, L, NS, NH, dirty, lane, wave);
+      W2B_TICK(8);
       worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);   // lists of the next step are published; this step is done
       if (stop) break;
     }
   }
   const int sl = S->sen_len;
   for (int i = tid; i < sl; i += WPT) G->sen[i] = s_sen[i];
-  if (LOSS) {
-    // producer lanes hold the log-sigmoid terms, lane 0 of every data wavefront the regularisation terms
-    if (producer) {
-      const double lsum = wave_sum_d(loss_acc);
-      if (lane == 0) atomicAdd(&G->loss, lsum);
-    } else if (lane == 0 && loss_acc != 0.0) {
-      atomicAdd(&G->loss, loss_acc);
-    }
+  if (LOSS && producer) {       // producer lanes hold the log-sigmoid terms; the regularisation terms were summed in LDS
+    const double lsum = wave_sum_d(loss_acc);
+    if (lane == 0) atomicAdd(&G->loss, lsum + L.S->loss_reg);
   }
   if (tid == 0) {
     G->rng = S->rng; G->cursor = S->cursor; G->word_count = S->wc; G->last_word_count = S->last_wc;
