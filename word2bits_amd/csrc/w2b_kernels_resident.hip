@@ -113,7 +113,8 @@ struct Step2 {
   int next_row;           // row of the position that enters the window at the NEXT step (-1: unknown / none)
   int nck;                // number of target chunks = number of workgroup barriers inside the data phase
   float alpha;
-  int pad[3];
+  int cdup;               // 1: a window slot occurs more than once in this step's context list (phase C must run in order)
+  int pad[2];
 };
 
 
@@ -306,34 +307,47 @@ __device__ __forceinline__ void window_admit(const Rows<MM> &A, const Win2 &L, i
 // something write (a read-modify-write by a worker with nothing to publish could only overwrite a newer value).
 template <int MM>
 __device__ __forceinline__ void hot_merge(const Rows<MM> &A, const Win2 &L, int NS, int NH, unsigned &dirty, int lane, int wave) {
-  for (int k = 0; k < NH; k++) {
-    const int slot = NS + k;
-    Col4 g = col_zero();
-    if (A.active) g = A.ld_v(k + 1);
-    const unsigned now = wave_xor(A.active ? col_bits(g) : 0u);
-    if (!((dirty >> k) & 1u)) {                      // nothing of ours: adopt the current row
-      if (A.active) {
-        lds_st(L.win + slot * A.dim + A.col0, g);
-        A.st_entry(0, slot, g);
-      }
-      if (lane == 0) L.csum[slot * W2B_NDWMAX + wave] = now;
-      continue;
-    }
-    const bool untouched = (now == L.csum[slot * W2B_NDWMAX + wave]);
-    Col4 val = col_zero();
-    if (A.active) {
-      val = lds_ld(L.win + slot * A.dim + A.col0);
-      if (!untouched) {
-        const Col4 en = A.ld_entry(0, slot);
+  // four rows per trip: their current values and (for the rows this worker has touched) their entry rows are
+  // requested together -- one memory round trip per trip instead of up to two per row
+  for (int k0 = 0; k0 < NH; k0 += 4) {
+    Col4 g[4], en[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) val.e[e] = g.e[e] + (val.e[e] - en.e[e]);
-        lds_st(L.win + slot * A.dim + A.col0, val);
+    for (int j = 0; j < 4; j++) {
+      g[j] = col_zero(); en[j] = col_zero();
+      if (A.active && k0 + j < NH) {
+        g[j] = A.ld_v(k0 + j + 1);
+        if ((dirty >> (k0 + j)) & 1u) en[j] = A.ld_entry(0, NS + k0 + j);
       }
-      A.st_v(k + 1, val);
-      A.st_entry(0, slot, val);
     }
-    const unsigned cs = wave_xor(A.active ? col_bits(val) : 0u);
-    if (lane == 0) L.csum[slot * W2B_NDWMAX + wave] = cs;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = k0 + j, slot = NS + k;
+      if (k < NH) {
+        const unsigned now = wave_xor(A.active ? col_bits(g[j]) : 0u);
+        if (!((dirty >> k) & 1u)) {                      // nothing of ours: adopt the current row
+          if (A.active) {
+            lds_st(L.win + slot * A.dim + A.col0, g[j]);
+            A.st_entry(0, slot, g[j]);
+          }
+          if (lane == 0) L.csum[slot * W2B_NDWMAX + wave] = now;
+        } else {
+          const bool untouched = (now == L.csum[slot * W2B_NDWMAX + wave]);
+          Col4 val = col_zero();
+          if (A.active) {
+            val = lds_ld(L.win + slot * A.dim + A.col0);
+            if (!untouched) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) val.e[e] = g[j].e[e] + (val.e[e] - en[j].e[e]);
+              lds_st(L.win + slot * A.dim + A.col0, val);
+            }
+            A.st_v(k + 1, val);
+            A.st_entry(0, slot, val);
+          }
+          const unsigned cs = wave_xor(A.active ? col_bits(val) : 0u);
+          if (lane == 0) L.csum[slot * W2B_NDWMAX + wave] = cs;
+        }
+      }
+    }
   }
   dirty = 0u;
 }
@@ -427,7 +441,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
       unsigned long long rng = S->rng;
       long long cursor = S->cursor, wc = S->wc, last_wc = S->last_wc;
       int sen_len = S->sen_len, sen_pos = S->sen_pos, ovr = S->override_, eof = S->eof;
-      int done = 0, cw = 0, nt = 0, uc_n = 0, nck = 0, next_row = -1;
+      int done = 0, cw = 0, nt = 0, uc_n = 0, nck = 0, next_row = -1, cdup = 0;
       float alpha = 0.f, alpha_own = 0.f;
       bool new_sentence = false, alpha_set = false;
       int lo = 0, hi = -1;                               // window wanted for this step (empty = flush)
@@ -564,6 +578,20 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           }
           W2B_WAVE_SYNC();
         }
+        if (cw > 0) {
+          // does a slot occur twice in the context list (a word at two window positions)?  Then phase C has to apply
+          // its updates strictly in order; otherwise it may keep several LDS rows in flight.
+          int dupf = 0;
+          for (int j0 = 0; j0 < cw; j0 += 64) {
+            const int mine = (j0 + lane < cw) ? O.cslot[j0 + lane] : -100 - lane;
+            for (int j = 0; j < min(64, cw - j0); j++) {
+              const int sj = __builtin_amdgcn_readlane(mine, j);
+              dupf |= (__ballot(lane > j && mine == sj) != 0ull) ? 1 : 0;
+            }
+            if (cw > 64) dupf = 1;                   // (window > 32: not worth a second pass)
+          }
+          cdup = dupf;
+        }
         if (cw > 0) {                                                    // ref :450-460
           int cnt = 0;
           for (int d0 = 1; d0 <= K; d0 += 64) {
@@ -613,6 +641,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
         O.St->stop = (done || last) ? 1 : 0; O.St->cw = cw; O.St->nt = nt; O.St->uc_n = uc_n;
         O.St->n_ret = n_ret; O.St->n_adm = n_adm; O.St->next_row = next_row; O.St->nck = (cw > 0) ? nck : 0;
         O.St->alpha = alpha;
+        O.St->cdup = cdup;
         if (done) S->done = 1;
       }
   };
@@ -765,21 +794,28 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
             if (UC && active && uc_n > 1) ur1 = A.ld_u(I.uc_row[1]);
             // ---- phase A from LDS (ref :431-449), window order
             if (active) {
-              for (int j = 0; j < cw; j++) {
-                const int s = cslot[j];
-                Col4 r;
-                if (!UC || s >= 0) {
-                  r = lds_ld(L.win + s * dim + col0);
-                } else {
+              for (int j0 = 0; j0 < cw; j0 += 4) {          // four rows requested together, summed in window order
+                Col4 r[4];
 #pragma unroll
-                  for (int e = 0; e < 4; e++) r.e[e] = (s == -1) ? ur0.e[e] : ur1.e[e];
+                for (int k = 0; k < 4; k++) {
+                  const int s = cslot[min(j0 + k, cw - 1)];
+                  if (!UC || s >= 0) {
+                    r[k] = lds_ld(L.win + s * dim + col0);
+                  } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) r[k].e[e] = (s == -1) ? ur0.e[e] : ur1.e[e];
+                  }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                  const float q = quant<QM>(r.e[e], qp);
-                  avg.e[e] += q;
-                  if (LOSS) regsq += q * q;
-                }
+                for (int k = 0; k < 4; k++)
+                  if (j0 + k < cw) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                      const float q = quant<QM>(r[k].e[e], qp);
+                      avg.e[e] += q;
+                      if (LOSS) regsq += q * q;
+                    }
+                  }
               }
               const float cwf = (float)cw;
 #pragma unroll
@@ -822,6 +858,12 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        // The row prefetched for the next step's admit has arrived by now (memory returns in order and the target
+        // rows were requested later).  Saying so here -- an empty asm that "redefines" it -- keeps the wait for it out
+        // of the next step's window exchange, where it would be a wait for every load issued in between: that
+        // step's whole chunk of target rows, before phase A instead of after it.
+#pragma unroll
+        for (int e = 0; e < 4; e++) asm volatile("" : "+v"(apre.e[e]));
         W2B_TICK(5);
         worker_barrier(bar_chunk, (unsigned)NDW * ++n_chunk, lane);
         W2B_TICK(6);
@@ -883,7 +925,21 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
 
       if (word_step) {
         // ---- phase C on the resident rows (ref :494-503), window order; duplicates hit the same slot twice
-        if (active) {
+        if (active && !UC && !I.St->cdup) {
+          // no slot twice: the read-modify-writes are independent, four rows in flight
+          for (int j0 = 0; j0 < cw; j0 += 4) {
+            Col4 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = lds_ld(L.win + cslot[min(j0 + k, cw - 1)] * dim + col0);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if (j0 + k < cw) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) w[k].e[e] = w[k].e[e] + (err.e[e] - ar2 * w[k].e[e]);
+                lds_st(L.win + cslot[j0 + k] * dim + col0, w[k]);
+              }
+          }
+        } else if (active) {
           for (int j = 0; j < cw; j++) {
             const int s = cslot[j];
             if (!UC || s >= 0) {

@@ -177,7 +177,7 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.exact = t->cfg.exact_reduction != 0;
   if (p.exact) p.mem_mode = 0;             // the exact mode exists for coherent rows only
   p.entry = t->entry;
-  p.hot_period = 32;
+  p.hot_period = 8;                 // steps between two merges of a worker's private hot rows (W2B_HOT_PERIOD overrides)
   if (const char *e = getenv("W2B_HOT_PERIOD")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4096 && (v & (v - 1)) == 0) p.hot_period = v;
@@ -382,13 +382,15 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
     // How often is row i of v a target (ref :450-460)?  Per centre word: negative * cn_i^0.75 / sum cn^0.75 (the
     // unigram table) + cn_i / train_words (as the centre word itself).  The vocabulary is sorted by count, so the
     // rows worth a private on-chip copy in the sentence-resident kernel are a prefix 1..hot_wanted: those that are
-    // a target of at least one centre word in 25 (a coherent row sustains ~7 M read-modify-writes per second).
+    // a target of at least one centre word in 10 (a coherent row sustains ~7 M read-modify-writes per second; at
+    // 25 M words/s that is where its line starts to queue), at most four.  Privatising a row trades freshness for
+    // speed (the first-epoch loss moves with rows x merge period), hence the short list.
     double pw = 0, tot = 0;
     for (int64_t a = 0; a < V; a++) { pw += pow((double)cn[a], 0.75); tot += (double)cn[a]; }
     int n = 0;
-    for (int64_t a = 1; a < V && a <= 8; a++) {
+    for (int64_t a = 1; a < V && a <= 4; a++) {
       const double rate = (pw > 0 ? t->cfg.negative * pow((double)cn[a], 0.75) / pw : 0) + (tot > 0 ? cn[a] / tot : 0);
-      if (rate < 0.04) break;
+      if (rate < 0.1) break;
       n++;
     }
     t->hot_wanted = n;
