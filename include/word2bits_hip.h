@@ -136,6 +136,13 @@ int w2b_train_step(w2b_trainer *t, int64_t max_positions);
 int w2b_epoch_status(w2b_trainer *t, int32_t *finished, int64_t *word_count_actual, float *alpha,
                      double *loss_sum);
 
+/* Non-blocking form of w2b_epoch_status: the state after the launch `lag` launches before the latest one (lag 0..3;
+ * waits only for THAT launch, so with lag = 1 the next launch is already running while the host looks at the previous
+ * one -- an epoch is then noticed to be finished one launch late, and that extra launch returns at once).  loss_sum is
+ * the epoch's loss accumulated on the device (atomic adds: same terms as w2b_epoch_status, summed in a different order). */
+int w2b_epoch_poll(w2b_trainer *t, int32_t lag, int32_t *finished, int64_t *word_count_actual, float *alpha,
+                   double *loss_sum);
+
 /* Number of Hogwild workers (-threads) that exactly fills this GPU for the configured shape: the workgroups
  * of the worker kernel that are resident at once (more workers run in rounds; fewer leave CUs idle) -- but, when
  * cfg.train_words is known, never more than train_words / 20000: a worker re-computes alpha only after >10000 of

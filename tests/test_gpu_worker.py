@@ -216,3 +216,37 @@ def test_sentence_resident_kernel_equals_plain_kernel_many_workers(gpu, threads,
         assert r.returncode == 0, r.stderr[-300:]
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("window_cache", [True, False])
+def test_epoch_poll_one_launch_behind(gpu, window_cache):
+    """w2b_epoch_poll(lag=1): the host looks at the launch before the latest one without waiting for the latest -- the
+    loop ./word2bits runs.  The epoch is seen finished one launch late, the counters are the blocking call's, the
+    device-accumulated loss equals the per-worker sum up to the order of the additions."""
+    V, n, D = 200, 30000, 64
+    rng = np.random.default_rng(3)
+    ids = token_stream(rng, V, n)
+    cn = counts_of(ids, V)
+    t = w2b.Trainer(V, D, 5, 5, 1, num_threads=6, iter=1, sample=1e-3, train_words=int(cn.sum()), window_cache=window_cache)
+    t.init_net()
+    t.set_vocab_counts(cn, 50000)
+    t.set_corpus(ids)
+    t.set_shards(np.arange(6, dtype=np.int64) * (n // 6))
+    for epoch in range(2):
+        t.epoch_begin()
+        assert t.epoch_poll(1) == (False, 0, pytest.approx(0.05), 0.0)        # nothing launched yet
+        launches, seen_wca = 0, -1
+        while True:
+            t.train_step(400)
+            launches += 1
+            fin, wca, alpha, loss = t.epoch_poll(1)
+            assert wca >= seen_wca
+            seen_wca = wca
+            if fin:
+                break
+            assert launches < 200
+        fin0, wca0, alpha0, loss0 = t.epoch_poll(0)
+        fin2, wca2, alpha2, loss2 = t.epoch_status()
+        assert fin0 and fin2 and wca0 == wca2 == wca and alpha0 == alpha2
+        assert loss0 == pytest.approx(loss2, rel=1e-9) and loss == pytest.approx(loss2, rel=1e-9) and loss2 < 0
+    t.close()

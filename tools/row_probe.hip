@@ -149,6 +149,9 @@ int main() {
     ROW(1, 16, 16, 24, 1, "paired16 sc1+sc1");
     ROW(0, 16, 16, 12, 4, "8B/lane sc1+sc1");
     ROW(1, 16, 16, 12, 4, "paired16 sc1+sc1");
+    ROW(2, 16, 16, 24, 1, "16B/lane sc1+sc1");          // one workgroup per CU, a whole word's rows per batch
+    ROW(2, 16, 16, 12, 1, "16B/lane sc1+sc1");
+    ROW(2, 16, 16, 24, 2, "16B/lane sc1+sc1");
   }
   return 0;
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "w2b_epoch_begin": (C.c_int, [vp]),
     "w2b_train_step": (C.c_int, [vp, C.c_int64]),
     "w2b_epoch_status": (C.c_int, [vp, i32p, i64p, f32p, f64p]),
+    "w2b_epoch_poll": (C.c_int, [vp, C.c_int32, i32p, i64p, f32p, f64p]),
     "w2b_suggested_threads": (C.c_int, [vp, i32p]),
     "w2b_worker_kernel_info": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p]),
     "w2b_train_tuples": (C.c_int, [vp, C.c_int64, i32p, i32p, i32p, i32p, C.c_float, C.c_int32, f64p]),

@@ -974,7 +974,10 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
   for (int i = tid; i < sl; i += WPT) G->sen[i] = s_sen[i];
   if (LOSS && producer) {       // producer lanes hold the log-sigmoid terms; the regularisation terms were summed in LDS
     const double lsum = wave_sum_d(loss_acc);
-    if (lane == 0) atomicAdd(&G->loss, lsum + L.S->loss_reg);
+    if (lane == 0) {
+      atomicAdd(&G->loss, lsum + L.S->loss_reg);
+      atomicAdd(&P.shared->loss_epoch, lsum + L.S->loss_reg);       // what w2b_epoch_poll reports without a per-worker copy
+    }
   }
   if (tid == 0) {
     G->rng = S->rng; G->cursor = S->cursor; G->word_count = S->wc; G->last_word_count = S->last_wc;

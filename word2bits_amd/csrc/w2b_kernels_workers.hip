@@ -118,12 +118,12 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
   if (LOSS) {
     // wave 0 holds the log-sigmoid terms on its lanes; lane 0 of every wave holds reg terms
     if (wave == 0) lsum = wave_sum_d(loss_acc);
-    else if (lane == 0 && loss_acc != 0.0) atomicAdd(&G->loss, loss_acc);
+    else if (lane == 0 && loss_acc != 0.0) { atomicAdd(&G->loss, loss_acc); atomicAdd(&P.shared->loss_epoch, loss_acc); }
   }
   if (tid == 0) {
     G->rng = S->rng; G->cursor = S->cursor; G->word_count = S->wc; G->last_word_count = S->last_wc;
     G->sen_len = S->sen_len; G->sen_pos = S->sen_pos; G->first_override = S->override_;
-    if (LOSS) atomicAdd(&G->loss, lsum);
+    if (LOSS) { atomicAdd(&G->loss, lsum); atomicAdd(&P.shared->loss_epoch, lsum); }
     if (S->done) { G->done = 1; atomicAdd(&P.shared->workers_done, 1); }
   }
 }

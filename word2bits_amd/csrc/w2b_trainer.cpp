@@ -67,6 +67,11 @@ struct w2b_trainer {
   // RCCL
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
+  // non-blocking progress: after every launch the shared block is copied into a pinned ring slot behind an event
+  static const int kPoll = 4;
+  W2bShared *poll_host = nullptr;          // pinned [kPoll]
+  hipEvent_t poll_ev[kPoll] = {nullptr, nullptr, nullptr, nullptr};
+  long long launches = 0;                  // w2b_train_step calls since w2b_epoch_begin
   unsigned long long *wca_buf = nullptr;   // [2]: this replica's word_count_actual, the sum over all replicas
   hipEvent_t sync_a = nullptr, sync_b = nullptr;
   double sync_ms = 0;                       // device time of the replica exchanges since the last w2b_sync_stats
@@ -269,6 +274,8 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   if (t->comm) ncclCommDestroy(t->comm);
   for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : t->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : t->poll_ev) if (e) (void)hipEventDestroy(e);
+  if (t->poll_host) (void)hipHostFree(t->poll_host);
   if (t->sync_a) (void)hipEventDestroy(t->sync_a);
   if (t->sync_b) (void)hipEventDestroy(t->sync_b);
   void *ptrs[] = {t->uv, t->base, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->corpus_owned, t->workers, t->shared,
@@ -523,7 +530,10 @@ extern "C" int w2b_epoch_begin(w2b_trainer *t) {
   HIPCHK(hipStreamSynchronize(t->stream));
   HIPCHK(hipMemcpy(t->workers, w.data(), sizeof(W2bWorker) * nw, hipMemcpyHostToDevice));
   int zero = 0;
+  double dzero = 0;
   HIPCHK(hipMemcpy(&t->shared->workers_done, &zero, sizeof zero, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(&t->shared->loss_epoch, &dzero, sizeof dzero, hipMemcpyHostToDevice));
+  t->launches = 0;
   return W2B_OK;
 }
 
@@ -606,6 +616,37 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, hot, t->cfg.compute_loss != 0, t->stream));
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));
+  {   // progress snapshot of this launch for w2b_epoch_poll (asynchronous; pinned host memory)
+    if (!t->poll_host) {
+      HIPCHK(hipHostMalloc((void **)&t->poll_host, sizeof(W2bShared) * w2b_trainer::kPoll, hipHostMallocDefault));
+      for (int i = 0; i < w2b_trainer::kPoll; i++) HIPCHK(hipEventCreateWithFlags(&t->poll_ev[i], hipEventDisableTiming));
+    }
+    const int slot = (int)(t->launches % w2b_trainer::kPoll);
+    HIPCHK(hipMemcpyAsync(&t->poll_host[slot], t->shared, sizeof(W2bShared), hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipEventRecord(t->poll_ev[slot], t->stream));
+    t->launches++;
+  }
+  return W2B_OK;
+}
+
+extern "C" int w2b_epoch_poll(w2b_trainer *t, int32_t lag, int32_t *finished, int64_t *wca, float *alpha,
+                              double *loss_sum) {
+  NEED(t);
+  if (lag < 0 || lag >= w2b_trainer::kPoll) return fail(W2B_EINVAL, "w2b_epoch_poll: lag must be 0..3");
+  if (t->launches - lag <= 0) {              // nothing launched that far back yet
+    if (finished) *finished = 0;
+    if (wca) *wca = 0;
+    if (alpha) *alpha = t->cfg.alpha;
+    if (loss_sum) *loss_sum = 0;
+    return W2B_OK;
+  }
+  const int slot = (int)((t->launches - 1 - lag) % w2b_trainer::kPoll);
+  HIPCHK(hipEventSynchronize(t->poll_ev[slot]));
+  const W2bShared &sh = t->poll_host[slot];
+  if (finished) *finished = (sh.workers_done >= t->cfg.num_threads) ? 1 : 0;
+  if (wca) *wca = (int64_t)sh.word_count_actual;
+  if (alpha) *alpha = sh.alpha;
+  if (loss_sum) *loss_sum = sh.loss_epoch;
   return W2B_OK;
 }
 

@@ -226,6 +226,10 @@ int main(int argc, char **argv) {
     double last_loss = 0, epoch_loss = 0;
     bool finished = false;
     long long launches = 0;
+    // One replica: the host stays one launch behind the device (w2b_epoch_poll with lag 1 waits for the previous launch
+    // only, the next one is already queued; the launch after the last one finds every worker done and returns at once).
+    // Replicas: the exchange is a rendezvous of all GPUs anyway, the state is read right after each launch (lag 0).
+    const int lag = (o.gpus == 1) ? 1 : 0;
     while (!finished) {
       for (auto &r : reps) CK(w2b_train_step(r.t, o.positions));
       finished = true;
@@ -237,7 +241,7 @@ int main(int argc, char **argv) {
         int64_t w = 0;
         float a = 0;
         double l = 0;
-        CK(w2b_epoch_status(r.t, &fin, &w, &a, &l));
+        CK(w2b_epoch_poll(r.t, lag, &fin, &w, &a, &l));
         finished = finished && fin;
         wca += w;
         alpha = a;
@@ -259,6 +263,13 @@ int main(int argc, char **argv) {
         fflush(stdout);
         last_loss = epoch_loss;
       }
+    }
+    epoch_loss = 0;                                           // the epoch is over: the workers' totals, in worker order (ref :537-538)
+    for (auto &r : reps) {
+      int32_t fin = 0;
+      double l = 0;
+      CK(w2b_epoch_status(r.t, &fin, nullptr, nullptr, &l));
+      epoch_loss += l;
     }
     printf("Epoch Loss: %lf\n", epoch_loss);                  // ref :539
     if (o.save_every_epoch && o.classes == 0) {               // ref :540-542 (the per-epoch file only when classes == 0)

@@ -183,6 +183,12 @@ class Trainer:
                                      C.byref(loss) if want_loss else None))
         return bool(fin.value), wca.value, alpha.value, loss.value
 
+    def epoch_poll(self, lag=1):
+        """state after the launch `lag` launches before the latest one, without waiting for the newer ones"""
+        fin, wca, alpha, loss = C.c_int32(0), C.c_int64(0), C.c_float(0), C.c_double(0)
+        check(lib().w2b_epoch_poll(self._h, int(lag), C.byref(fin), C.byref(wca), C.byref(alpha), C.byref(loss)))
+        return bool(fin.value), wca.value, alpha.value, loss.value
+
     def train_epoch(self, positions_per_launch=4096):
         """pthread_create + pthread_join of one epoch (ref :535-536). Returns the epoch loss."""
         self.epoch_begin()
