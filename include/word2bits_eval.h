@@ -36,6 +36,14 @@ int w2b_eval_load(const char *file, int32_t bitlevel, int64_t threshold, int32_t
                   w2b_eval **out);
 void w2b_eval_free(w2b_eval *e);
 
+/* The evaluator on a live trainer (include/word2bits_hip.h), without the file round trip: exactly what
+ * w2b_eval_load(file, bitlevel, threshold, ...) would hold after the trainer's vectors had been written to `file` in
+ * the binary format (quantize(u+v) with the trainer's bitlevel, ref src/word2bits.cpp:565-574) -- the values stay
+ * on the device, `words[i]` is the vocabulary word of row i (w2b_corpus_word), n_words = vocab_size. */
+struct w2b_trainer;
+int w2b_eval_from_trainer(struct w2b_trainer *t, int64_t n_words, const char *const *words, int32_t bitlevel,
+                          int64_t threshold, int32_t fused, w2b_eval **out);
+
 int64_t w2b_eval_words(const w2b_eval *e);                  /* `words` after the threshold, ref :85-86 */
 int64_t w2b_eval_size(const w2b_eval *e);                   /* `size`, ref :87 */
 const char *w2b_eval_word(const w2b_eval *e, int64_t row);  /* &vocab[row * max_w], ref :99-104 */

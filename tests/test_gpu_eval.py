@@ -236,3 +236,42 @@ def test_vector_file_reader_fuzz(gpu, tmp_path_factory):
             ev.close()
 
     run()
+
+
+@pytest.mark.parametrize("bitlevel,ev_bitlevel,threshold,fused", [(1, 0, 0, True), (2, 0, 0, False), (0, 2, 37, True)])
+def test_evaluator_on_live_trainer_equals_file_round_trip(gpu, bitlevel, ev_bitlevel, threshold, fused, tmp_path):
+    """w2b_eval_from_trainer (no file): names through the same reader logic (a 57-character word, a word with bytes >=
+    0x80), quantize(u+v) exported on the device, the evaluator's own quantize / threshold / normalisation -- everything
+    bit-identical to saving the vectors and loading the file."""
+    rng = np.random.default_rng(bitlevel * 7 + threshold)
+    V, D = 90, 44
+    words = ["</s>"] + ["w%d" % i for i in range(1, V)]
+    words[5] = "x" * 57
+    words[6] = "caf\xe9"
+    words[40] = "Mixed_Case"
+    corpus = str(tmp_path / "c.txt")
+    toks = rng.integers(1, V, 6000)
+    with open(corpus, "wb") as f:
+        for i in range(0, len(toks), 20):
+            f.write(" ".join(words[t] for t in toks[i:i + 20]).encode("latin1") + b"\n")
+    c = w2b.Corpus(corpus, 1)
+    t = w2b.Trainer(c.vocab_size, D, 5, 5, bitlevel, num_threads=4, iter=1, sample=0.0, train_words=c.train_words)
+    t.init_net()
+    t.set_vocab_counts(c.counts(), 100000)
+    t.set_corpus(c.tokens())
+    starts, ov = c.shards(4)
+    t.set_shards(starts, ov)
+    t.train_epoch(500)
+    path = str(tmp_path / "v.bin")
+    c.save_vectors(path, t.export_quantized(), 1)
+    a = w2b.Evaluator(path, ev_bitlevel, threshold, fused=fused)
+    b = w2b.Evaluator.from_trainer(t, c.words(), ev_bitlevel, threshold, fused=fused)
+    try:
+        assert (a.words, a.size) == (b.words, b.size)
+        assert [a.word(i) for i in range(a.words)] == [b.word(i) for i in range(b.words)]
+        assert same_floats(a.matrix(), b.matrix())
+        qs = (": s\n" + "".join("%s %s %s %s\n" % tuple(c.words()[j] for j in rng.integers(1, c.vocab_size, 4))
+                                for _ in range(300))).encode("latin1")
+        assert a.transcript(qs) == b.transcript(qs)
+    finally:
+        a.close(); b.close(); t.close(); c.close()

@@ -90,6 +90,7 @@ SIGNATURES = {
     # include/word2bits_eval.h
     "w2b_eval_load": (C.c_int, [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "w2b_eval_free": (None, [vp]),
+    "w2b_eval_from_trainer": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_char_p), C.c_int32, C.c_int64, C.c_int32, C.POINTER(vp)]),
     "w2b_eval_words": (C.c_int64, [vp]),
     "w2b_eval_size": (C.c_int64, [vp]),
     "w2b_eval_word": (C.c_char_p, [vp, C.c_int64]),

@@ -71,6 +71,66 @@ static bool scan_ll(const std::vector<unsigned char> &d, size_t &pos, long long 
   return true;
 }
 
+// One row's name as the reference's reader leaves it (ref :97-105): bytes up to the first ' ', '\n' bytes dropped, at
+// most max_w characters kept (the rest lands on index max_w = the next row's first byte, overwritten by that row
+// later), a terminating 0, then upper-cased.  Consumes from d[pos...].
+static void read_name(const unsigned char *d, size_t n, size_t &pos, char *row) {
+  long long a = 0;
+  for (;;) {
+    const bool at_end = pos >= n;
+    const unsigned char ch = at_end ? 0xFF : d[pos];              // (char)EOF
+    if (!at_end) pos++;
+    row[a] = (char)ch;
+    if (at_end || ch == ' ') break;
+    if (a < kMaxW && ch != '\n') a++;
+  }
+  row[a] = 0;
+  for (long long i = 0; i < kMaxW; i++) row[i] = c_upper(row[i]);
+}
+
+// common tail of the two constructors: device buffers, quantize(x, bitlevel) + normalisation of the rows (ref :106-110).
+// `host_rows` ([words][size], may be null) or `dev_rows` ([words][size] on the device, may be null) hold the raw values.
+static int eval_finish(w2b_eval *e, int32_t bitlevel, const float *host_rows, const float *dev_rows, w2b_eval **out) {
+  const long long words = e->words, size = e->size;
+  char *vocab = e->vocab.data();
+  for (long long b = 0; b < words; b++) e->first.emplace(std::string(vocab + b * kMaxW), b);   // first wins
+  auto bail = [&](int rc) { eval_release(e); return rc; };
+  if (hipSetDevice(e->device) != hipSuccess) return bail(efail(W2B_EHIP, "hipSetDevice failed"));
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(efail(W2B_EHIP, "hipStreamCreate failed"));
+  const size_t mbytes = (size_t)e->rows_padded * e->ld * 4;
+  float *len = nullptr;
+  if (hipMalloc(&e->M, mbytes) != hipSuccess || hipMalloc(&len, (size_t)(words + 1) * 4) != hipSuccess)
+    return bail(efail(W2B_ENOMEM, "w2b_eval: device allocation failed"));
+  hipError_t he = hipMemsetAsync(e->M, 0, mbytes, e->stream);
+  if (he == hipSuccess && words > 0 && host_rows)
+    he = hipMemcpy2DAsync(e->M, (size_t)e->ld * 4, host_rows, (size_t)size * 4, (size_t)size * 4, (size_t)words,
+                          hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess && words > 0 && dev_rows)
+    he = hipMemcpy2DAsync(e->M, (size_t)e->ld * 4, dev_rows, (size_t)size * 4, (size_t)size * 4, (size_t)words,
+                          hipMemcpyDeviceToDevice, e->stream);
+  if (he == hipSuccess) he = w2b_launch_eval_normalize(e->M, words, size, e->ld, bitlevel, e->fused, len, e->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+  (void)hipFree(len);
+  if (he != hipSuccess) return bail(efail(W2B_EHIP, std::string("w2b_eval: ") + hipGetErrorString(he)));
+  *out = e;
+  return W2B_OK;
+}
+
+static w2b_eval *eval_new(long long words, long long size, int32_t fused, int32_t device) {
+  w2b_eval *e = new w2b_eval;
+  e->device = device;
+  e->words = words;
+  e->size = size;
+  e->fused = fused ? 1 : 0;
+  if (const char *env = getenv("W2B_EVAL_KERNEL")) e->variant = atoi(env);   // 0 vector ALU; 1 MFMA (default grouping); >1 MFMA with that many question tiles per row tile
+  e->ld = (size + 15) / 16 * 16;
+  e->rows_padded = (words + kTile - 1) / kTile * kTile;
+  if (e->rows_padded == 0) e->rows_padded = kTile;
+  e->vocab.assign((size_t)(words * kMaxW + kMaxW + 2), 0);
+  return e;
+}
+
 extern "C" int w2b_eval_load(const char *file, int32_t bitlevel, int64_t threshold, int32_t fused, int32_t device,
                              w2b_eval **out) {
   if (!file || !out) return efail(W2B_EINVAL, "w2b_eval_load: null argument");
@@ -101,31 +161,11 @@ extern "C" int w2b_eval_load(const char *file, int32_t bitlevel, int64_t thresho
     return efail(W2B_ENOGPU, "w2b_eval_load: no HIP device visible (the evaluator has no CPU fallback)");
   if (device < 0 || device >= ndev) return efail(W2B_EINVAL, "w2b_eval_load: bad device index");
 
-  w2b_eval *e = new w2b_eval;
-  e->device = device;
-  e->words = words;
-  e->size = size;
-  e->fused = fused ? 1 : 0;
-  if (const char *env = getenv("W2B_EVAL_KERNEL")) e->variant = atoi(env);   // 0 vector ALU; 1 MFMA (default grouping); >1 MFMA with that many question tiles per row tile
-  e->ld = (size + 15) / 16 * 16;
-  e->rows_padded = (words + kTile - 1) / kTile * kTile;
-  if (e->rows_padded == 0) e->rows_padded = kTile;
-  e->vocab.assign((size_t)(words * kMaxW + kMaxW + 2), 0);
+  w2b_eval *e = eval_new(words, size, fused, device);
   std::vector<float> raw((size_t)(words * size), 0.f);
   char *vocab = e->vocab.data();
   for (long long b = 0; b < words; b++) {                           // ref :96-105
-    long long a = 0;
-    char *row = vocab + b * kMaxW;
-    for (;;) {
-      const bool at_end = pos >= d.size();
-      const unsigned char ch = at_end ? 0xFF : d[pos];              // (char)EOF
-      if (!at_end) pos++;
-      row[a] = (char)ch;
-      if (at_end || ch == ' ') break;
-      if (a < kMaxW && ch != '\n') a++;
-    }
-    row[a] = 0;
-    for (long long i = 0; i < kMaxW; i++) row[i] = c_upper(row[i]);
+    read_name(d.data(), d.size(), pos, vocab + b * kMaxW);
     const size_t want = (size_t)size * 4, have = d.size() - pos;
     const size_t take = (want < have ? want : have) / 4 * 4;
     memcpy(raw.data() + b * size, d.data() + pos, take);
@@ -133,26 +173,51 @@ extern "C" int w2b_eval_load(const char *file, int32_t bitlevel, int64_t thresho
   }
   d.clear();
   d.shrink_to_fit();
-  for (long long b = 0; b < words; b++) e->first.emplace(std::string(vocab + b * kMaxW), b);   // first wins
+  return eval_finish(e, bitlevel, raw.data(), nullptr, out);
+}
 
-  auto bail = [&](int rc) { eval_release(e); return rc; };
-  if (hipSetDevice(device) != hipSuccess) return bail(efail(W2B_EHIP, "hipSetDevice failed"));
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
-    return bail(efail(W2B_EHIP, "hipStreamCreate failed"));
-  const size_t mbytes = (size_t)e->rows_padded * e->ld * 4;
-  float *len = nullptr;
-  if (hipMalloc(&e->M, mbytes) != hipSuccess || hipMalloc(&len, (size_t)(words + 1) * 4) != hipSuccess)
-    return bail(efail(W2B_ENOMEM, "w2b_eval_load: device allocation failed"));
-  hipError_t he = hipMemsetAsync(e->M, 0, mbytes, e->stream);
-  if (he == hipSuccess && words > 0)
-    he = hipMemcpy2DAsync(e->M, (size_t)e->ld * 4, raw.data(), (size_t)size * 4, (size_t)size * 4, (size_t)words,
-                          hipMemcpyHostToDevice, e->stream);
-  if (he == hipSuccess) he = w2b_launch_eval_normalize(e->M, words, size, e->ld, bitlevel, e->fused, len, e->stream);
-  if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-  (void)hipFree(len);
-  if (he != hipSuccess) return bail(efail(W2B_EHIP, std::string("w2b_eval_load: ") + hipGetErrorString(he)));
-  *out = e;
-  return W2B_OK;
+// The evaluator on a LIVE trainer: what `compute_accuracy <file> <bitlevel> <threshold>` would load after
+// `./word2bits -binary 1` had written <file> from this trainer -- without the file: quantize(u+v) (ref src/word2bits.cpp
+// :568-569) is exported on the device straight into the evaluator's matrix, the names go through the same reader
+// logic as a file's would (each row of a binary file is "word" + ' ' + floats + '\n', ref :565-574).
+extern "C" int w2b_eval_from_trainer(w2b_trainer *t, int64_t n_words, const char *const *words_in, int32_t bitlevel,
+                                     int64_t threshold, int32_t fused, w2b_eval **out) {
+  if (!t || !out || (n_words > 0 && !words_in)) return efail(W2B_EINVAL, "w2b_eval_from_trainer: null argument");
+  *out = nullptr;
+  float *u = nullptr, *v = nullptr;
+  long long V = 0, D = 0;
+  int tb = 0, dev = 0;
+  hipStream_t ts = nullptr;
+  w2b_internal_trainer_view(t, &u, &v, &V, &D, &tb, &dev, &ts);
+  if (n_words != V) return efail(W2B_EINVAL, "w2b_eval_from_trainer: one word per vocabulary row is needed");
+  long long words = V;
+  if (threshold && words > threshold) words = threshold;            // ref :86
+  w2b_eval *e = eval_new(words, D, fused, dev);
+  char *vocab = e->vocab.data();
+  std::string rowbytes;
+  for (long long b = 0; b < words; b++) {
+    rowbytes.assign("\n");                                          // what the previous row (or the header) left behind
+    rowbytes += words_in[b];
+    rowbytes += ' ';
+    size_t pos = 0;
+    read_name((const unsigned char *)rowbytes.data(), rowbytes.size(), pos, vocab + b * kMaxW);
+  }
+  if (hipSetDevice(dev) != hipSuccess) { eval_release(e); return efail(W2B_EHIP, "hipSetDevice failed"); }
+  float *q = nullptr;
+  if (hipMalloc(&q, sizeof(float) * (size_t)(words > 0 ? words : 1) * D) != hipSuccess) {
+    eval_release(e);
+    return efail(W2B_ENOMEM, "w2b_eval_from_trainer: device allocation failed");
+  }
+  hipError_t he = w2b_launch_export(u, v, q, words * D, tb, ts);     // quantize(u+v) with the TRAINER's bitlevel
+  if (he == hipSuccess) he = hipStreamSynchronize(ts);
+  if (he != hipSuccess) {
+    (void)hipFree(q);
+    eval_release(e);
+    return efail(W2B_EHIP, std::string("w2b_eval_from_trainer: ") + hipGetErrorString(he));
+  }
+  const int rc = eval_finish(e, bitlevel, nullptr, q, out);
+  (void)hipFree(q);
+  return rc;
 }
 
 extern "C" void w2b_eval_free(w2b_eval *e) { eval_release(e); }

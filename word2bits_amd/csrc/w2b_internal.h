@@ -92,6 +92,10 @@ hipError_t w2b_launch_eval_scores(const float *Q, const float *M, int nq, int wo
                                   const int *b1, const int *b2, const int *b3, unsigned long long *best,
                                   int variant /* 0: vector-ALU kernel always; else MFMA when fused */, hipStream_t s);
 int w2b_internal_fail(int code, const char *msg);   // sets w2b_last_error() (w2b_trainer.cpp)
+struct w2b_trainer;
+// what the evaluator needs from a live trainer (w2b_trainer.cpp): device tables, shape, bitlevel, device, stream
+void w2b_internal_trainer_view(w2b_trainer *t, float **u, float **v, long long *V, long long *D, int *bitlevel,
+                               int *device, hipStream_t *stream);
 hipError_t w2b_launch_wca_pack(const W2bShared *sh, unsigned long long *buf, hipStream_t s);   // buf[0] = local word count
 hipError_t w2b_launch_wca_unpack(W2bShared *sh, const unsigned long long *buf, hipStream_t s); // from buf[1] = global sum
 hipError_t w2b_launch_sub(float *w, const float *base, long long n, hipStream_t s);       // w -= base

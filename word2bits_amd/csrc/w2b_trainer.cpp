@@ -342,6 +342,17 @@ extern "C" int w2b_model_device_ptrs(w2b_trainer *t, void **u_dev, void **v_dev)
   return W2B_OK;
 }
 
+void w2b_internal_trainer_view(w2b_trainer *t, float **u, float **v, long long *V, long long *D, int *bitlevel,
+                               int *device, hipStream_t *stream) {
+  *u = t->uv;
+  *v = t->uv + t->table_elems;
+  *V = t->cfg.vocab_size;
+  *D = t->cfg.layer1_size;
+  *bitlevel = t->cfg.bitlevel;
+  *device = t->device;
+  *stream = t->stream;
+}
+
 extern "C" int w2b_export_quantized(w2b_trainer *t, float *out) {
   NEED(t);
   if (!out) return fail(W2B_EINVAL, "w2b_export_quantized: null output");

@@ -279,36 +279,37 @@ int main(int argc, char **argv) {
     }
   }
   save(o, corpus, reps[0].t, o.output_file);                  // ref :560-576
-  for (auto &r : reps) w2b_trainer_destroy(r.t);
-  w2b_corpus_free(corpus);
+  int rc_eval = 0;
   if (!o.eval_file.empty()) {
-    // what `compute_accuracy <output> 0 0 < FILE` prints, run on the GPU on the file just written (the evaluator
-    // -- the reference's too -- reads the binary format only)
-    if (!o.binary) {
-      fprintf(stderr, "word2bits: -eval needs -binary 1 (the evaluator reads the binary vector format)\n");
-      return 1;
-    }
+    // what `compute_accuracy <output> 0 0 < FILE` prints for the vectors just saved (binary format), scored on the GPU
+    // straight from the live model: no file round trip
     FILE *qf = fopen(o.eval_file.c_str(), "rb");
     if (!qf) {
       fprintf(stderr, "word2bits: cannot open %s\n", o.eval_file.c_str());
-      return 1;
+      rc_eval = 1;
+    } else {
+      std::string qs;
+      char buf[1 << 16];
+      size_t n;
+      while ((n = fread(buf, 1, sizeof buf, qf)) > 0) qs.append(buf, n);
+      fclose(qf);
+      std::vector<const char *> names((size_t)V);
+      for (long long a = 0; a < V; a++) names[(size_t)a] = w2b_corpus_word(corpus, a);
+      w2b_eval *ev = nullptr;
+      char *txt = nullptr;
+      int64_t len = 0;
+      if (w2b_eval_from_trainer(reps[0].t, V, names.data(), 0, 0, 1, &ev) != W2B_OK ||
+          w2b_eval_transcript(ev, qs.data(), (int64_t)qs.size(), &txt, &len) != W2B_OK) {
+        fprintf(stderr, "word2bits: -eval failed: %s\n", w2b_last_error());
+        rc_eval = 1;
+      } else {
+        fwrite(txt, 1, (size_t)len, stdout);
+        w2b_eval_free_text(txt);
+      }
+      if (ev) w2b_eval_free(ev);
     }
-    std::string qs;
-    char buf[1 << 16];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, qf)) > 0) qs.append(buf, n);
-    fclose(qf);
-    w2b_eval *ev = nullptr;
-    char *txt = nullptr;
-    int64_t len = 0;
-    if (w2b_eval_load(o.output_file.c_str(), 0, 0, 1, o.device, &ev) != W2B_OK ||
-        w2b_eval_transcript(ev, qs.data(), (int64_t)qs.size(), &txt, &len) != W2B_OK) {
-      fprintf(stderr, "word2bits: -eval failed: %s\n", w2b_last_error());
-      return 1;
-    }
-    fwrite(txt, 1, (size_t)len, stdout);
-    w2b_eval_free_text(txt);
-    w2b_eval_free(ev);
   }
-  return 0;
+  for (auto &r : reps) w2b_trainer_destroy(r.t);
+  w2b_corpus_free(corpus);
+  return rc_eval;
 }

@@ -16,13 +16,27 @@ class Evaluator:
     """`fused=True` reproduces the reference built with its own Makefile flags (FMA-contracted dot products),
     `fused=False` the -ffp-contract=off build; answers are identical to that build's, ties included."""
 
-    def __init__(self, path, bitlevel=0, threshold=0, fused=True, device=0):
+    def __init__(self, path, bitlevel=0, threshold=0, fused=True, device=0, _handle=None):
         self._h = C.c_void_p()
         self._L = _lib.lib()
-        _lib.check(self._L.w2b_eval_load(str(path).encode(), int(bitlevel), int(threshold), int(bool(fused)),
-                                         int(device), C.byref(self._h)))
+        if _handle is not None:
+            self._h = _handle
+        else:
+            _lib.check(self._L.w2b_eval_load(str(path).encode(), int(bitlevel), int(threshold), int(bool(fused)),
+                                             int(device), C.byref(self._h)))
         self.words = int(self._L.w2b_eval_words(self._h))
         self.size = int(self._L.w2b_eval_size(self._h))
+
+    @classmethod
+    def from_trainer(cls, trainer, words, bitlevel=0, threshold=0, fused=True):
+        """The evaluator on a live Trainer (no file round trip): what Evaluator(path) would hold after the trainer's
+        vectors had been saved to `path` with binary=1.  `words` = the vocabulary (Corpus.words())."""
+        L = _lib.lib()
+        arr = (C.c_char_p * len(words))(*[w if isinstance(w, bytes) else w.encode("latin1") for w in words])
+        h = C.c_void_p()
+        _lib.check(L.w2b_eval_from_trainer(trainer._h, len(words), arr, int(bitlevel), int(threshold), int(bool(fused)),
+                                           C.byref(h)))
+        return cls(None, _handle=h)
 
     def close(self):
         if self._h:
