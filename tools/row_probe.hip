@@ -23,7 +23,7 @@ __device__ __forceinline__ unsigned swap_pair(unsigned x) {   // value of the ne
 }
 
 template <int SHAPE, int LAUX, int SAUX, int T, bool PF>
-__global__ void __launch_bounds__(512) k_probe(float *tab, unsigned nrows, int dim, int iters, unsigned *sink) {
+__global__ void __launch_bounds__(512) k_probe(float *tab, unsigned nrows, int dim, int iters, unsigned *sink, int what) {
   extern __shared__ int pad[];
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned rowb = (unsigned)dim * 4u;
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(512) k_probe(float *tab, unsigned nrows, int d
     for (int i = 0; i < T; i++) { s = s * 25214903917ull + 11; rows[b][i] = __builtin_amdgcn_readfirstlane((unsigned)((s >> 20) % nrows)); }
   };
   auto load = [&](int b) {
-    if (!act) return;
+    if (!act || what == 2) return;
     if (SHAPE == 0) {
 #pragma unroll
       for (int i = 0; i < T; i++) { u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, off8, rows[b][i] * rowb, LAUX); x[b][i][0] = t.x; x[b][i][1] = t.y; }
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(512) k_probe(float *tab, unsigned nrows, int d
     }
   };
   auto store = [&](int b) {
-    if (!act) return;
+    if (!act || what == 1) return;
     if (SHAPE == 0) {
 #pragma unroll
       for (int i = 0; i < T; i++) { u32x2 t; t.x = x[b][i][0] + 1; t.y = x[b][i][1] + 1; __builtin_amdgcn_raw_buffer_store_b64(t, r, off8, rows[b][i] * rowb, SAUX); }
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(512) k_probe(float *tab, unsigned nrows, int d
 }
 
 template <int SHAPE, int LAUX, int SAUX, int T, bool PF>
-static void run(const char *name, float *tab, unsigned nrows, int dim, int wg_per_cu, unsigned *sink) {
+static void run(const char *name, float *tab, unsigned nrows, int dim, int wg_per_cu, unsigned *sink, int what = 0) {
   const int threads = (SHAPE == 2) ? 256 : 448;
   const size_t lds = (size_t)(160 * 1024 / wg_per_cu) - 1024;
   const int grid = 256 * wg_per_cu, iters = 400;
@@ -116,14 +116,15 @@ static void run(const char *name, float *tab, unsigned nrows, int dim, int wg_pe
   float best = 1e30f;
   for (int rep = 0; rep < 3; rep++) {
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL((k_probe<SHAPE, LAUX, SAUX, T, PF>), dim3(grid), dim3(threads), lds, 0, tab, nrows, dim, iters, sink);
+    hipLaunchKernelGGL((k_probe<SHAPE, LAUX, SAUX, T, PF>), dim3(grid), dim3(threads), lds, 0, tab, nrows, dim, iters, sink, what);
     CK(hipEventRecord(b));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     if (ms < best) best = ms;
   }
-  const double bytes = 2.0 * grid * (double)iters * T * dim * 4;
-  printf("%-34s T=%2d pf=%d wg/cu=%d: %8.3f ms  %6.2f TB/s (read+write)\n", name, T, (int)PF, wg_per_cu, best, bytes / best / 1e9);
+  const double bytes = (what ? 1.0 : 2.0) * grid * (double)iters * T * dim * 4;
+  printf("%-34s T=%2d pf=%d wg/cu=%d: %8.3f ms  %6.2f TB/s (%s)\n", name, T, (int)PF, wg_per_cu, best, bytes / best / 1e9,
+         what == 0 ? "read+write" : (what == 1 ? "reads only" : "writes only"));
   fflush(stdout);
 }
 
@@ -152,6 +153,12 @@ int main() {
     ROW(2, 16, 16, 24, 1, "16B/lane sc1+sc1");          // one workgroup per CU, a whole word's rows per batch
     ROW(2, 16, 16, 12, 1, "16B/lane sc1+sc1");
     ROW(2, 16, 16, 24, 2, "16B/lane sc1+sc1");
+    run<2, 16, 16, 12, false>("16B/lane sc1", tab, nrows, dim, 2, sink, 1);
+    run<2, 16, 16, 12, false>("16B/lane sc1", tab, nrows, dim, 2, sink, 2);
+    run<2, 0, 0, 12, false>("16B/lane plain", tab, nrows, dim, 2, sink, 1);
+    run<2, 0, 0, 12, false>("16B/lane plain", tab, nrows, dim, 2, sink, 2);
+    run<2, 16, 16, 8, false>("16B/lane sc1", tab, nrows, dim, 4, sink, 1);
+    run<2, 16, 16, 8, false>("16B/lane sc1", tab, nrows, dim, 4, sink, 2);
   }
   return 0;
 }

@@ -282,14 +282,93 @@ __device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP c
   return k;     // number of chunks
 }
 
+// ------------------------------------------------------------------------------------ private hot rows
+// The tuple kernel and the plain worker kernel touch every row through memory; with coherent (agent-scope) rows the few
+// most frequent rows of u (context words) and of v (targets) then serialise at their memory lines (~7 M read-modify-
+// writes per second per row, against e.g. 0.67 context uses and 0.32 target uses of row 1 per centre word on
+// Zipf(1) ids).  A workgroup therefore keeps PRIVATE copies of rows 1..nu of u and 1..nv of v (the vocabulary is sorted
+// by count; the numbers come from the word counts, 0 when unknown) in LDS, thread-private 16-byte columns, and merges
+// them with memory every `period` centre words and when it ends -- the exact-or-merge rule of the sentence-resident
+// kernel (w2b_kernels_resident.hip): untouched in memory since the last merge -> the exact value is stored (one
+// workgroup alone stays bit-identical to the kernel without private rows), else value - entry is added to the
+// current row.  16-byte columns only (VEC == 4).
+struct HotSet {
+  float *rows;           // [nu + nv][dim]      private values (u rows first)
+  unsigned *csum;        // [nu + nv][W2B_MAXW] per-wavefront checksum of the row bits at the last merge
+  int nu, nv;
+  unsigned dirty_u, dirty_v;     // bit k: this workgroup has updated its copy of row k+1 since the last merge
+  long long scratch0;    // first scratch ("entry") row of this workgroup in P.entry
+};
+
+__device__ __forceinline__ unsigned col4_bits(const Col<4> &c) {
+  return __float_as_uint(c.e[0]) * 3u ^ __float_as_uint(c.e[1]) * 5u ^ __float_as_uint(c.e[2]) * 7u ^ __float_as_uint(c.e[3]) * 9u;
+}
+__device__ __forceinline__ Col<4> hot_ld(const float *p) {
+  Col<4> c;
+#pragma unroll
+  for (int e = 0; e < 4; e++) c.e[e] = p[e];
+  return c;
+}
+__device__ __forceinline__ void hot_st(float *p, const Col<4> &c) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) p[e] = c.e[e];
+}
+
+// (re)load the private copies / meet memory.  `init`: first call of a launch (adopt everything).
+template <int MM>
+__device__ __forceinline__ void hot_set_merge(const W2bParams &P, HotSet &H, bool init, bool active, int col0, int lane, int wave) {
+  const int dim = P.dim;
+#pragma unroll 1
+  for (int tsel = 0; tsel < 2; tsel++) {
+    float *tab = tsel ? P.v : P.u;
+    const int n = tsel ? H.nv : H.nu, base = tsel ? H.nu : 0;
+    unsigned &dirty = tsel ? H.dirty_v : H.dirty_u;
+#pragma unroll 1
+    for (int k = 0; k < n; k++) {
+      const int slot = base + k;
+      Col<4> g;
+#pragma unroll
+      for (int e = 0; e < 4; e++) g.e[e] = 0.f;
+      if (active) g = load_col<4, MM>(tab, k + 1, dim, col0, P.tab_bytes);
+      const unsigned now = wave_xor(active ? col4_bits(g) : 0u);
+      if (init || !((dirty >> k) & 1u)) {               // nothing of ours: adopt the current row
+        if (active) {
+          hot_st(H.rows + slot * dim + col0, g);
+          store_col<4, 1, 1>(P.entry, H.scratch0 + slot, dim, col0, g, 0u);
+        }
+        if (lane == 0) H.csum[slot * W2B_MAXW + wave] = now;
+        continue;
+      }
+      const bool untouched = (now == H.csum[slot * W2B_MAXW + wave]);
+      Col<4> val = g;
+      if (active) {
+        val = hot_ld(H.rows + slot * dim + col0);
+        if (!untouched) {
+          const Col<4> en = load_col<4, 0, 1>(P.entry, H.scratch0 + slot, dim, col0, 0u);
+#pragma unroll
+          for (int e = 0; e < 4; e++) val.e[e] = g.e[e] + (val.e[e] - en.e[e]);
+          hot_st(H.rows + slot * dim + col0, val);
+        }
+        store_col<4, MM>(tab, k + 1, dim, col0, val, P.tab_bytes);
+        store_col<4, 1, 1>(P.entry, H.scratch0 + slot, dim, col0, val, 0u);
+      }
+      const unsigned cs = wave_xor(active ? col4_bits(val) : 0u);
+      if (lane == 0) H.csum[slot * W2B_MAXW + wave] = cs;
+    }
+    dirty = 0u;
+  }
+}
+
 // ------------------------------------------------------------------------------------ one centre word
 // Preconditions: L.ctx[0..cw), L.tgt[0..nt) and prep_lists() results published by a __syncthreads();
 // cw >= 1, nt >= 1.
 // Ends with a __syncthreads() (lists may be overwritten afterwards).
+// H: the workgroup's private hot rows (nu = nv = 0: none; VEC == 4 only).  Passed by reference and never through a
+// pointer, so that its fields stay in registers.
 template <int QM, int VEC, bool LOSS, int MM>
 __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &L, const QParam &qp,
                                              const int cw, const int nt, const float alpha,
-                                             double &loss_acc) {
+                                             double &loss_acc, HotSet &H) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int dim = P.dim, col0 = tid * VEC;
   const bool active = col0 < dim;
@@ -305,13 +384,29 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     for (int i = 0; i < TC; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
   };
   chunk_rows();
+  const int nhu = (VEC == 4) ? H.nu : 0, nhv = (VEC == 4) ? H.nv : 0;
+  // one chunk of target rows: private hot rows first, from LDS (issued after the loads, an LDS read into a register
+  // that could have a load in flight would drain every outstanding load), then the loads
+  auto load_targets = [&](bool zero) {
+#pragma unroll
+    for (int i = 0; i < TC; i++) {
+      if (zero) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
+      }
+      if (VEC == 4 && nhv > 0 && active && start + i < end && (unsigned)(rows[i] - 1) < (unsigned)nhv) {
+        const float *hp = H.rows + (nhu + rows[i] - 1) * dim + col0;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) x[i].e[e] = hp[e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TC; i++)
+      if (active && start + i < end && !((unsigned)(rows[i] - 1) < (unsigned)nhv))
+        x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0, P.tab_bytes);
+  };
   // issue the first chunk of target-row loads before the context phase so both gathers overlap
-#pragma unroll
-  for (int i = 0; i < TC; i++) {
-#pragma unroll
-    for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
-    if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0, P.tab_bytes);
-  }
+  load_targets(true);
 
   // ---- phase A: context_avg = (1/cw) * sum_j quantize(u[ctx_j])   (ref :431-449)
   Col<VEC> avg;
@@ -320,9 +415,24 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
   for (int e = 0; e < VEC; e++) avg.e[e] = 0.f;
   for (int j0 = 0; j0 < cw; j0 += W2B_CA) {
     Col<VEC> r[W2B_CA];
+    if (VEC == 4 && nhu > 0) {
+#pragma unroll
+      for (int jj = 0; jj < W2B_CA; jj++)
+        if (active && j0 + jj < cw) {
+          const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
+          if ((unsigned)(crow - 1) < (unsigned)nhu) {
+            const float *hp = H.rows + (crow - 1) * dim + col0;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) r[jj].e[e] = hp[e];
+          }
+        }
+    }
 #pragma unroll
     for (int jj = 0; jj < W2B_CA; jj++)
-      if (active && j0 + jj < cw) r[jj] = load_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0, P.tab_bytes);
+      if (active && j0 + jj < cw) {
+        const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
+        if (!((unsigned)(crow - 1) < (unsigned)nhu)) r[jj] = load_col<VEC, MM>(P.u, crow, dim, col0, P.tab_bytes);
+      }
 #pragma unroll
     for (int jj = 0; jj < W2B_CA; jj++)
       if (active && j0 + jj < cw) {
@@ -447,8 +557,15 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
             err.e[e] += g * quant<QM>(xv, qp);
             x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
           }
-          store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i], P.tab_bytes);
+          if (VEC == 4 && (unsigned)(rows[i] - 1) < (unsigned)nhv) {
+            float *hp = H.rows + (nhu + rows[i] - 1) * dim + col0;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) hp[e] = x[i].e[e];
+          } else {
+            store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i], P.tab_bytes);
+          }
         }
+        if (VEC == 4 && (unsigned)(rows[i] - 1) < (unsigned)nhv) H.dirty_v |= 1u << (rows[i] - 1);
       }
     }
     start = end;
@@ -456,9 +573,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     end = L.cend[++chunk];
     par ^= 1;
     chunk_rows();
-#pragma unroll
-    for (int i = 0; i < TC; i++)
-      if (active && start + i < end) x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0, P.tab_bytes);
+    load_targets(false);
   }
 
   // ---- phase C: u[ctx_j] += context_avge - 2*alpha*reg*u[ctx_j]   (ref :494-503)
@@ -467,11 +582,16 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
 #pragma unroll
     for (int jj = 0; jj < W2B_CA; jj++)
       if (active && j0 + jj < cw && L.umult[j0 + jj] > 0) {
+        const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
         if (j0 + jj < W2B_STASH) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) r[jj].e[e] = L.stash[((j0 + jj) * blockDim.x + tid) * VEC + e];
+        } else if (VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu) {
+          const float *hp = H.rows + (crow - 1) * dim + col0;
+#pragma unroll
+          for (int e = 0; e < VEC; e++) r[jj].e[e] = hp[e];
         } else {
-          r[jj] = load_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0, P.tab_bytes);
+          r[jj] = load_col<VEC, MM>(P.u, crow, dim, col0, P.tab_bytes);
         }
       }
 #pragma unroll
@@ -483,9 +603,24 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
 #pragma unroll
             for (int e = 0; e < VEC; e++) r[jj].e[e] = r[jj].e[e] + (err.e[e] - ar2 * r[jj].e[e]);
           }
-          store_col<VEC, MM>(P.u, L.ctx[j0 + jj], dim, col0, r[jj], P.tab_bytes);
+          const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
+          if (VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu) {
+            float *hp = H.rows + (crow - 1) * dim + col0;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) hp[e] = r[jj].e[e];
+          } else {
+            store_col<VEC, MM>(P.u, crow, dim, col0, r[jj], P.tab_bytes);
+          }
         }
       }
+    if (VEC == 4 && nhu > 0) {       // (wave-uniform bookkeeping outside the per-lane `active` region)
+#pragma unroll
+      for (int jj = 0; jj < W2B_CA; jj++)
+        if (j0 + jj < cw && L.umult[j0 + jj] > 0) {
+          const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
+          if ((unsigned)(crow - 1) < (unsigned)nhu) H.dirty_u |= 1u << (crow - 1);
+        }
+    }
   }
   if (LOSS && P.reg != 0.f) {
     const float s = wave_sum(regsq);

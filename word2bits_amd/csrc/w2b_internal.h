@@ -58,7 +58,8 @@ struct W2bParams {
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
   int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
   float *entry;                   // sentence-resident kernel: scratch rows [num_threads][2][slots][dim] (see w2b_kernels_resident.hip)
-  int hot_period;                 // sentence-resident kernel: steps between merges of the private hot target rows (power of two)
+  int hot_period;                 // centre words between two merges of a worker's / workgroup's private hot rows (power of two)
+  int hot_u, hot_v;               // tuple kernel: leading rows of u / v with a private copy per workgroup (0 = none)
   int exact;                      // serial dot product in the reference's order (plain worker / tuple kernels)
   float starting_alpha, sample, reg;
 };
@@ -66,7 +67,8 @@ struct W2bParams {
 // launchers implemented in w2b_kernels.hip --------------------------------------------------------
 // block size chosen from dim: one thread per 16-byte (or 4-byte) column of a row
 int w2b_block_threads(int dim, int *vec_out);
-size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact = false);
+size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact = false, int hot_rows = 0);
+int w2b_tuple_max_grid(int num_cus);                                   // most workgroups w2b_launch_tuples starts
 hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *center,
                              const int32_t *ctx_off, const int32_t *ctx, const int32_t *neg,
                              float alpha, int grid, int num_cus, int per_cu_override, bool loss,

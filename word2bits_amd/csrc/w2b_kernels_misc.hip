@@ -89,7 +89,7 @@ int w2b_block_threads(int dim, int *vec_out) {
   return threads;   // caller rejects > 1024
 }
 
-size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact) {
+size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact, int hot_rows) {
   const int maxc = (2 * window + 1 + 3) & ~3, maxt = (negative + 1 + 3) & ~3;
   int vec;
   const int threads = w2b_block_threads(dim, &vec);
@@ -97,6 +97,8 @@ size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool e
   if (worker_form) ints += ((W2B_MAX_SEN + 3) & ~3) + 4 + (sizeof(WorkerLds) + 3) / 4 + 4;
   else ints += 4;
   if (exact) ints += (size_t)W2B_T * (W2B_EXACT_COLS + 1) + 4;
+  ints = (ints + 3) & ~(size_t)3;                                  // the hot rows start 16-byte aligned
+  ints += (size_t)hot_rows * (dim + W2B_MAXW);                     // private hot rows + their checksums
   return ints * 4;
 }
 

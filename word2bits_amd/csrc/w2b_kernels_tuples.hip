@@ -9,12 +9,26 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
                                                       const int32_t *__restrict__ ctx_off,
                                                       const int32_t *__restrict__ ctx,
                                                       const int32_t *__restrict__ neg,
-                                                      const float alpha) {
+                                                      const float alpha, const int hot_off) {
   extern __shared__ int smem[];
   WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
   int *s_cnt = L.cend + round4(P.negative + 1);   // [0] cw, [1] nt
   if (MM == W2B_MM_EXACT) L.xprod = reinterpret_cast<float *>(s_cnt + 4);
   const int tid = threadIdx.x, lane = tid & 63;
+  // private copies of the hottest rows of u and v (16-byte columns, coherent rows, not in the parity mode)
+  HotSet HS;
+  HS.rows = reinterpret_cast<float *>(smem + hot_off);
+  HS.nu = 0; HS.nv = 0; HS.dirty_u = 0u; HS.dirty_v = 0u;
+  HS.csum = nullptr;
+  HS.scratch0 = 0;
+  const bool hot = (VEC == 4 && MM == 0 && P.hot_u + P.hot_v > 0);
+  if (hot) {
+    HS.csum = reinterpret_cast<unsigned *>(HS.rows + (P.hot_u + P.hot_v) * P.dim);
+    HS.nu = P.hot_u; HS.nv = P.hot_v;
+    HS.scratch0 = (long long)blockIdx.x * (P.hot_u + P.hot_v);
+    hot_set_merge<MM>(P, HS, true, tid * VEC < P.dim, tid * VEC, lane, tid >> 6);
+  }
+  int since_merge = 0;
   QParam qp;
   qp.bitlevel = P.bitlevel;
   qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
@@ -40,9 +54,14 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     }
     __syncthreads();
     const int cw = s_cnt[0], nt = s_cnt[1];
-    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc);
+    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, HS);
     else __syncthreads();
+    if (hot && ++since_merge >= P.hot_period) {
+      since_merge = 0;
+      hot_set_merge<MM>(P, HS, false, tid * VEC < P.dim, tid * VEC, lane, tid >> 6);
+    }
   }
+  if (hot) hot_set_merge<MM>(P, HS, false, tid * VEC < P.dim, tid * VEC, lane, tid >> 6);
   if (LOSS) {
     if (tid < 64) {
       const double s = wave_sum_d(loss_acc);
@@ -56,6 +75,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
 }  // namespace
 
 // instantiation), so the grid-stride loop has no tail of late-starting workgroups.
+int w2b_tuple_max_grid(int num_cus) { return num_cus * 32; }   // 32 wavefronts per CU is all the hardware holds
 template <typename KernelT>
 static int auto_grid(KernelT kernel, int threads, size_t lds, int num_cus, int per_cu_override, long long n) {
   int nb = 0;
@@ -71,7 +91,9 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
                              int per_cu_override, bool loss, hipStream_t s) {
   int vec;
   const int threads = w2b_block_threads(p.dim, &vec);
-  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, false, p.exact != 0);
+  const int hot = (vec == 4 && threads <= 256 && p.mem_mode == 0 && !p.exact) ? p.hot_u + p.hot_v : 0;
+  const int hot_off = (int)(w2b_lds_bytes(p.dim, p.window, p.negative, false, p.exact != 0, 0) / 4);
+  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, false, p.exact != 0, hot);
   return dispatch_mm_exact(p.mem_mode, p.exact, [&](auto mm) -> hipError_t {
   constexpr int MM = decltype(mm)::value;
   return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
@@ -79,8 +101,9 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
 #define W2B_LAUNCH_T2(VEC, LOSS, MAXT)                                                                      \
     do {                                                                                                     \
       auto kern = k_train_tuples<QM, VEC, LOSS, MAXT, MM>;                                                       \
-      const int g = grid > 0 ? grid : auto_grid(kern, threads, lds, num_cus, per_cu_override, n);            \
-      hipLaunchKernelGGL(kern, dim3(g), dim3(threads), lds, s, p, n, center, ctx_off, ctx, neg, alpha);      \
+      int g = grid > 0 ? grid : auto_grid(kern, threads, lds, num_cus, per_cu_override, n);                  \
+      if (grid <= 0 && hot > 0 && per_cu_override <= 0 && g > w2b_tuple_max_grid(num_cus)) g = w2b_tuple_max_grid(num_cus); \
+      hipLaunchKernelGGL(kern, dim3(g), dim3(threads), lds, s, p, n, center, ctx_off, ctx, neg, alpha, hot_off); \
     } while (0)
 #define W2B_LAUNCH_T(VEC, LOSS) \
     do { if (threads <= 256) W2B_LAUNCH_T2(VEC, LOSS, 256); else W2B_LAUNCH_T2(VEC, LOSS, 1024); } while (0)

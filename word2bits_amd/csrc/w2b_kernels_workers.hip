@@ -30,6 +30,8 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
   }
   __syncthreads();
   double loss_acc = 0.0;
+  HotSet no_hot;                 // (the plain worker kernel keeps no private rows)
+  no_hot.rows = nullptr; no_hot.csum = nullptr; no_hot.nu = 0; no_hot.nv = 0; no_hot.dirty_u = 0u; no_hot.dirty_v = 0u; no_hot.scratch0 = 0;
   const int W = P.window, K = P.negative;
   for (long long it = 0; it < max_positions; ++it) {
     if (wave == 0) {
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     if (S->done) break;
     const int cw = S->cw, nt = S->nt;
     const float alpha = S->alpha;
-    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc);
+    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, no_hot);
     else __syncthreads();
   }
   // save the worker

@@ -48,6 +48,8 @@ struct w2b_trainer {
   float *entry = nullptr;       // scratch rows of the sentence-resident kernel
   size_t entry_floats = 0;
   int hot_wanted = 0;           // leading rows of v whose target rate justifies a private on-chip copy (from the counts)
+  int hot_wanted_u = 0;         // ... rows of u (context uses per centre word; tuple kernel only -- the sentence-resident
+                                // kernel keeps the whole context window on chip anyway)
   const int32_t *corpus = nullptr;
   int32_t *corpus_owned = nullptr;
   long long n_tokens = 0;
@@ -412,6 +414,12 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
       n++;
     }
     t->hot_wanted = n;
+    n = 0;                       // row i of u is a context row (window + 1 on average) * cn_i / train_words times per word
+    for (int64_t a = 1; a < V && a <= 4; a++) {
+      if (tot <= 0 || (t->cfg.window + 1) * (cn[a] / tot) < 0.1) break;
+      n++;
+    }
+    t->hot_wanted_u = n;
   }
   if (table_size > 0) {
     std::vector<int32_t> tab((size_t)table_size);
@@ -689,7 +697,37 @@ extern "C" int w2b_train_tuples_device(w2b_trainer *t, int64_t n, const void *ce
   if (n < 0 || !center || !ctx_off || !ctx || (!neg && t->cfg.negative > 0))
     return fail(W2B_EINVAL, "w2b_train_tuples_device: bad argument");
   if (n == 0) return W2B_OK;
-  const W2bParams p = make_params(t);
+  W2bParams p = make_params(t);
+  {
+    // private hot rows per workgroup (coherent rows, 16-byte columns, not in the parity mode): at most two of each
+    // table, so that three workgroups still share a CU's LDS; W2B_TUPLE_HOT="u,v" overrides (test hook)
+    int hu = t->hot_wanted_u < 2 ? t->hot_wanted_u : 2, hv = t->hot_wanted < 2 ? t->hot_wanted : 2;
+    if (const char *e = getenv("W2B_TUPLE_HOT")) {
+      if (sscanf(e, "%d,%d", &hu, &hv) != 2) hu = hv = 0;
+      if (hu < 0 || hu > 8) hu = 0;
+      if (hv < 0 || hv > 8) hv = 0;
+    }
+    int vec = 0;
+    const int threads = w2b_block_threads(t->cfg.layer1_size, &vec);
+    if (vec != 4 || threads > 256 || p.mem_mode != 0 || p.exact || t->cfg.vocab_size <= 8) hu = hv = 0;
+    p.hot_u = hu;
+    p.hot_v = hv;
+    if (hu + hv > 0) {
+      long long wgs = w2b_tuple_max_grid(t->num_cus);
+      if (grid > wgs) wgs = grid;
+      if ((long long)t->grid_per_cu * t->num_cus > wgs) wgs = (long long)t->grid_per_cu * t->num_cus;
+      const size_t need = (size_t)wgs * (hu + hv) * t->cfg.layer1_size;
+      if (need > t->entry_floats) {
+        HIPCHK(hipStreamSynchronize(t->stream));
+        if (t->entry) HIPCHK(hipFree(t->entry));
+        t->entry = nullptr;
+        t->entry_floats = 0;
+        HIPCHK(hipMalloc(&t->entry, sizeof(float) * need));
+        t->entry_floats = need;
+      }
+      p.entry = t->entry;
+    }
+  }
   HIPCHK(timing_begin(t));
   HIPCHK(w2b_launch_tuples(p, n, (const int32_t *)center, (const int32_t *)ctx_off, (const int32_t *)ctx,
                            (const int32_t *)neg, alpha, grid > 0 ? grid : 0, t->num_cus, t->grid_per_cu,
