@@ -275,7 +275,7 @@ extern "C" int w2b_eval_top1(w2b_eval *e, int64_t nq, const int32_t *b1, const i
     EHIP(hipEventCreate(&t0));
     EHIP(hipEventCreate(&t1));
     EHIP(hipEventRecord(t0, e->stream));
-    hipError_t le = w2b_launch_eval_scores(e->Q, e->M, (int)n, (int)e->words, (int)e->ld, e->fused, d1, d2, d3,
+    hipError_t le = w2b_launch_eval_scores(e->Q, e->M, (int)n, (int)e->words, (int)e->size, (int)e->ld, e->fused, d1, d2, d3,
                                            e->best, e->variant, e->stream);
     if (le == hipSuccess) le = hipEventRecord(t1, e->stream);
     keys.resize((size_t)n);
@@ -288,7 +288,7 @@ extern "C" int w2b_eval_top1(w2b_eval *e, int64_t nq, const int32_t *b1, const i
     if (le != hipSuccess) return efail(W2B_EHIP, std::string("w2b_eval_top1: ") + hipGetErrorString(le));
     e->kernel_ms += ms;
     e->launches++;
-    e->macs += (double)np * (double)e->rows_padded * (double)e->ld;
+    e->macs += (double)n * (double)e->words * (double)e->size;   // algorithmic: padding is not work
     for (int64_t q = 0; q < n; q++) {
       const unsigned long long k = keys[(size_t)q];
       best[q0 + q] = k ? (int32_t)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull)) : -1;

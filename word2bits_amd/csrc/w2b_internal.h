@@ -90,7 +90,7 @@ hipError_t w2b_launch_eval_normalize(float *M, long long words, long long size, 
                                      int fused, float *len_scratch, hipStream_t s);
 hipError_t w2b_launch_eval_queries(const float *M, long long ld, long long nq, const int *b1, const int *b2,
                                    const int *b3, float *Q, int variant, hipStream_t s);
-hipError_t w2b_launch_eval_scores(const float *Q, const float *M, int nq, int words, int ld, int fused,
+hipError_t w2b_launch_eval_scores(const float *Q, const float *M, int nq, int words, int size, int ld, int fused,
                                   const int *b1, const int *b2, const int *b3, unsigned long long *best,
                                   int variant /* 0: vector-ALU kernel always; else MFMA when fused */, hipStream_t s);
 int w2b_internal_fail(int code, const char *msg);   // sets w2b_last_error() (w2b_trainer.cpp)

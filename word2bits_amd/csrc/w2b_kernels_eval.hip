@@ -185,15 +185,36 @@ k_eval_scores(const float *__restrict__ Q, const float *__restrict__ M, int nq, 
 // purpose: a lane then holds ONE question (column) and 16 rows per tile, so the arg-max over rows is mostly
 // in-lane; one exchange with lane^32 and one ds_max_u64 finish it.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef W2B_EVAL_EXP
+#define W2B_EVAL_EXP 0
+#endif
+#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
+__device__ unsigned long long g_eval_ticks[16];
+#define W2B_ETICK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_eval_ticks[i], n_ - tk_); tk_ = n_; } while (0)
+#else
+#define W2B_ETICK(i) do { } while (0)
+#endif
 
-template <int MK>
+// Software pipeline (the unit is HALF a slab = 8 k = 4 MFMA k-pairs x 4 tiles = 16 MFMAs = 1024 matrix-pipe
+// cycles per wavefront): while the 16 MFMAs of one half issue, the fragments of the next half are read from LDS, and
+// the slab after that is written to the other LDS buffer -- so the LDS latency, the staging writes and the global
+// loads all sit in the shadow of the matrix pipe and only the skew of the one barrier per slab is exposed.  `nh`
+// halves are walked, nh = ceil(size / 8): the zero columns that pad a row to a multiple of 16 are never multiplied.
 __global__ void __launch_bounds__(ETHREADS, 2)
-k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int nq, int words, int ld, int q_tiles,
-                   int c_tiles, int c_per_xcd, int q_group, const int *__restrict__ b1, const int *__restrict__ b2,
-                   const int *__restrict__ b3, unsigned long long *__restrict__ best) {
-  __shared__ float As[2][MK][ELD];       // rows of M
-  __shared__ float Bs[2][MK][ELD];       // questions
+k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int nq, int words, int ld, int nh,
+                   int q_tiles, int c_tiles, int c_per_xcd, int q_group, const int *__restrict__ b1,
+                   const int *__restrict__ b2, const int *__restrict__ b3, unsigned long long *__restrict__ best) {
+  constexpr int MK = 16;
+  // row pitch 130 floats: the staging writes of a 32-lane group (4 k-quads x 8 rows) then fall on 32 different banks
+  // (4 * 130 = 8 mod 32); the fragment reads are 32 consecutive floats of one k row whatever the pitch
+  constexpr int MLD = EBM + 2;
+  __shared__ float As[2][MK][MLD];       // rows of M
+  __shared__ float Bs[2][MK][MLD];       // questions
   __shared__ unsigned long long skey[EBN];
+#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 64)
+  __shared__ float occupancy_pad[6000];          // 24 KB more: two workgroups per CU
+  if (nq < 0) occupancy_pad[threadIdx.x] = 1.f, best[0] = (unsigned long long)occupancy_pad[threadIdx.x ^ 1];
+#endif
 
   // XCD-aware order: an XCD owns a stripe of row tiles; inside it consecutive workgroups take `q_group` question
   // tiles of ONE row tile before moving to the next row tile, so a row tile fetched into that XCD's L2 is reused
@@ -207,19 +228,49 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
   if (tid < EBN) skey[tid] = 0ull;
+#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
+  unsigned long long tk_ = __builtin_readcyclecounter();
+  if (tid == 0) { atomicAdd(&g_eval_ticks[4], 1ull); atomicMin(&g_eval_ticks[5], tk_); }
+#endif
+#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 4)
+  // first generation of workgroups: stagger the ones that share a CU by a third of a tile each
+  if (blockIdx.x < 1024) {
+    const int slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));      // HW_ID.WAVE_ID
+    for (int i = 0; i < (slot % 3) * 2; i++) __builtin_amdgcn_s_sleep(70);
+  }
+#endif
 
-  // global -> register staging: 128 rows x MK k per operand; a thread covers rows lrow0 + (256 / KQ) * i
+  // global -> register staging: 128 rows x 16 k per operand; a thread covers rows lrow0 and lrow0 + 64
   constexpr int KQ = MK / 4, RS = ETHREADS / KQ, NL = EBM / RS;   // float4 per row, rows per pass, passes
   const int lrow0 = tid / KQ, lk = (tid % KQ) * 4;
   const float *ga = M + (long long)(m0 + lrow0) * ld + lk;
   const float *gb = Q + (long long)(n0 + lrow0) * ld + lk;
   const long long rstep = (long long)RS * ld;
-  f32x4 ra[NL], rb[NL];
+  // two staging sets: slab s+2 is requested while slab s+1 still waits in registers for its LDS buffer, i.e. a
+  // load has two slabs of matrix work (>= 4096 cycles) to arrive -- one slab is not enough for a miss of the XCD's L2
+  struct Stage { f32x4 a[NL], b[NL]; };
+  Stage st0, st1;
+  int next_slab = 0;                    // the slab ga / gb point to
+  auto stage_load = [&](Stage &st, int nslab) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) {
-    ra[i] = *(const f32x4 *)(ga + i * rstep);
-    rb[i] = *(const f32x4 *)(gb + i * rstep);
-  }
+    for (int i = 0; i < NL; i++) {
+      st.a[i] = *(const f32x4 *)(ga + i * rstep);
+      st.b[i] = *(const f32x4 *)(gb + i * rstep);
+    }
+    const int adv = next_slab + 1 < nslab ? MK : 0;     // never past the last slab (a repeated load is never stored)
+    next_slab++;
+    ga += adv;
+    gb += adv;
+  };
+  auto stage_store = [&](const Stage &st, int buf) {
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        As[buf][lk + e][lrow0 + RS * i] = st.a[i][e];
+        Bs[buf][lk + e][lrow0 + RS * i] = st.b[i][e];
+      }
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -230,79 +281,169 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
   const int lk2 = lane >> 5, l32 = lane & 31;
-  const int nk = ld / MK;
-  for (int kt = 0; kt < nk; kt++) {
-    const int buf = kt & 1;
+  // fragments of one half: k-pair p of half h is k = 8 h + 2 p + (lane / 32)
+  auto read_half = [&](float (&fa)[4][2], float (&fq)[4][2], int buf, int h) {
 #pragma unroll
-    for (int i = 0; i < NL; i++)
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        As[buf][lk + e][lrow0 + RS * i] = ra[i][e];
-        Bs[buf][lk + e][lrow0 + RS * i] = rb[i][e];
-      }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      ga += MK;
-      gb += MK;
-#pragma unroll
-      for (int i = 0; i < NL; i++) {
-        ra[i] = *(const f32x4 *)(ga + i * rstep);
-        rb[i] = *(const f32x4 *)(gb + i * rstep);
-      }
+    for (int p = 0; p < 4; p++) {
+      const int k = h * 8 + 2 * p + lk2;
+      fa[p][0] = As[buf][k][wm + l32];
+      fa[p][1] = As[buf][k][wm + 32 + l32];
+      fq[p][0] = Bs[buf][k][wn + l32];
+      fq[p][1] = Bs[buf][k][wn + 32 + l32];
     }
-    // all fragments of the slab first (the LDS latency is paid once per slab, not once per four MFMAs)
+  };
+  auto mma_pairs = [&](const float (&fa)[4][2], const float (&fq)[4][2], int p0, int p1) {
 #pragma unroll
-    for (int g = 0; g < MK / 16; g++) {         // groups of 8 k-pairs: 32 fragment registers live at a time
-      float fa[8][2], fq[8][2];
+    for (int p = p0; p < p1; p++) {             // strictly increasing k: the chain order of the reference
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p][0], fq[p][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p][0], fq[p][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p][1], fq[p][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p][1], fq[p][1], acc[1][1], 0, 0, 0);
+    }
+  };
+  auto mma_half = [&](const float (&fa)[4][2], const float (&fq)[4][2]) { mma_pairs(fa, fq, 0, 4); };
+#define W2B_PIN() __builtin_amdgcn_sched_barrier(0)    /* the machine scheduler would re-serialise the pipeline */
+
+  // the question words of this lane's two questions (excluded from the arg-max, ref :169-171): fetched now, used
+  // in the epilogue
+  int qw[2][3];
 #pragma unroll
-      for (int p = 0; p < 8; p++) {
-        const int k = g * 16 + 2 * p + lk2;
-        fa[p][0] = As[buf][k][wm + l32];
-        fa[p][1] = As[buf][k][wm + 32 + l32];
-        fq[p][0] = Bs[buf][k][wn + l32];
-        fq[p][1] = Bs[buf][k][wn + 32 + l32];
-      }
-      __builtin_amdgcn_sched_barrier(0);        // keep the reads ahead of the MFMAs (the scheduler would sink them)
-#pragma unroll
-      for (int p = 0; p < 8; p++) {             // strictly increasing k: the chain order of the reference
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p][0], fq[p][0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p][0], fq[p][1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p][1], fq[p][0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p][1], fq[p][1], acc[1][1], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+  for (int nt = 0; nt < 2; nt++) {
+    const int q = n0 + wn + nt * 32 + l32;
+    qw[nt][0] = q < nq ? b1[q] : -1;
+    qw[nt][1] = q < nq ? b2[q] : -1;
+    qw[nt][2] = q < nq ? b3[q] : -1;
+  }
+  const int nslab = (nh + 1) >> 1;
+  float f0a[4][2], f0q[4][2], f1a[4][2], f1q[4][2];
+#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 32)
+  for (int p = 0; p < 4; p++) for (int j = 0; j < 2; j++) { f1a[p][j] = lane * 0.5f + p; f1q[p][j] = lane * 0.25f - j; }
+#endif
+  stage_load(st0, nslab);
+  stage_store(st0, 0);
+  __syncthreads();
+  W2B_ETICK(0);
+  stage_load(st0, nslab);               // slab 1
+  stage_load(st1, nslab);               // slab 2
+  read_half(f0a, f0q, 0, 0);
+  // steady state, free of branches so that the wait counters stay exact: slab kt has both halves and a successor,
+  // which waits in `st`
+  auto slab = [&](int kt, Stage &st) {
+    const int buf = kt & 1;
+    if (!(W2B_EVAL_EXP & 32)) read_half(f1a, f1q, buf, 1);        // arrives while the matrix pipe works on f0
+    W2B_PIN();
+    mma_pairs(f0a, f0q, 0, 3);
+    W2B_PIN();
+    if (!(W2B_EVAL_EXP & 8)) stage_store(st, buf ^ 1);           // buf^1 was last read two halves ago, before the previous barrier
+    W2B_PIN();
+    mma_pairs(f0a, f0q, 3, 4);          // the staging writes complete under these four
+    W2B_PIN();
+    if (!(W2B_EVAL_EXP & 16)) __syncthreads();
+    if (!(W2B_EVAL_EXP & 2)) stage_load(st, nslab);              // slab kt + 3
+    if (!(W2B_EVAL_EXP & 32)) read_half(f0a, f0q, buf ^ 1, 0);    // arrives while the matrix pipe works on f1
+    W2B_PIN();
+    mma_half(f1a, f1q);
+    W2B_PIN();
+  };
+  int kt = 0;
+  for (; kt + 2 < nslab; kt += 2) {
+    slab(kt, st0);
+    slab(kt + 1, st1);
+  }
+  if (kt + 1 < nslab) slab(kt, st0);
+  {                                     // last slab: one half when nh is odd
+    const int buf = (nslab - 1) & 1;
+    if (nh & 1) {
+      mma_half(f0a, f0q);
+    } else {
+      read_half(f1a, f1q, buf, 1);
+      mma_half(f0a, f0q);
+      mma_half(f1a, f1q);
     }
   }
 
+#undef W2B_PIN
+  W2B_ETICK(1);
   // epilogue (ref :166-175, N = 1).  Accumulator e of tile (mt, nt) in lane l is
-  // row m = wm + mt*32 + 8*(e/4) + 4*(l/32) + e%4, question n = wn + nt*32 + l%32.
+  // row m = wm + mt*32 + 8*(e/4) + 4*(l/32) + e%4, question n = wn + nt*32 + l%32; a lane walks its rows in
+  // increasing order, so "strictly greater" keeps the lowest row among equal scores (the reference's first-wins).
+  const int r0 = m0 + wm;
+  // While other wavefronts of the SIMD stream MFMAs, an ordinary vector instruction of this one is issued about once
+  // per MFMA (measured: 55-80 cycles each, a 26 K-cycle epilogue for 25.6 K cycles of matrix work) -- unless the
+  // wavefront outranks them: a few hundred 4-cycle issue slots taken from the MFMA stream cost less than a
+  // wavefront that holds its registers and LDS four times longer.
+  if (!(W2B_EVAL_EXP & 256)) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int nt = 0; nt < 2; nt++) {
     const int nl = wn + nt * 32 + l32, q = n0 + nl;
     const bool live = q < nq;
-    const int e1 = live ? b1[q] : -1, e2 = live ? b2[q] : -1, e3 = live ? b3[q] : -1;
+    const int e1 = qw[nt][0], e2 = qw[nt][1], e3 = qw[nt][2];
+#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
+    if (e1 + e2 + e3 == -12345) skey[0] = 1;
+    W2B_ETICK(8 + nt * 3);
+#endif
+    // no question word of these 64 questions among this wavefront's 64 rows and no row past the vocabulary (the
+    // usual case): a float compare and two selects per accumulator
+    const bool excl = (unsigned)(e1 - r0) < 64u || (unsigned)(e2 - r0) < 64u || (unsigned)(e3 - r0) < 64u;
     unsigned long long key = 0ull;
+#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 1)
+    if (acc[0][nt][0] + acc[1][nt][5] == 123.f) key = 5ull;
+    else if (false) {
+#else
+    if (r0 + 64 <= words && !__any(excl)) {
+#endif
+      float bd = 0.f;
+      int bo = 0;
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+      for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int c = m0 + wm + mt * 32 + 8 * (e >> 2) + 4 * lk2 + (e & 3);
-        const float d = acc[mt][nt][e];
-        if (live && c < words && c != e1 && c != e2 && c != e3 && d > 0.f) {
-          const unsigned long long k2 =
-              ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c);
-          key = k2 > key ? k2 : key;
+        for (int e = 0; e < 16; e++) {
+          const float d = acc[mt][nt][e];
+          const bool g = d > bd;                       // NaN fails like `dist > bestd`
+          bd = g ? d : bd;
+          bo = g ? mt * 32 + 8 * (e >> 2) + (e & 3) : bo;
         }
-      }
+      if (live && bd > 0.f)
+        key = ((unsigned long long)__float_as_uint(bd) << 32) |
+              (unsigned long long)(0xFFFFFFFFu - (unsigned)(r0 + 4 * lk2 + bo));
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int c = r0 + mt * 32 + 8 * (e >> 2) + 4 * lk2 + (e & 3);
+          const float d = acc[mt][nt][e];
+          if (live && c < words && c != e1 && c != e2 && c != e3 && d > 0.f) {
+            const unsigned long long k2 =
+                ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c);
+            key = k2 > key ? k2 : key;
+          }
+        }
+    }
+    if (key == 77ull) skey[1] = 1;
+    W2B_ETICK(9 + nt * 3);
     const unsigned long long other = __shfl_xor(key, 32, 64);
     key = other > key ? other : key;
     if (lk2 == 0 && key) atomicMax(&skey[nl], key);
+    W2B_ETICK(10 + nt * 3);
   }
   __syncthreads();
   if (tid < EBN && skey[tid] && n0 + tid < nq) atomicMax(&best[n0 + tid], skey[tid]);
+  W2B_ETICK(2);
+#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
+  if (tid == 0) atomicMax(&g_eval_ticks[6], tk_);
+#endif
 }
 
 }  // namespace
+#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
+extern "C" int w2b_debug_eval_ticks(unsigned long long *out, int reset) {
+  unsigned long long z[16] = {0, 0, 0, 0, 0, ~0ull, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eval_ticks), 128) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_eval_ticks), z, 128) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------ launchers
 hipError_t w2b_launch_eval_normalize(float *M, long long words, long long size, long long ld, int bitlevel,
@@ -330,7 +471,7 @@ hipError_t w2b_launch_eval_queries(const float *M, long long ld, long long nq, c
   return hipGetLastError();
 }
 
-hipError_t w2b_launch_eval_scores(const float *Q, const float *M, int nq, int words, int ld, int fused,
+hipError_t w2b_launch_eval_scores(const float *Q, const float *M, int nq, int words, int size, int ld, int fused,
                                   const int *b1, const int *b2, const int *b3, unsigned long long *best,
                                   int variant, hipStream_t s) {
   if (nq <= 0 || words <= 0) return hipSuccess;
@@ -341,12 +482,8 @@ hipError_t w2b_launch_eval_scores(const float *Q, const float *M, int nq, int wo
     int g = variant > 1 ? variant : 8;
     if (g > q_tiles) g = q_tiles;
     const long long grid2 = 8ll * c_per_xcd * ((q_tiles + g - 1) / g * g);
-    if (ld % 32 == 0 && getenv("W2B_EVAL_MK32"))   // experiment: fewer barriers, half the occupancy -- slower
-      hipLaunchKernelGGL(k_eval_scores_mfma<32>, dim3((unsigned)grid2), dim3(ETHREADS), 0, s, Q, M, nq, words, ld,
-                         q_tiles, c_tiles, c_per_xcd, g, b1, b2, b3, best);
-    else
-      hipLaunchKernelGGL(k_eval_scores_mfma<16>, dim3((unsigned)grid2), dim3(ETHREADS), 0, s, Q, M, nq, words, ld,
-                         q_tiles, c_tiles, c_per_xcd, g, b1, b2, b3, best);
+    hipLaunchKernelGGL(k_eval_scores_mfma, dim3((unsigned)grid2), dim3(ETHREADS), 0, s, Q, M, nq, words, ld,
+                       (size + 7) / 8, q_tiles, c_tiles, c_per_xcd, g, b1, b2, b3, best);
   }
   else if (fused)
     hipLaunchKernelGGL((k_eval_scores<true>), dim3((unsigned)grid), dim3(ETHREADS), 0, s, Q, M, nq, words, ld,
