@@ -185,36 +185,32 @@ k_eval_scores(const float *__restrict__ Q, const float *__restrict__ M, int nq, 
 // purpose: a lane then holds ONE question (column) and 16 rows per tile, so the arg-max over rows is mostly
 // in-lane; one exchange with lane^32 and one ds_max_u64 finish it.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifndef W2B_EVAL_EXP
-#define W2B_EVAL_EXP 0
-#endif
-#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
-__device__ unsigned long long g_eval_ticks[16];
-#define W2B_ETICK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_eval_ticks[i], n_ - tk_); tk_ = n_; } while (0)
-#else
-#define W2B_ETICK(i) do { } while (0)
-#endif
 
-// Software pipeline (the unit is HALF a slab = 8 k = 4 MFMA k-pairs x 4 tiles = 16 MFMAs = 1024 matrix-pipe
-// cycles per wavefront): while the 16 MFMAs of one half issue, the fragments of the next half are read from LDS, and
-// the slab after that is written to the other LDS buffer -- so the LDS latency, the staging writes and the global
-// loads all sit in the shadow of the matrix pipe and only the skew of the one barrier per slab is exposed.  `nh`
-// halves are walked, nh = ceil(size / 8): the zero columns that pad a row to a multiple of 16 are never multiplied.
+// What the matrix pipe leaves to everything else (tools/mfma_probe.hip; matrix-pipe cycles taken from a saturated
+// stream of these 64-cycle MFMAs, three wavefronts per SIMD): an ordinary vector instruction ~4, ds_write2_b32 ~3.5,
+// ds_read2_b32 ~2, buffer_load_dwordx4 with a 32-bit offset ~12, global_load_dwordx4 with a 64-bit address pair ~50.
+// And a wavefront OUTSIDE its MFMA loop gets a vector instruction issued only about once per MFMA of the others
+// (55-80 cycles each, s_setprio changes nothing): a 250-instruction arg-max lasts 17 K cycles next to 25.6 K cycles
+// of matrix work, and for that long its SIMD has one MFMA stream fewer.  Hence:
+//   * software pipeline with HALF a slab (8 k = 4 MFMA k-pairs x 4 tiles = 16 MFMAs = 1024 matrix cycles) as the unit:
+//     fragment reads of the next half, staging writes of the next slab and the loads of the slab after it are
+//     issued under the MFMAs of the current half; one barrier per slab.  `nh` halves, nh = ceil(size / 8): the zero
+//     columns that pad a row to a multiple of 16 are never multiplied;
+//   * loads through buffer descriptors of the two 128-row operand tiles, one 32-bit lane offset for both and the
+//     slab / row-block advance in scalar registers: no vector instruction computes an address in the loop;
+//   * an arg-max that usually ends after 40 instructions: the lane maxima (v_max3) are compared with the best key
+//     the question already has in memory; only a wavefront that can still improve one scans for row numbers.
 __global__ void __launch_bounds__(ETHREADS, 2)
 k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int nq, int words, int ld, int nh,
                    int q_tiles, int c_tiles, int c_per_xcd, int q_group, const int *__restrict__ b1,
                    const int *__restrict__ b2, const int *__restrict__ b3, unsigned long long *__restrict__ best) {
   constexpr int MK = 16;
-  // row pitch 130 floats: the staging writes of a 32-lane group (4 k-quads x 8 rows) then fall on 32 different banks
+  // row pitch 130 floats: the staging writes of a 32-lane group (4 k-quads x 8 rows) fall on 32 different banks
   // (4 * 130 = 8 mod 32); the fragment reads are 32 consecutive floats of one k row whatever the pitch
   constexpr int MLD = EBM + 2;
   __shared__ float As[2][MK][MLD];       // rows of M
   __shared__ float Bs[2][MK][MLD];       // questions
   __shared__ unsigned long long skey[EBN];
-#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 64)
-  __shared__ float occupancy_pad[6000];          // 24 KB more: two workgroups per CU
-  if (nq < 0) occupancy_pad[threadIdx.x] = 1.f, best[0] = (unsigned long long)occupancy_pad[threadIdx.x ^ 1];
-#endif
 
   // XCD-aware order: an XCD owns a stripe of row tiles; inside it consecutive workgroups take `q_group` question
   // tiles of ONE row tile before moving to the next row tile, so a row tile fetched into that XCD's L2 is reused
@@ -227,40 +223,47 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  const int lk2 = lane >> 5, l32 = lane & 31;
   if (tid < EBN) skey[tid] = 0ull;
-#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
-  unsigned long long tk_ = __builtin_readcyclecounter();
-  if (tid == 0) { atomicAdd(&g_eval_ticks[4], 1ull); atomicMin(&g_eval_ticks[5], tk_); }
-#endif
-#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 4)
-  // first generation of workgroups: stagger the ones that share a CU by a third of a tile each
-  if (blockIdx.x < 1024) {
-    const int slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));      // HW_ID.WAVE_ID
-    for (int i = 0; i < (slot % 3) * 2; i++) __builtin_amdgcn_s_sleep(70);
+
+  // what the epilogue needs from memory, requested now: the question words of this lane's two questions (excluded
+  // from the arg-max, ref :169-171) and the best key each question has so far (possibly stale: then it is only lower)
+  int qw[2][3];
+  unsigned long long seen[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const int q = n0 + wn + nt * 32 + l32;
+    qw[nt][0] = q < nq ? b1[q] : -1;
+    qw[nt][1] = q < nq ? b2[q] : -1;
+    qw[nt][2] = q < nq ? b3[q] : -1;
+    seen[nt] = q < nq ? __hip_atomic_load(&best[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
   }
-#endif
 
   // global -> register staging: 128 rows x 16 k per operand; a thread covers rows lrow0 and lrow0 + 64
   constexpr int KQ = MK / 4, RS = ETHREADS / KQ, NL = EBM / RS;   // float4 per row, rows per pass, passes
   const int lrow0 = tid / KQ, lk = (tid % KQ) * 4;
-  const float *ga = M + (long long)(m0 + lrow0) * ld + lk;
-  const float *gb = Q + (long long)(n0 + lrow0) * ld + lk;
-  const long long rstep = (long long)RS * ld;
+  const int tile_bytes = EBM * ld * 4, rstep_bytes = RS * ld * 4;
+  const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(M + (long long)m0 * ld), 0, tile_bytes, 0x27000);
+  const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(Q + (long long)n0 * ld), 0, tile_bytes, 0x27000);
+  const int voff = (lrow0 * ld + lk) * 4;
   // two staging sets: slab s+2 is requested while slab s+1 still waits in registers for its LDS buffer, i.e. a
   // load has two slabs of matrix work (>= 4096 cycles) to arrive -- one slab is not enough for a miss of the XCD's L2
   struct Stage { f32x4 a[NL], b[NL]; };
   Stage st0, st1;
-  int next_slab = 0;                    // the slab ga / gb point to
+  int next_slab = 0, slab_off = 0;      // the slab the next stage_load fetches and its byte offset in a row
   auto stage_load = [&](Stage &st, int nslab) {
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-      st.a[i] = *(const f32x4 *)(ga + i * rstep);
-      st.b[i] = *(const f32x4 *)(gb + i * rstep);
+      const u32x4 ta = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, voff, slab_off + i * rstep_bytes, 0);
+      const u32x4 tb = __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, voff, slab_off + i * rstep_bytes, 0);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        st.a[i][e] = __uint_as_float(ta[e]);
+        st.b[i][e] = __uint_as_float(tb[e]);
+      }
     }
-    const int adv = next_slab + 1 < nslab ? MK : 0;     // never past the last slab (a repeated load is never stored)
+    slab_off += next_slab + 1 < nslab ? MK * 4 : 0;     // never past the last slab (a repeated load is never stored)
     next_slab++;
-    ga += adv;
-    gb += adv;
   };
   auto stage_store = [&](const Stage &st, int buf) {
 #pragma unroll
@@ -280,7 +283,6 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  const int lk2 = lane >> 5, l32 = lane & 31;
   // fragments of one half: k-pair p of half h is k = 8 h + 2 p + (lane / 32)
   auto read_half = [&](float (&fa)[4][2], float (&fq)[4][2], int buf, int h) {
 #pragma unroll
@@ -304,25 +306,11 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
   auto mma_half = [&](const float (&fa)[4][2], const float (&fq)[4][2]) { mma_pairs(fa, fq, 0, 4); };
 #define W2B_PIN() __builtin_amdgcn_sched_barrier(0)    /* the machine scheduler would re-serialise the pipeline */
 
-  // the question words of this lane's two questions (excluded from the arg-max, ref :169-171): fetched now, used
-  // in the epilogue
-  int qw[2][3];
-#pragma unroll
-  for (int nt = 0; nt < 2; nt++) {
-    const int q = n0 + wn + nt * 32 + l32;
-    qw[nt][0] = q < nq ? b1[q] : -1;
-    qw[nt][1] = q < nq ? b2[q] : -1;
-    qw[nt][2] = q < nq ? b3[q] : -1;
-  }
   const int nslab = (nh + 1) >> 1;
   float f0a[4][2], f0q[4][2], f1a[4][2], f1q[4][2];
-#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 32)
-  for (int p = 0; p < 4; p++) for (int j = 0; j < 2; j++) { f1a[p][j] = lane * 0.5f + p; f1q[p][j] = lane * 0.25f - j; }
-#endif
   stage_load(st0, nslab);
   stage_store(st0, 0);
   __syncthreads();
-  W2B_ETICK(0);
   stage_load(st0, nslab);               // slab 1
   stage_load(st1, nslab);               // slab 2
   read_half(f0a, f0q, 0, 0);
@@ -330,17 +318,17 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
   // which waits in `st`
   auto slab = [&](int kt, Stage &st) {
     const int buf = kt & 1;
-    if (!(W2B_EVAL_EXP & 32)) read_half(f1a, f1q, buf, 1);        // arrives while the matrix pipe works on f0
+    read_half(f1a, f1q, buf, 1);        // arrives while the matrix pipe works on f0
     W2B_PIN();
     mma_pairs(f0a, f0q, 0, 3);
     W2B_PIN();
-    if (!(W2B_EVAL_EXP & 8)) stage_store(st, buf ^ 1);           // buf^1 was last read two halves ago, before the previous barrier
+    stage_store(st, buf ^ 1);           // buf^1 was last read two halves ago, before the previous barrier
     W2B_PIN();
     mma_pairs(f0a, f0q, 3, 4);          // the staging writes complete under these four
     W2B_PIN();
-    if (!(W2B_EVAL_EXP & 16)) __syncthreads();
-    if (!(W2B_EVAL_EXP & 2)) stage_load(st, nslab);              // slab kt + 3
-    if (!(W2B_EVAL_EXP & 32)) read_half(f0a, f0q, buf ^ 1, 0);    // arrives while the matrix pipe works on f1
+    __syncthreads();
+    stage_load(st, nslab);              // slab kt + 3
+    read_half(f0a, f0q, buf ^ 1, 0);    // arrives while the matrix pipe works on f1
     W2B_PIN();
     mma_half(f1a, f1q);
     W2B_PIN();
@@ -361,37 +349,33 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
       mma_half(f1a, f1q);
     }
   }
-
 #undef W2B_PIN
-  W2B_ETICK(1);
+
   // epilogue (ref :166-175, N = 1).  Accumulator e of tile (mt, nt) in lane l is
   // row m = wm + mt*32 + 8*(e/4) + 4*(l/32) + e%4, question n = wn + nt*32 + l%32; a lane walks its rows in
   // increasing order, so "strictly greater" keeps the lowest row among equal scores (the reference's first-wins).
   const int r0 = m0 + wm;
-  // While other wavefronts of the SIMD stream MFMAs, an ordinary vector instruction of this one is issued about once
-  // per MFMA (measured: 55-80 cycles each, a 26 K-cycle epilogue for 25.6 K cycles of matrix work) -- unless the
-  // wavefront outranks them: a few hundred 4-cycle issue slots taken from the MFMA stream cost less than a
-  // wavefront that holds its registers and LDS four times longer.
-  if (!(W2B_EVAL_EXP & 256)) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int nt = 0; nt < 2; nt++) {
     const int nl = wn + nt * 32 + l32, q = n0 + nl;
     const bool live = q < nq;
     const int e1 = qw[nt][0], e2 = qw[nt][1], e3 = qw[nt][2];
-#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
-    if (e1 + e2 + e3 == -12345) skey[0] = 1;
-    W2B_ETICK(8 + nt * 3);
-#endif
-    // no question word of these 64 questions among this wavefront's 64 rows and no row past the vocabulary (the
+    // can any of this wavefront's 64 x 32 scores still improve its question's key?  A key orders by (score, lower
+    // row): a score below the one already recorded never does; an equal one only with a lower row (another XCD's
+    // stripe may have recorded a higher row first), so "greater or equal" goes on to the exact comparison.
+    float m = acc[0][nt][0];
+#pragma unroll
+    for (int e = 1; e < 15; e += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[0][nt][e]), acc[0][nt][e + 1]);
+    m = __builtin_fmaxf(m, acc[0][nt][15]);
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[1][nt][e]), acc[1][nt][e + 1]);
+    const bool may = live && m > 0.f && __float_as_uint(m) >= (unsigned)(seen[nt] >> 32);     // (NaN: m > 0 fails)
+    if (!__any(may)) continue;
+    // no question word of these 32 questions among this wavefront's 64 rows and no row past the vocabulary (the
     // usual case): a float compare and two selects per accumulator
     const bool excl = (unsigned)(e1 - r0) < 64u || (unsigned)(e2 - r0) < 64u || (unsigned)(e3 - r0) < 64u;
     unsigned long long key = 0ull;
-#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 1)
-    if (acc[0][nt][0] + acc[1][nt][5] == 123.f) key = 5ull;
-    else if (false) {
-#else
     if (r0 + 64 <= words && !__any(excl)) {
-#endif
       float bd = 0.f;
       int bo = 0;
 #pragma unroll
@@ -420,30 +404,15 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
           }
         }
     }
-    if (key == 77ull) skey[1] = 1;
-    W2B_ETICK(9 + nt * 3);
     const unsigned long long other = __shfl_xor(key, 32, 64);
     key = other > key ? other : key;
-    if (lk2 == 0 && key) atomicMax(&skey[nl], key);
-    W2B_ETICK(10 + nt * 3);
+    if (lk2 == 0 && key > seen[nt]) atomicMax(&skey[nl], key);
   }
   __syncthreads();
   if (tid < EBN && skey[tid] && n0 + tid < nq) atomicMax(&best[n0 + tid], skey[tid]);
-  W2B_ETICK(2);
-#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
-  if (tid == 0) atomicMax(&g_eval_ticks[6], tk_);
-#endif
 }
 
 }  // namespace
-#if defined(W2B_EVAL_EXP) && (W2B_EVAL_EXP & 128)
-extern "C" int w2b_debug_eval_ticks(unsigned long long *out, int reset) {
-  unsigned long long z[16] = {0, 0, 0, 0, 0, ~0ull, 0, 0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eval_ticks), 128) != hipSuccess) return 1;
-  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_eval_ticks), z, 128) != hipSuccess) return 1;
-  return 0;
-}
-#endif
 
 // ------------------------------------------------------------------------------------ launchers
 hipError_t w2b_launch_eval_normalize(float *M, long long words, long long size, long long ld, int bitlevel,
