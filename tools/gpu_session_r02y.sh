@@ -5,4 +5,4 @@ timeout 900 python -m pytest tests/test_gpu_eval.py -m gpu -q --no-header -p no:
 for dim in 104 200 400 808; do
   timeout 300 python bench.py --form eval --cpu-baseline none --dim $dim --steps 6 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print($dim, d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['answers_differ_between_modes'])"
 done
-timeout 300 python bench.py --form eval --cpu-baseline none --eval-kind gauss --steps 6 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('gauss', d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['answers_differ_between_modes'])"
+timeout 300 python bench.py --form eval --cpu-baseline none --eval-kind fp --steps 6 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fp', d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['answers_differ_between_modes'])"

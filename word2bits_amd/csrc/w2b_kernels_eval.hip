@@ -185,6 +185,7 @@ k_eval_scores(const float *__restrict__ Q, const float *__restrict__ M, int nq, 
 // purpose: a lane then holds ONE question (column) and 16 rows per tile, so the arg-max over rows is mostly
 // in-lane; one exchange with lane^32 and one ds_max_u64 finish it.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) volatile float lds_vf;
 
 // What the matrix pipe leaves to everything else (tools/mfma_probe.hip; matrix-pipe cycles taken from a saturated
 // stream of these 64-cycle MFMAs, three wavefronts per SIMD): an ordinary vector instruction ~4, ds_write2_b32 ~3.5,
@@ -199,8 +200,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   * loads through buffer descriptors of the two 128-row operand tiles, one 32-bit lane offset for both and the
 //     slab / row-block advance in scalar registers: no vector instruction computes an address in the loop;
 //   * an arg-max that usually ends after 40 instructions: the lane maxima (v_max3) are compared with the best key
-//     the question already has in memory; only a wavefront that can still improve one scans for row numbers.
-__global__ void __launch_bounds__(ETHREADS, 2)
+//     the question already has in memory; only a wavefront that can still improve one scans for row numbers;
+//   * fragments through single ds_read_b32 (volatile keeps them from being merged): 16-bit offsets from ONE address
+//     register per operand, where ds_read2_b32 (8-bit offsets) needs one per k row -- ~50 registers, the difference
+//     between two and THREE workgroups per CU (168 registers), which is worth +6 % here: a workgroup's prologue
+//     (~5 K cycles), its arg-max and the ~6 K cycles until its successor starts in the same slot are covered by
+//     two other workgroups instead of one.  At most 8 reads per burst: the LDS wait counter has four bits.
+// Measured and rejected: persistent workgroups that walk their tiles as one slab stream
+// (with or without the arg-max of tile t riding between the MFMAs of tile t+1): 5-10 % slower than this.
+__global__ void __launch_bounds__(ETHREADS, 3)
 k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int nq, int words, int ld, int nh,
                    int q_tiles, int c_tiles, int c_per_xcd, int q_group, const int *__restrict__ b1,
                    const int *__restrict__ b2, const int *__restrict__ b3, unsigned long long *__restrict__ best) {
@@ -284,16 +292,17 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
   // fragments of one half: k-pair p of half h is k = 8 h + 2 p + (lane / 32)
-  auto read_half = [&](float (&fa)[4][2], float (&fq)[4][2], int buf, int h) {
+  auto read_pairs = [&](float (&fa)[4][2], float (&fq)[4][2], int buf, int h, int p0, int p1) {
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
+    for (int p = p0; p < p1; p++) {
       const int k = h * 8 + 2 * p + lk2;
-      fa[p][0] = As[buf][k][wm + l32];
-      fa[p][1] = As[buf][k][wm + 32 + l32];
-      fq[p][0] = Bs[buf][k][wn + l32];
-      fq[p][1] = Bs[buf][k][wn + 32 + l32];
+      fa[p][0] = *(lds_vf *)&As[buf][k][wm + l32];
+      fa[p][1] = *(lds_vf *)&As[buf][k][wm + 32 + l32];
+      fq[p][0] = *(lds_vf *)&Bs[buf][k][wn + l32];
+      fq[p][1] = *(lds_vf *)&Bs[buf][k][wn + 32 + l32];
     }
   };
+  auto read_half = [&](float (&fa)[4][2], float (&fq)[4][2], int buf, int h) { read_pairs(fa, fq, buf, h, 0, 4); };
   auto mma_pairs = [&](const float (&fa)[4][2], const float (&fq)[4][2], int p0, int p1) {
 #pragma unroll
     for (int p = p0; p < p1; p++) {             // strictly increasing k: the chain order of the reference
@@ -318,9 +327,13 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
   // which waits in `st`
   auto slab = [&](int kt, Stage &st) {
     const int buf = kt & 1;
-    read_half(f1a, f1q, buf, 1);        // arrives while the matrix pipe works on f0
+    read_pairs(f1a, f1q, buf, 1, 0, 2);
     W2B_PIN();
-    mma_pairs(f0a, f0q, 0, 3);
+    mma_pairs(f0a, f0q, 0, 2);
+    W2B_PIN();
+    read_pairs(f1a, f1q, buf, 1, 2, 4);
+    W2B_PIN();
+    mma_pairs(f0a, f0q, 2, 3);
     W2B_PIN();
     stage_store(st, buf ^ 1);           // buf^1 was last read two halves ago, before the previous barrier
     W2B_PIN();
@@ -328,9 +341,13 @@ k_eval_scores_mfma(const float *__restrict__ Q, const float *__restrict__ M, int
     W2B_PIN();
     __syncthreads();
     stage_load(st, nslab);              // slab kt + 3
-    read_half(f0a, f0q, buf ^ 1, 0);    // arrives while the matrix pipe works on f1
+    read_pairs(f0a, f0q, buf ^ 1, 0, 0, 2);
     W2B_PIN();
-    mma_half(f1a, f1q);
+    mma_pairs(f1a, f1q, 0, 2);
+    W2B_PIN();
+    read_pairs(f0a, f0q, buf ^ 1, 0, 2, 4);
+    W2B_PIN();
+    mma_pairs(f1a, f1q, 2, 4);
     W2B_PIN();
   };
   int kt = 0;
