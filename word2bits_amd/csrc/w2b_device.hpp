@@ -50,13 +50,13 @@ struct QParam { int bitlevel; int steps_i; float steps_f; };
 template <int QM>
 __device__ __forceinline__ float quant(float x, const QParam &q) {
   if (QM == 0) return x;
+  if (QM == 2) {                                       // ref :80,:91-94 in four instructions (|x| is an operand modifier):
+    const float lvl = (__builtin_fabsf(x) <= .5f) ? .25f : .75f;   // mag = x * sgn = |x|; NaN fails the compare -> .75
+    return (x < 0.f) ? -lvl : lvl;                     // +0, -0, NaN -> + (ref :80)
+  }
   const float sgn = (x < 0.f) ? -1.f : 1.f;          // +0, -0, NaN -> +1 (ref :80)
   if (QM == 1) return sgn / 3.f;                      // ref :85-87
   const float mag = x * sgn;
-  if (QM == 2) {                                       // ref :91-94
-    const float lvl = (mag >= 0.f && mag <= .5f) ? .25f : .75f;
-    return sgn * lvl;
-  }
   float lvl = 0.f;                                     // bitlevel 3 falls through to +-0
   if (q.bitlevel >= 4) {                               // ref :99-104
     int k = (int)(mag * q.steps_f + .5f);              // v_cvt saturates where x86 yields INT_MIN
