@@ -125,7 +125,6 @@ static w2b_eval *eval_new(long long words, long long size, int32_t fused, int32_
   e->fused = fused ? 1 : 0;
   if (const char *env = getenv("W2B_EVAL_KERNEL")) e->variant = atoi(env);   // 0 vector ALU; 1 MFMA (default grouping); >1 MFMA with that many question tiles per row tile
   e->ld = (size + 15) / 16 * 16;
-  if (e->ld < 64) e->ld = 64;     // (the matrix kernel's pipeline is four 16-column slabs deep; zero columns change nothing)
   e->rows_padded = (words + kTile - 1) / kTile * kTile;
   if (e->rows_padded == 0) e->rows_padded = kTile;
   e->vocab.assign((size_t)(words * kMaxW + kMaxW + 2), 0);
