@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's profile session (run through gpurun): default bench line, rocprofv3 kernel stats and the PMC passes of
-# the SAME command, the cfg5-shape line + stats, the evaluator.  Summaries are copied to profiles/ by hand afterwards.
+# the SAME command, the cfg5-shape line + stats, the evaluator, the tuples form, the matrix-pipe probe.  Summaries are copied to profiles/ by hand afterwards.
 set +e
 RND=${RND:-r02}
 OUT=gpurun_out/${RND}_profile
@@ -27,5 +27,11 @@ echo "== evaluator"
 timeout 300 python bench.py --form eval --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/eval_bench.json; cut -c1-300 $OUT/eval_bench.json
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_eval -o $RND -- python $R/bench.py --form eval --steps 5 --warmup 1 --eval-cpu-questions 0 > /dev/null 2>&1)
 head -3 $OUT/prof_eval/${RND}_kernel_stats.csv | cut -c1-200
+echo "== tuples form (coherent rows)"
+timeout 300 python bench.py --form tuples --cpu-baseline none 2>/dev/null | tail -1 > $OUT/bench_tuples.json; cut -c1-300 $OUT/bench_tuples.json
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_stats_tuples -o $RND -- python $R/bench.py --form tuples --steps 8 --warmup 2 --cpu-baseline none --also-relaxed 0 > /dev/null 2>&1)
+head -3 $OUT/prof_stats_tuples/${RND}_kernel_stats.csv | cut -c1-250
+echo "== f32 matrix pipe probe"
+hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_probe tools/mfma_probe.hip 2>/dev/null && timeout 120 /tmp/mfma_probe 20000 > $OUT/mfma_probe.txt 2>&1; tail -3 $OUT/mfma_probe.txt
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
 echo "== done"
