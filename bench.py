@@ -298,11 +298,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # (test hook for 1-GPU boxes: W2B_BENCH_SHARE_GPU=1 puts every rank on the devices that exist and
+    # W2B_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device -- the N > 1 control flow of this
+    # file can then be smoke-tested; such a line says so in `config.replica_sync` and is not a measurement)
+    shared = os.environ.get("W2B_BENCH_SHARE_GPU") == "1"
+    if shared:
+        local_rank %= torch.cuda.device_count()
+    backend = os.environ.get("W2B_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     V, D, W, K = args.vocab, args.dim, args.window, args.negative
     cw = W + 1                                   # mean context words at window W
     gen = torch.Generator(device=dev)
@@ -350,11 +360,11 @@ def main():
         # torch.distributed.run set up (default) or through the library's own communicator
         ok = torch.ones(1, device=dev)
         try:
-            if args.sync_impl != "lib":
+            if args.sync_impl != "lib" or shared:
                 raise RuntimeError("torch sync requested")
             t.comm_init(world, rank, replicas.exchange_unique_id(dist, rank, w2b.comm_unique_id))
         except Exception as e:
-            if args.sync_impl == "lib":
+            if args.sync_impl == "lib" and not shared:
                 print("rank %d: library RCCL init failed (%r), using torch.distributed" % (rank, e), file=sys.stderr)
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -362,7 +372,8 @@ def main():
             torch_sync = replicas.TorchReplicaSync(dist, args.sync_mode)
             model_view = t.model_tensor()
             base_view = model_view.clone()
-            sync_impl = "torch.distributed all_reduce (RCCL) on a view of [u||v]"
+            sync_impl = "torch.distributed all_reduce (%s) on a view of [u||v]%s" % (
+                "RCCL" if backend == "nccl" else backend, " -- SMOKE TEST: ranks share GPUs, not a measurement" if shared else "")
         else:
             sync_impl = "library RCCL communicator (w2b_sync_replicas)"
 
@@ -452,6 +463,26 @@ def main():
                     exchange()
 
     run(0, args.warmup, False)
+    if world > 1:
+        # one untimed exchange: first-use costs of the communicator stay out of the timed region, and a library
+        # communicator that cannot exchange (all ranks must agree) is replaced by the torch.distributed path
+        ok = torch.ones(1, device=dev)
+        try:
+            exchange()
+        except Exception as e:
+            if torch_sync is not None:
+                raise
+            print("rank %d: library exchange failed (%r), using torch.distributed" % (rank, e), file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0 and torch_sync is None:
+            torch_sync = replicas.TorchReplicaSync(dist, args.sync_mode)
+            model_view = t.model_tensor()
+            base_view = model_view.clone()
+            sync_impl = "torch.distributed all_reduce (RCCL) on a view of [u||v] (library exchange failed)"
+        n_syncs[0] = 0
+        if torch_sync is None:
+            t.sync_stats()
     t.synchronize()
     t.timing_enable(True)
     t.timing_read()

@@ -184,3 +184,28 @@ def test_cli_two_gpus(gpu, tmp_path):
     words, M = read_vectors(out, 1)
     assert len(words) == 60 and np.isfinite(M).all()
     assert set(np.unique(M.view(np.uint32)).tolist()) <= {0x3EAAAAAB, 0xBEAAAAAB}
+
+
+def test_bench_two_ranks_control_flow(gpu):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on a box with one
+    GPU: W2B_BENCH_SHARE_GPU / W2B_BENCH_BACKEND=gloo put both ranks on device 0 without RCCL.  What it guards is the
+    N > 1 control flow of bench.py (global vocabulary, per-rank worker ids, untimed warm exchange, exchange inside
+    the timed region, max-over-ranks timing, one JSON line from rank 0) -- not a measurement."""
+    import json
+    import subprocess
+    import sys
+    from w2b_testlib import ROOT
+    env = dict(os.environ, W2B_BENCH_BACKEND="gloo", W2B_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--tokens", "8000000", "--vocab", "50000", "--dim", "200", "--cpu-baseline", "none",
+           "--also-relaxed", "0", "--also-legs", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["exchanges_in_timed_region"] >= 1
+    assert "SMOKE TEST" in d["config"]["replica_sync"]
+    assert d["value"] > 0 and d["cpu_baseline"] is None
