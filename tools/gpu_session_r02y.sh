@@ -1,6 +1,7 @@
 #!/bin/bash
-# what the driver runs at round end, in its order: smoke(), then the default bench line
+# hot-row merges staggered across workers vs all workers at the same steps, same box, alternating
 set +e
 export TMPDIR=/tmp
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
-timeout 900 python bench.py 2>&1 | tail -1 | cut -c1-2500
+for rep in 1 2; do for lib in "" _ns; do
+  W2B_LIB=$PWD/word2bits_amd/libword2bits_hip$lib.so timeout 300 python bench.py --cpu-baseline none --also-relaxed 0 --also-legs 0 --steps 12 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('lib$lib', d['value'], d['roofline']['frac'])"
+done; done
