@@ -405,10 +405,13 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
     // a target of at least one centre word in 10 (a coherent row sustains ~7 M read-modify-writes per second; at
     // 25 M words/s that is where its line starts to queue), at most four.  Privatising a row trades freshness for
     // speed (the first-epoch loss moves with rows x merge period), hence the short list.
+    // (W2B_HOT_CAP raises the cap: 8 gives 7 rows and +15 % at a 60 K-word, 200-float shape for +1 % of first-epoch
+    // loss drift on the text8-sized corpus -- DESIGN.md section 6; the default stays at four)
+    const int W2B_HOT_CAP = getenv("W2B_HOT_CAP") ? atoi(getenv("W2B_HOT_CAP")) : 4;
     double pw = 0, tot = 0;
     for (int64_t a = 0; a < V; a++) { pw += pow((double)cn[a], 0.75); tot += (double)cn[a]; }
     int n = 0;
-    for (int64_t a = 1; a < V && a <= 4; a++) {
+    for (int64_t a = 1; a < V && a <= W2B_HOT_CAP; a++) {
       const double rate = (pw > 0 ? t->cfg.negative * pow((double)cn[a], 0.75) / pw : 0) + (tot > 0 ? cn[a] / tot : 0);
       if (rate < 0.1) break;
       n++;
