@@ -83,6 +83,10 @@ def parse():
                          "LDS), 0 = plain kernel")
     ap.add_argument("--relaxed", type=int, default=0,
                     help="1: plain cached row accesses (not coherent between XCDs); default 0 = agent-scope (sc1)")
+    ap.add_argument("--hot-rows", type=int, default=-1,
+                    help="w2b_tuning.hot_rows_v / hot_rows_u: leading rows with per-XCD copies (-1 = from the word counts)")
+    ap.add_argument("--hot-period", type=int, default=0, help="w2b_tuning.hot_period (0 = library default)")
+    ap.add_argument("--hot-cap", type=int, default=-1, help="w2b_tuning.hot_cap (-1 = library default)")
     ap.add_argument("--eval-questions", type=int, default=19544, help="--form eval: questions (questions-words.txt)")
     ap.add_argument("--eval-kind", choices=["1bit", "fp"], default="1bit")
     ap.add_argument("--eval-cpu-questions", type=int, default=24)
@@ -92,6 +96,20 @@ def parse():
 def algorithmic_bytes_per_word(D, cw, K):
     # every touched row read once + written once, ids read once
     return 8 * D * (cw + K + 1) + 4 * (1 + cw + K)
+
+
+def workload_name(args):
+    """which BASELINE.json configuration (if any) the arguments describe"""
+    shape = (args.vocab, args.dim, args.window, args.negative)
+    if shape == (400_000, 800, 8, 24) and args.bitlevel == 1 and args.ids == "zipf":
+        return "BASELINE configs[1]" if args.tokens == 100_000_000 else "BASELINE configs[1] shape (%d tokens)" % args.tokens
+    if shape == (3_700_000, 1000, 8, 12) and args.bitlevel in (0, 1):
+        return "BASELINE configs[4] shape (one GPU of the eight)"
+    if args.dim == 200 and args.bitlevel == 1 and args.negative == 24 and args.window == 8:
+        return "BASELINE configs[0] shape (size 200, bitlevel 1) on a synthetic vocabulary"
+    if args.dim == 400 and args.bitlevel == 2 and args.negative == 24 and args.window == 8:
+        return "BASELINE configs[2] shape (size 400, bitlevel 2) on a synthetic vocabulary"
+    return "custom shape"
 
 
 def zipf_cdf(torch, V, device, uniform, shift=0):
@@ -342,17 +360,26 @@ def main():
     nw_local = workers if args.form == "worker" else 1
     worker_offset, _ = replicas.worker_plan(nw_local * world, world, rank)   # global Hogwild worker ids
 
+    tune = {}
+    if args.hot_rows >= 0:
+        tune.update(hot_rows_v=args.hot_rows, hot_rows_u=args.hot_rows)
+    if args.hot_period > 0:
+        tune["hot_period"] = args.hot_period
+    if args.hot_cap >= 0:
+        tune["hot_cap"] = args.hot_cap
+
     def make_trainer(relaxed, loss=bool(args.loss), bitlevel=args.bitlevel):
         tr = w2b.Trainer(V, D, W, K, bitlevel, num_threads=nw_local,
                          iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words * world,
                          compute_loss=loss, device=local_rank, worker_offset=worker_offset,
                          total_threads=nw_local * world, relaxed_coherence=relaxed,
-                         window_cache=wcache)
+                         window_cache=wcache, **tune)
         tr.init_net()                                  # InitNet values (LCG seed 1), ref :343-361
         tr.set_vocab_counts(counts, 100_000_000)       # 1e8-entry unigram table, ref :112-128
         return tr
 
     t = make_trainer(bool(args.relaxed))
+    tuning_used = t.get_tuning()
     sync_impl = "none (1 GPU)"
     torch_sync = None
     if world > 1:
@@ -511,10 +538,10 @@ def main():
         "value": value, "unit": "words/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: synthetic %dM-token %s stream, vocab=%d, bitlevel=%d, "
+        "config": {"workload": "%s: synthetic %dM-token %s stream, vocab=%d, bitlevel=%d, "
                                "size=%d, window=%d, negative=%d, sample=0; form=%s, %d centre words/step/GPU"
-                               % (args.tokens // 1_000_000, args.ids, V, args.bitlevel, D, W, K, args.form,
-                                  words_per_step),
+                               % (workload_name(args), args.tokens // 1_000_000, args.ids, V, args.bitlevel, D, W, K,
+                                  args.form, words_per_step),
                    "form": args.form, "vocab": V, "dim": D, "window": W, "negative": K,
                    "bitlevel": args.bitlevel, "words_per_step_per_gpu": words_per_step, "ids": args.ids,
                    "row_coherence": "relaxed (plain cached accesses)" if args.relaxed else
@@ -523,7 +550,8 @@ def main():
                                     (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl,
                    "exchanges_in_timed_region": n_syncs[0],
                    "worker_kernel": (dict(zip(("sentence_resident", "radius", "column_bytes", "workers_per_cu",
-                                               "private_hot_rows"), kinfo)) if kinfo else None),
+                                               "hot_rows_with_xcd_copies"), kinfo)) if kinfo else None),
+                   "tuning": tuning_used,
                    "workers": workers if args.form == "worker" else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,

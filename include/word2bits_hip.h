@@ -71,7 +71,8 @@ typedef struct w2b_config {
    * while a worker walks a sentence (a row is read once when it enters the window and merged back once
    * when it leaves).  Plain: every context row of every position is read from / written to memory.
    * 0 = automatic (sentence-resident for coherent rows when the window fits in LDS, plain otherwise),
-   * 1 = plain, 2 = sentence-resident whenever it fits. */
+   * 1 = plain, 2 = sentence-resident whenever it fits -- for coherent rows: with relaxed_coherence or exact_reduction
+   * set the plain kernel runs whatever this field says (w2b_worker_kernel_info tells which one a trainer uses). */
   int32_t plain_worker_kernel;
   /* 1: parity mode.  The dot product of ref :461-467 is accumulated serially in the reference's own order
    * (c = 0 .. layer1_size-1, product rounded, then added) instead of the wavefront reduction tree -- the one
@@ -101,6 +102,32 @@ float w2b_quantize(float x, int32_t bitlevel);
 /* ---- trainer lifetime ------------------------------------------------------------------ */
 int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out);
 void w2b_trainer_destroy(w2b_trainer *t);
+
+/* ---- tuning knobs --------------------------------------------------------------------------
+ * Everything that changes which code path runs or trades fidelity for speed is in this struct (round 2 read these from
+ * environment variables, which a host binding could neither set nor see).  A new trainer holds the defaults;
+ * w2b_get_tuning returns the current values, w2b_set_tuning replaces them (before the first launch, or between
+ * launches).  struct_size = sizeof(w2b_tuning) versions the struct; reserved fields must be zero.
+ *
+ * Hot rows: with coherent rows the few most frequent rows of u (context words) and v (targets) queue at their memory
+ * lines.  Rows 1..hot_rows_u / 1..hot_rows_v (the vocabulary is sorted by count) therefore get one copy per XCD, shared
+ * by all workers of the XCD through its L2, and every hot_period centre words a worker brings a few copies up to date
+ * with their master rows.  -1 = automatic: as many rows as reach a load threshold computed from
+ * the word counts of w2b_set_vocab_counts and the number of workers (0 on flat distributions and for few workers), at
+ * most hot_cap.  0 = every access goes to the master rows.  A single worker is bit-identical with and without copies. */
+typedef struct w2b_tuning {
+  int32_t struct_size;     /* sizeof(w2b_tuning) */
+  int32_t hot_rows_v;      /* -1 automatic (default), else 0..128 leading rows of v */
+  int32_t hot_rows_u;      /* same for u (plain worker kernel and tuple kernel; the sentence-resident kernel keeps context rows in LDS) */
+  int32_t hot_period;      /* centre words between two merge events of a worker; power of two; default 8 */
+  int32_t hot_cap;         /* most rows the automatic choice takes; default 64 */
+  int32_t force_row_desc;  /* 1: address rows through per-row buffer descriptors (the form tables >= 2 GiB use) on any table */
+  int32_t grid_per_cu;     /* tuple form: workgroups per CU (0 = occupancy query) */
+  int32_t mem_mode;        /* -1 = from w2b_config.relaxed_coherence (default); 0 / 1 override it */
+  int32_t reserved[8];
+} w2b_tuning;
+int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out);
+int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in);
 
 /* ---- model: u ("syn0"), v ("syn1neg"), [vocab_size][layer1_size] fp32 row-major ---------- */
 int w2b_init_net(w2b_trainer *t);                                   /* InitNet, ref :343-361 */
@@ -151,8 +178,8 @@ int w2b_suggested_threads(w2b_trainer *t, int32_t *out);
 
 /* Which form-(i) kernel w2b_train_step() runs for this trainer: *resident = 1 for the sentence-resident kernel
  * (*radius = sentence positions on either side of the centre word whose rows stay in LDS, *column_bytes = bytes
- * of a row owned by one lane, *hot_rows = leading rows of v with a private on-chip copy per worker -- chosen from
- * the word counts of w2b_set_vocab_counts: 0 on flat distributions), 0 for the plain kernel.  Any pointer may be NULL. */
+ * of a row owned by one lane), 0 for the plain kernel; *hot_rows = leading rows of v with per-XCD copies (w2b_tuning;
+ * chosen from the word counts of w2b_set_vocab_counts and num_threads: 0 on flat distributions).  Any pointer may be NULL. */
 int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t *radius, int32_t *column_bytes,
                            int32_t *workgroups_per_cu, int32_t *hot_rows);
 

@@ -2,8 +2,9 @@
 w2b_device.hpp load_col/store_col; the `MM + 8` instantiations of the sentence-resident kernel).
 
 Three layers:
-  1. the bit-exact parity tests of the small-table form re-run with W2B_FORCE_ROW_DESC=1 (the test hook that selects
-     the large-table form on any table size) -- tuple form, plain worker kernel, sentence-resident kernel;
+  1. the bit-exact parity tests of the small-table form re-run with w2b_tuning.force_row_desc = 1 (selects the
+     large-table form on any table size; `./word2bits -row-desc 1`) -- tuple form, plain worker kernel,
+     sentence-resident kernel;
   2. a genuine > 2 GiB table (V = 700 000 x D = 800: 2.24 GB per table) -- collision-free tuple batch against the
      oracle on the touched rows (bit-exact in parity mode, rounding-tight in the fast mode), every other row still
      holding its InitNet bits, and sentence-resident == plain worker kernel bit for bit on the whole 4.5 GB model;
@@ -25,7 +26,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def row_desc(monkeypatch):
-    monkeypatch.setenv("W2B_FORCE_ROW_DESC", "1")
+    monkeypatch.setitem(w2b.Trainer.default_tuning, "force_row_desc", 1)          # every Trainer the re-used tests create
+    monkeypatch.setattr(test_gpu_worker, "EXTRA_CLI", ["-row-desc", "1"])          # ... and every ./word2bits they run
 
 
 # ------------------------------------------------------------------------------- 1. forced form on small tables

@@ -162,16 +162,15 @@ def test_text8_size_threads0_resident_vs_plain_vs_reference(gpu, tmp_path_factor
     assert np.all(np.abs(res["resident"] - res["plain"]) <= np.array([0.07, 0.035, 0.025]) * np.abs(res["plain"]))
 
 
-def test_text8_size_window_residency_alone_is_loss_neutral(gpu, tmp_path_factory, monkeypatch):
+def test_text8_size_window_residency_alone_is_loss_neutral(gpu, tmp_path_factory):
     """same corpus, 128 workers, private hot rows switched off: what remains of the sentence-resident kernel (LDS window,
     scratch entries, exact-or-merge write-back) must give the plain kernel's epoch losses (measured: -58.667 M vs
     -58.675 M in the first epoch)"""
     from w2b_testlib import write_zipf_text_corpus
-    monkeypatch.setenv("W2B_HOT_ROWS", "0")
     d = tmp_path_factory.mktemp("t8b")
     corpus = write_zipf_text_corpus(str(d / "c.txt"))
     flags = dict(bitlevel=1, size=200, window=8, negative=24, iter=1)
-    r = np.array(train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "1"]))
-    p = np.array(train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "0"]))
+    r = np.array(train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "1", "-hot-rows", "0"]))
+    p = np.array(train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "0", "-hot-rows", "0"]))
     print("FIDELITY text8size threads=128 hot rows off: resident %s plain %s" % (r.tolist(), p.tolist()))
     assert np.all(np.abs(r - p) <= 0.005 * np.abs(p))

@@ -30,13 +30,13 @@ def single_step_atol(bitlevel):
     return 3 * 1.6e-4 * max_level(bitlevel) + ROUNDING_ATOL
 
 
-def make_pair(gpu, V, D, window, negative, bitlevel, reg=0.0, seed=0, table_size=20000):
+def make_pair(gpu, V, D, window, negative, bitlevel, reg=0.0, seed=0, table_size=20000, **tune):
     rng = np.random.default_rng(seed)
     cn = np.concatenate([[0], np.sort(rng.integers(5, 2000, V - 1))[::-1]]).astype(np.int64)
     o = OracleState(cn, D, window=window, negative=negative, bitlevel=bitlevel, reg=reg, sample=0.0,
                     table_size=table_size)
     t = w2b.Trainer(V, D, window, negative, bitlevel, num_threads=1, iter=1, alpha=0.05, sample=0.0, reg=reg,
-                    train_words=int(cn.sum()), compute_loss=True)
+                    train_words=int(cn.sum()), compute_loss=True, **tune)
     # spread the init a little so that bitlevel>=2 sees both levels
     o.u *= 3.0
     o.v *= 3.0
@@ -258,7 +258,7 @@ def test_suggested_threads_fills_the_device(gpu):
     a.close(); b.close()
 
 
-# ------------------------------------------------------------------ private hot rows of the tuple kernel
+# ------------------------------------------------------------------ per-XCD copies of hot rows in the tuple kernel
 def zipf_tuples(rng, V, n, window, negative):
     """colliding tuples with word2vec-like row frequencies (rows 1 and 2 in most tuples)"""
     from w2b_testlib import zipf_ids
@@ -272,15 +272,15 @@ def zipf_tuples(rng, V, n, window, negative):
 
 @pytest.mark.parametrize("D,bitlevel,period", [(96, 1, 8), (800, 1, 1), (400, 2, 32), (1000, 0, 8)])
 def test_tuple_hot_rows_are_invisible_to_one_workgroup(gpu, monkeypatch, D, bitlevel, period):
-    """W2B_TUPLE_HOT=u,v keeps rows 1..u of u and 1..v of v privately in LDS and meets memory every W2B_HOT_PERIOD
-    tuples.  With ONE workgroup (serial=True) nobody else writes the rows, so the merge must take its exact path and
-    the end state -- and the loss -- must equal the run without private rows bit for bit."""
+    """w2b_tuning.hot_rows_u / hot_rows_v: rows 1..u of u and 1..v of v are read and written at the XCD's copy and meet
+    their master rows every hot_period tuples and after the launch.  With ONE workgroup (serial=True) nobody else writes
+    the rows, so every merge must take its exact path and the end state -- and the loss -- must equal the run without
+    copies bit for bit."""
     V, window, negative, n = 40, 4, 6, 300
     res = {}
-    for hot in ("0,0", "2,2", "3,1", "0,4"):
-        monkeypatch.setenv("W2B_TUPLE_HOT", hot)
-        monkeypatch.setenv("W2B_HOT_PERIOD", str(period))
-        o, t, rng = make_pair(gpu, V, D, window, negative, bitlevel, seed=5)
+    for hot in ("0,0", "2,2", "3,1", "0,4", "39,39"):
+        hu, hv = (int(x) for x in hot.split(","))
+        o, t, rng = make_pair(gpu, V, D, window, negative, bitlevel, seed=5, hot_rows_u=hu, hot_rows_v=hv, hot_period=period)
         tup = zipf_tuples(rng, V, n, window, negative)
         loss = t.train_tuples(*tup, 0.025, serial=True)
         res[hot] = t.get_model() + (loss,)
@@ -295,13 +295,12 @@ def test_tuple_hot_rows_are_invisible_to_one_workgroup(gpu, monkeypatch, D, bitl
 
 @pytest.mark.parametrize("D,window,negative,bitlevel", [(800, 8, 24, 1), (400, 8, 24, 2), (1000, 5, 12, 0)])
 def test_single_step_parity_with_tuple_hot_rows(gpu, monkeypatch, D, window, negative, bitlevel):
-    """collision-free tuples over many workgroups, private hot rows forced on: the one workgroup that uses row 1 / 2
-    writes its update back at the final merge, every other workgroup leaves the rows alone -> same bounds against the
-    oracle as without private rows"""
-    monkeypatch.setenv("W2B_TUPLE_HOT", "2,2")
+    """collision-free tuples over many workgroups, copies of rows 1-2 forced on: the one workgroup that uses row 1 / 2
+    updates its XCD's copy, which meets the master row in a merge or after the launch; every other workgroup leaves
+    the rows alone -> same bounds against the oracle as without copies"""
     n = 24
     V = n * (2 * window + negative + 2) + 64
-    o, t, rng = make_pair(gpu, V, D, window, negative, bitlevel)
+    o, t, rng = make_pair(gpu, V, D, window, negative, bitlevel, hot_rows_u=2, hot_rows_v=2)
     center, ctx_off, ctx, neg = disjoint_tuples(rng, V, n, window, negative)
     def swap(arrs, a, b):                          # rename row a <-> b inside one table's id space
         for x in arrs:
@@ -319,17 +318,16 @@ def test_single_step_parity_with_tuple_hot_rows(gpu, monkeypatch, D, window, neg
 
 
 def test_tuple_hot_rows_hogwild_tracks_plain(gpu, monkeypatch):
-    """many workgroups, Zipf tuples, rows 1-2 of both tables private (merged every 8 tuples and at the end) against all
-    rows coherent, and against the serial oracle.  60 000 tuples over the 8 192 one-wavefront workgroups a 200-float
-    launch starts are seven tuples per workgroup -- far more parallel than any real run (bench: 128 tuples per workgroup)
-    -- so this is the worst case for stale private rows: the two Hogwild passes must stay within 6 % of each other
-    (measured 4 %; at this parallelism BOTH are far from the serial pass, -547 K / -525 K against -338 K, which is why
-    fidelity is judged on real corpora at the reference's thread counts in test_gpu_fidelity.py, not here)"""
+    """many workgroups, Zipf tuples, rows 1-32 of both tables at per-XCD copies (a workgroup merges every 8 tuples) against
+    all rows coherent, and against the serial oracle.  60 000 tuples over the thousands of one-wavefront workgroups a
+    200-float launch starts are a handful of tuples per workgroup -- far more parallel than any real run (bench: 128
+    tuples per workgroup) -- so this is the worst case for stale copies: the two Hogwild passes must stay within 6 % of
+    each other (at this parallelism BOTH are far from the serial pass, -547 K / -525 K against -338 K in round 2, which
+    is why fidelity is judged on real corpora at the reference's thread counts in test_gpu_fidelity.py, not here)"""
     V, D, window, negative, n = 3000, 200, 5, 12, 60000
     out = {}
-    for name, hot in (("plain", "0,0"), ("hot", "2,2")):
-        monkeypatch.setenv("W2B_TUPLE_HOT", hot)
-        o, t, rng = make_pair(gpu, V, D, window, negative, 1, seed=9)
+    for name, hot in (("plain", 0), ("hot", 32)):
+        o, t, rng = make_pair(gpu, V, D, window, negative, 1, seed=9, hot_rows_u=hot, hot_rows_v=hot)
         tup = zipf_tuples(rng, V, n, window, negative)
         loss = t.train_tuples(*tup, 0.025, serial=False)
         out[name] = t.get_model() + (loss,)

@@ -7,6 +7,7 @@ import word2bits_amd as w2b
 from w2b_testlib import OracleState, zipf_ids
 
 pytestmark = pytest.mark.gpu
+EXTRA_CLI = []          # extra ./word2bits arguments (test_gpu_bigtable.py re-runs tests of this file with -row-desc 1)
 
 
 def token_stream(rng, V, n, line=37):
@@ -153,17 +154,14 @@ def test_shard_override_and_multi_worker_bookkeeping(gpu, window_cache):
     (768, 12, 5, 1),         # window too wide for LDS: radius window-1, the outermost context rows are register-held
     (1024, 3, 3, 2),         # the widest row of the 16-byte-column form
 ])
-@pytest.mark.parametrize("hot", ["0", None, "8"])
+@pytest.mark.parametrize("hot", [0, None, 8])
 def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, window, negative, bitlevel, hot, monkeypatch):
     """The LDS-resident window is an optimisation, not a different algorithm: with one worker nobody else
     touches a resident row, so the exact fp32 value is written back and the whole model must come out
     BIT-IDENTICAL to the plain kernel (same launches, same dot-product reduction tree, same target order) --
-    without private hot target rows (W2B_HOT_ROWS=0), with the number the library derives from the word counts
-    (unset) and with as many as fit (8)."""
-    if hot is None:
-        monkeypatch.delenv("W2B_HOT_ROWS", raising=False)
-    else:
-        monkeypatch.setenv("W2B_HOT_ROWS", hot)
+    without per-XCD copies of hot rows (w2b_tuning.hot_rows_* = 0), with the number the library derives from the word
+    counts and the worker count (default: none for one worker) and with 8 forced, merged every 2 steps."""
+    tune = {} if hot is None else dict(hot_rows_v=hot, hot_rows_u=hot, hot_period=2)
     V, n = 300, 6000
     rng = np.random.default_rng(9)
     ids = token_stream(rng, V, n, line=23)          # short sentences: many window fills/flushes
@@ -173,7 +171,7 @@ def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, wind
     out = []
     for wc, pos in ((True, 333), (False, 333), (True, 50)):
         t = w2b.Trainer(V, D, window, negative, bitlevel, num_threads=1, iter=1, sample=1e-3, train_words=tw,
-                        window_cache=wc)
+                        window_cache=wc, **tune)
         t.init_net()
         t.set_vocab_counts(cn, 50000)
         t.set_corpus(ids)
@@ -181,10 +179,7 @@ def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, wind
         if wc:
             resident, radius, colb, _, nh = t.worker_kernel_info()
             assert resident and colb == 16 and radius == (window - 1 if (D, window) == (768, 12) else window)
-            if hot == "0":
-                assert nh == 0
-            elif D <= 200:
-                assert nh >= 1            # (wide rows or wide windows may leave no room next to the window)
+            assert nh == (8 if hot == 8 else 0)
         loss = t.train_epoch(positions_per_launch=pos)
         u, v = t.get_model()
         out.append((u, v, loss, t.epoch_status()[1]))
@@ -200,8 +195,9 @@ def test_sentence_resident_kernel_equals_plain_kernel_single_worker(gpu, D, wind
 def test_sentence_resident_kernel_equals_plain_kernel_many_workers(gpu, threads, size, window, bitlevel, tmp_path):
     """Several Hogwild workers, deterministic anyway (shards with disjoint vocabularies, -negative 0, shards shorter
     than an alpha period: no two workers share a row): the sentence-resident kernel -- window slots, scratch entries,
-    exact-or-merge write-back, private hot target rows, producer wavefront -- must write the same file as the
-    plain kernel, byte for byte."""
+    exact-or-merge write-back, per-XCD copies of the six hottest rows merged every 4 steps (every worker is the
+    only writer of its rows, whichever XCD it runs on), producer wavefront -- must write the same file as the plain
+    kernel, byte for byte."""
     import os
     import subprocess
     from w2b_testlib import ROOT, write_disjoint_shard_corpus
@@ -212,7 +208,8 @@ def test_sentence_resident_kernel_equals_plain_kernel_many_workers(gpu, threads,
         r = subprocess.run([os.path.join(ROOT, "word2bits"), "-train", corpus, "-output", out, "-threads", str(threads),
                             "-window-cache", str(wc), "-bitlevel", str(bitlevel), "-size", str(size), "-window", str(window),
                             "-negative", "0", "-iter", "2", "-min-count", "1", "-binary", "1", "-sample", "0",
-                            "-positions", "53"], capture_output=True, text=True)
+                            "-positions", "53", "-hot-rows", "6", "-hot-period", "4"] + EXTRA_CLI,
+                           capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-300:]
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1]

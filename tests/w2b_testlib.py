@@ -292,3 +292,20 @@ def write_zipf_text_corpus(path, vocab=70000, n_tokens=17_000_000, seed=0, line=
             f.write(b" ".join(words[ids[o:o + line]]))
             f.write(b"\n")
     return path
+
+
+def write_headline_corpus(path, vocab=400_000, n_zipf=20_000_000, seed=1234, line=1000):
+    """BASELINE configs[1] as a text file (SURVEY 8d "CPU baseline" recipe): every one of the vocab-1 words five times
+    (so that -min-count 5 keeps all `vocab` rows), shuffled, followed by n_zipf Zipf(1) draws; a newline every `line`
+    tokens.  Deterministic for a given numpy version.  Used by tests/golden/make_fidelity_bands.py (what the unmodified
+    reference does on it) and by the fidelity test of the benchmarked regime."""
+    rng = np.random.default_rng(seed)
+    base = np.repeat(np.arange(1, vocab, dtype=np.int64), 5)
+    rng.shuffle(base)
+    ids = np.concatenate([base, zipf_ids(rng, vocab, n_zipf)])
+    words = np.array([b"w%d" % i for i in range(vocab)], dtype=object)
+    with open(path, "wb") as f:
+        for o in range(0, len(ids), line):
+            f.write(b" ".join(words[ids[o:o + line]]))
+            f.write(b"\n")
+    return path

@@ -34,6 +34,15 @@ class Config(C.Structure):
     ]
 
 
+class Tuning(C.Structure):
+    """struct w2b_tuning -- the knobs that select code paths or trade fidelity for speed (include/word2bits_hip.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("hot_rows_v", C.c_int32), ("hot_rows_u", C.c_int32), ("hot_period", C.c_int32),
+        ("hot_cap", C.c_int32), ("force_row_desc", C.c_int32), ("grid_per_cu", C.c_int32), ("mem_mode", C.c_int32),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
 vp, i32p, i64p, f32p, f64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), \
     C.POINTER(C.c_float), C.POINTER(C.c_double)
 
@@ -48,6 +57,8 @@ SIGNATURES = {
     "w2b_quantize": (C.c_float, [C.c_float, C.c_int32]),
     "w2b_trainer_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),
     "w2b_trainer_destroy": (None, [vp]),
+    "w2b_get_tuning": (C.c_int, [vp, C.POINTER(Tuning)]),
+    "w2b_set_tuning": (C.c_int, [vp, C.POINTER(Tuning)]),
     "w2b_init_net": (C.c_int, [vp]),
     "w2b_set_model": (C.c_int, [vp, f32p, f32p]),
     "w2b_get_model": (C.c_int, [vp, f32p, f32p]),

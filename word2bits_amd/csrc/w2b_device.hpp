@@ -83,9 +83,11 @@ template <int VEC> struct Col { float e[VEC]; };
 // single-worker run bit-identical to the CPU program (w2b_config.exact_reduction; parity mode, not a fast path).
 #define W2B_MM_EXACT 4
 #define W2B_EXACT_COLS 256    // columns whose products sit in LDS at a time in the exact mode
+// MM 5 (W2B_MM_XCD) = nt loads + nt stores: past the CU's L1, served by and kept in the XCD's L2 -- the per-XCD copies
+// of the hottest rows (XHot below)
 template <int MM> struct Aux {
-  static constexpr int load = (MM == 0 || MM == W2B_MM_EXACT) ? 16 : ((MM == 2) ? 2 : 0);
-  static constexpr int store = (MM == 1) ? 0 : 16;
+  static constexpr int load = (MM == 0 || MM == W2B_MM_EXACT) ? 16 : ((MM == 2 || MM == 5) ? 2 : 0);
+  static constexpr int store = (MM == 1) ? 0 : ((MM == 5) ? 2 : 16);
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -282,93 +284,98 @@ __device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP c
   return k;     // number of chunks
 }
 
-// ------------------------------------------------------------------------------------ private hot rows
-// The tuple kernel and the plain worker kernel touch every row through memory; with coherent (agent-scope) rows the few
-// most frequent rows of u (context words) and of v (targets) then serialise at their memory lines (~7 M read-modify-
-// writes per second per row, against e.g. 0.67 context uses and 0.32 target uses of row 1 per centre word on
-// Zipf(1) ids).  A workgroup therefore keeps PRIVATE copies of rows 1..nu of u and 1..nv of v (the vocabulary is sorted
-// by count; the numbers come from the word counts, 0 when unknown) in LDS, thread-private 16-byte columns, and merges
-// them with memory every `period` centre words and when it ends -- the exact-or-merge rule of the sentence-resident
-// kernel (w2b_kernels_resident.hip): untouched in memory since the last merge -> the exact value is stored (one
-// workgroup alone stays bit-identical to the kernel without private rows), else value - entry is added to the
-// current row.  16-byte columns only (VEC == 4).
-struct HotSet {
-  float *rows;           // [nu + nv][dim]      private values (u rows first)
-  unsigned *csum;        // [nu + nv][W2B_MAXW] per-wavefront checksum of the row bits at the last merge
+// ------------------------------------------------------------------------------------ XCD-shared hot rows
+// With coherent (agent-scope) rows every access to a row goes to its memory line, and the few most frequent rows of
+// u (context words) and v (targets) queue there: a 3200-byte row sustains ~7 M read-modify-writes per second, against
+// e.g. 0.32 target uses of row 1 per centre word on Zipf(1) ids at 25 M words/s.  Rounds 1-2 gave every worker PRIVATE
+// copies of a handful of such rows (LDS) and merged them every few steps.  Now every XCD owns ONE copy of rows 1..nu of u
+// and 1..nv of v (the vocabulary is sorted by count; the numbers come from the word counts and the number of workers)
+// in global memory, accessed with `nt` loads and stores: they bypass the CU's L1 and are served by / stay in the XCD's
+// L2 (MI355X_MICROARCH.md, inter-workgroup visibility: measured in tools/coherence_probe2.hip as "all workgroups of an
+// XCD see each other's read-modify-writes").  All workers of an XCD therefore share a hot row coherently at L2 speed,
+// and only the eight copies have to meet: a MERGE of one row loads the XCD's copy c, the value e the copy had at its
+// last merge ("entry") and the master row m, and stores, per element,
+//      n = c              if m == e   (nobody else changed the master: the exact value -- one worker stays bit-identical
+//                                      to a run without copies)
+//          m              if c == e   (nothing of ours: adopt)
+//          m + (c - e)    otherwise   (our contribution since the last merge on top of the others')
+// to master, copy and entry (stores whose value cannot differ are skipped per wavefront).  Workers take turns: every
+// hot_period centre words a worker merges xhot_m rows, rotating through the set.  k_xhot_fold (w2b_kernels_misc.hip)
+// applies the same rule for all eight copies before and after every launch, so between launches the master rows are
+// complete and copy == entry == master.  16-byte columns only (VEC == 4).
+#define W2B_MM_XCD 5          // Aux<>: nt loads + nt stores (XCD scope)
+struct XHot {
+  float *cu, *cv, *eu, *ev;    // this XCD's copies of the hot rows of u / v, and their entry values
   int nu, nv;
-  unsigned dirty_u, dirty_v;     // bit k: this workgroup has updated its copy of row k+1 since the last merge
-  long long scratch0;    // first scratch ("entry") row of this workgroup in P.entry
 };
-
-__device__ __forceinline__ unsigned col4_bits(const Col<4> &c) {
-  return __float_as_uint(c.e[0]) * 3u ^ __float_as_uint(c.e[1]) * 5u ^ __float_as_uint(c.e[2]) * 7u ^ __float_as_uint(c.e[3]) * 9u;
+__device__ __forceinline__ XHot xhot_here(const W2bParams &P) {
+  XHot X;
+  X.nu = P.xhot ? P.xhot_u : 0;
+  X.nv = P.xhot ? P.xhot_v : 0;
+  // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): the XCD this workgroup runs on (a different placement would only be slower)
+  const int xcd = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (W2B_NXCD - 1);
+  float *base = P.xhot + (long long)xcd * 2 * (X.nu + X.nv) * P.dim;
+  X.cu = base;
+  X.cv = base + (long long)X.nu * P.dim;
+  X.eu = X.cv + (long long)X.nv * P.dim;
+  X.ev = X.eu + (long long)X.nu * P.dim;
+  return X;
 }
-__device__ __forceinline__ Col<4> hot_ld(const float *p) {
-  Col<4> c;
-#pragma unroll
-  for (int e = 0; e < 4; e++) c.e[e] = p[e];
-  return c;
+__device__ __forceinline__ Col<4> xhot_ld(const float *rows, int k, int n, int dim, int col0) {
+  return load_col<4, W2B_MM_XCD, 0>(rows, k, dim, col0, (unsigned)(n * dim * 4));
 }
-__device__ __forceinline__ void hot_st(float *p, const Col<4> &c) {
-#pragma unroll
-  for (int e = 0; e < 4; e++) p[e] = c.e[e];
+__device__ __forceinline__ void xhot_st(float *rows, int k, int n, int dim, int col0, const Col<4> &c) {
+  store_col<4, W2B_MM_XCD, 0>(rows, k, dim, col0, c, (unsigned)(n * dim * 4));
 }
-
-// (re)load the private copies / meet memory.  `init`: first call of a launch (adopt everything).
-template <int MM>
-__device__ __forceinline__ void hot_set_merge(const W2bParams &P, HotSet &H, bool init, bool active, int col0, int lane, int wave) {
-  const int dim = P.dim;
-#pragma unroll 1
-  for (int tsel = 0; tsel < 2; tsel++) {
-    float *tab = tsel ? P.v : P.u;
-    const int n = tsel ? H.nv : H.nu, base = tsel ? H.nu : 0;
-    unsigned &dirty = tsel ? H.dirty_v : H.dirty_u;
-#pragma unroll 1
-    for (int k = 0; k < n; k++) {
-      const int slot = base + k;
-      Col<4> g;
+// hot row k (master row k + 1 of `tab`) of this XCD meets memory.  MM / TB: how the master rows are accessed.
+template <int MM, int TB>
+__device__ __forceinline__ void xhot_merge_row(float *tab, float *copy, float *entry, int k, int n, int dim, int col0,
+                                               bool active, unsigned tab_bytes) {
+  Col<4> c, e, m, o;
 #pragma unroll
-      for (int e = 0; e < 4; e++) g.e[e] = 0.f;
-      if (active) g = load_col<4, MM>(tab, k + 1, dim, col0, P.tab_bytes);
-      const unsigned now = wave_xor(active ? col4_bits(g) : 0u);
-      if (init || !((dirty >> k) & 1u)) {               // nothing of ours: adopt the current row
-        if (active) {
-          hot_st(H.rows + slot * dim + col0, g);
-          store_col<4, 1, 1>(P.entry, H.scratch0 + slot, dim, col0, g, 0u);
-        }
-        if (lane == 0) H.csum[slot * W2B_MAXW + wave] = now;
-        continue;
-      }
-      const bool untouched = (now == H.csum[slot * W2B_MAXW + wave]);
-      Col<4> val = g;
-      if (active) {
-        val = hot_ld(H.rows + slot * dim + col0);
-        if (!untouched) {
-          const Col<4> en = load_col<4, 0, 1>(P.entry, H.scratch0 + slot, dim, col0, 0u);
-#pragma unroll
-          for (int e = 0; e < 4; e++) val.e[e] = g.e[e] + (val.e[e] - en.e[e]);
-          hot_st(H.rows + slot * dim + col0, val);
-        }
-        store_col<4, MM>(tab, k + 1, dim, col0, val, P.tab_bytes);
-        store_col<4, 1, 1>(P.entry, H.scratch0 + slot, dim, col0, val, 0u);
-      }
-      const unsigned cs = wave_xor(active ? col4_bits(val) : 0u);
-      if (lane == 0) H.csum[slot * W2B_MAXW + wave] = cs;
-    }
-    dirty = 0u;
+  for (int i = 0; i < 4; i++) { c.e[i] = 0.f; e.e[i] = 0.f; m.e[i] = 0.f; }
+  if (active) {
+    c = xhot_ld(copy, k, n, dim, col0);
+    e = xhot_ld(entry, k, n, dim, col0);
+    m = load_col<4, MM, TB>(tab, k + 1, dim, col0, tab_bytes);
   }
+  bool own = false, oth = false;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bool ce = __float_as_uint(c.e[i]) == __float_as_uint(e.e[i]);
+    const bool me = __float_as_uint(m.e[i]) == __float_as_uint(e.e[i]);
+    own = own || !ce;
+    oth = oth || !me;
+    o.e[i] = me ? c.e[i] : (ce ? m.e[i] : m.e[i] + (c.e[i] - e.e[i]));
+  }
+  const bool any_own = __ballot(own) != 0ull, any_oth = __ballot(oth) != 0ull;      // wave-uniform
+  if (active) {
+    if (any_own) store_col<4, MM, TB>(tab, k + 1, dim, col0, o, tab_bytes);
+    if (any_oth) xhot_st(copy, k, n, dim, col0, o);
+    if (any_own || any_oth) xhot_st(entry, k, n, dim, col0, o);
+  }
+}
+// one merge event of a workgroup of the plain kernels: P.xhot_m rows of each table, rotating through the sets
+template <int MM>
+__device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot &X, int &cursor, int col0, bool active) {
+  for (int j = 0; j < P.xhot_m; j++) {
+    const int i = cursor + j;
+    if (X.nu > 0 && j < X.nu) xhot_merge_row<MM, -1>(P.u, X.cu, X.eu, i % X.nu, X.nu, P.dim, col0, active, P.tab_bytes);
+    if (X.nv > 0 && j < X.nv) xhot_merge_row<MM, -1>(P.v, X.cv, X.ev, i % X.nv, X.nv, P.dim, col0, active, P.tab_bytes);
+  }
+  cursor += P.xhot_m;
 }
 
 // ------------------------------------------------------------------------------------ one centre word
 // Preconditions: L.ctx[0..cw), L.tgt[0..nt) and prep_lists() results published by a __syncthreads();
 // cw >= 1, nt >= 1.
 // Ends with a __syncthreads() (lists may be overwritten afterwards).
-// H: the workgroup's private hot rows (nu = nv = 0: none; VEC == 4 only).  Passed by reference and never through a
-// pointer, so that its fields stay in registers.
+// X: this XCD's copies of the hottest rows (nu = nv = 0: none; VEC == 4 only): a row k <= nu of u / k <= nv of v is read
+// and written at its copy instead of its master address.  Passed by reference, so that its fields stay in registers.
 template <int QM, int VEC, bool LOSS, int MM>
 __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &L, const QParam &qp,
                                              const int cw, const int nt, const float alpha,
-                                             double &loss_acc, HotSet &H) {
+                                             double &loss_acc, const XHot &X) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int dim = P.dim, col0 = tid * VEC;
   const bool active = col0 < dim;
@@ -384,9 +391,25 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     for (int i = 0; i < TC; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
   };
   chunk_rows();
-  const int nhu = (VEC == 4) ? H.nu : 0, nhv = (VEC == 4) ? H.nv : 0;
-  // one chunk of target rows: private hot rows first, from LDS (issued after the loads, an LDS read into a register
-  // that could have a load in flight would drain every outstanding load), then the loads
+  const int nhu = (VEC == 4) ? X.nu : 0, nhv = (VEC == 4) ? X.nv : 0;
+  // row accesses: a hot row at this XCD's copy (VEC == 4 only), every other row at its master address
+  auto ld_u = [&](int row) -> Col<VEC> {
+    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) return xhot_ld(X.cu, row - 1, nhu, dim, col0); }
+    return load_col<VEC, MM>(P.u, row, dim, col0, P.tab_bytes);
+  };
+  auto st_u = [&](int row, const Col<VEC> &c) {
+    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) { xhot_st(X.cu, row - 1, nhu, dim, col0, c); return; } }
+    store_col<VEC, MM>(P.u, row, dim, col0, c, P.tab_bytes);
+  };
+  auto ld_v = [&](int row) -> Col<VEC> {
+    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) return xhot_ld(X.cv, row - 1, nhv, dim, col0); }
+    return load_col<VEC, MM>(P.v, row, dim, col0, P.tab_bytes);
+  };
+  auto st_v = [&](int row, const Col<VEC> &c) {
+    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) { xhot_st(X.cv, row - 1, nhv, dim, col0, c); return; } }
+    store_col<VEC, MM>(P.v, row, dim, col0, c, P.tab_bytes);
+  };
+  // one chunk of target rows
   auto load_targets = [&](bool zero) {
 #pragma unroll
     for (int i = 0; i < TC; i++) {
@@ -394,16 +417,8 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
 #pragma unroll
         for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
       }
-      if (VEC == 4 && nhv > 0 && active && start + i < end && (unsigned)(rows[i] - 1) < (unsigned)nhv) {
-        const float *hp = H.rows + (nhu + rows[i] - 1) * dim + col0;
-#pragma unroll
-        for (int e = 0; e < VEC; e++) x[i].e[e] = hp[e];
-      }
+      if (active && start + i < end) x[i] = ld_v(rows[i]);
     }
-#pragma unroll
-    for (int i = 0; i < TC; i++)
-      if (active && start + i < end && !((unsigned)(rows[i] - 1) < (unsigned)nhv))
-        x[i] = load_col<VEC, MM>(P.v, rows[i], dim, col0, P.tab_bytes);
   };
   // issue the first chunk of target-row loads before the context phase so both gathers overlap
   load_targets(true);
@@ -415,24 +430,9 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
   for (int e = 0; e < VEC; e++) avg.e[e] = 0.f;
   for (int j0 = 0; j0 < cw; j0 += W2B_CA) {
     Col<VEC> r[W2B_CA];
-    if (VEC == 4 && nhu > 0) {
-#pragma unroll
-      for (int jj = 0; jj < W2B_CA; jj++)
-        if (active && j0 + jj < cw) {
-          const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
-          if ((unsigned)(crow - 1) < (unsigned)nhu) {
-            const float *hp = H.rows + (crow - 1) * dim + col0;
-#pragma unroll
-            for (int e = 0; e < VEC; e++) r[jj].e[e] = hp[e];
-          }
-        }
-    }
 #pragma unroll
     for (int jj = 0; jj < W2B_CA; jj++)
-      if (active && j0 + jj < cw) {
-        const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
-        if (!((unsigned)(crow - 1) < (unsigned)nhu)) r[jj] = load_col<VEC, MM>(P.u, crow, dim, col0, P.tab_bytes);
-      }
+      if (active && j0 + jj < cw) r[jj] = ld_u(__builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]));
 #pragma unroll
     for (int jj = 0; jj < W2B_CA; jj++)
       if (active && j0 + jj < cw) {
@@ -557,15 +557,8 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
             err.e[e] += g * quant<QM>(xv, qp);
             x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
           }
-          if (VEC == 4 && (unsigned)(rows[i] - 1) < (unsigned)nhv) {
-            float *hp = H.rows + (nhu + rows[i] - 1) * dim + col0;
-#pragma unroll
-            for (int e = 0; e < VEC; e++) hp[e] = x[i].e[e];
-          } else {
-            store_col<VEC, MM>(P.v, rows[i], dim, col0, x[i], P.tab_bytes);
-          }
+          st_v(rows[i], x[i]);
         }
-        if (VEC == 4 && (unsigned)(rows[i] - 1) < (unsigned)nhv) H.dirty_v |= 1u << (rows[i] - 1);
       }
     }
     start = end;
@@ -586,12 +579,8 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
         if (j0 + jj < W2B_STASH) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) r[jj].e[e] = L.stash[((j0 + jj) * blockDim.x + tid) * VEC + e];
-        } else if (VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu) {
-          const float *hp = H.rows + (crow - 1) * dim + col0;
-#pragma unroll
-          for (int e = 0; e < VEC; e++) r[jj].e[e] = hp[e];
         } else {
-          r[jj] = load_col<VEC, MM>(P.u, crow, dim, col0, P.tab_bytes);
+          r[jj] = ld_u(crow);
         }
       }
 #pragma unroll
@@ -603,24 +592,9 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
 #pragma unroll
             for (int e = 0; e < VEC; e++) r[jj].e[e] = r[jj].e[e] + (err.e[e] - ar2 * r[jj].e[e]);
           }
-          const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
-          if (VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu) {
-            float *hp = H.rows + (crow - 1) * dim + col0;
-#pragma unroll
-            for (int e = 0; e < VEC; e++) hp[e] = r[jj].e[e];
-          } else {
-            store_col<VEC, MM>(P.u, crow, dim, col0, r[jj], P.tab_bytes);
-          }
+          st_u(__builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]), r[jj]);
         }
       }
-    if (VEC == 4 && nhu > 0) {       // (wave-uniform bookkeeping outside the per-lane `active` region)
-#pragma unroll
-      for (int jj = 0; jj < W2B_CA; jj++)
-        if (j0 + jj < cw && L.umult[j0 + jj] > 0) {
-          const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
-          if ((unsigned)(crow - 1) < (unsigned)nhu) H.dirty_u |= 1u << (crow - 1);
-        }
-    }
   }
   if (LOSS && P.reg != 0.f) {
     const float s = wave_sum(regsq);

@@ -8,6 +8,8 @@
 #define W2B_LCG_C 11ULL
 #define W2B_MAX_SEN 1000           // ref src/word2bits.cpp:32
 #define W2B_MAXW 16                // max wavefronts per workgroup (1024 threads)
+#define W2B_NXCD 8                 // accelerator complex dies of an MI355X, each with its own L2 (HW_REG_XCC_ID: 0..7)
+#define W2B_XHOT_MAX 128           // most rows of one table with per-XCD copies
 
 // Racy globals of the reference that all workers share (ref src/word2bits.cpp:51,53):
 // alpha and word_count_actual.  One instance in device memory per trainer.
@@ -58,8 +60,12 @@ struct W2bParams {
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
   int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
   float *entry;                   // sentence-resident kernel: scratch rows [num_threads][2][slots][dim] (see w2b_kernels_resident.hip)
-  int hot_period;                 // centre words between two merges of a worker's / workgroup's private hot rows (power of two)
-  int hot_u, hot_v;               // tuple kernel: leading rows of u / v with a private copy per workgroup (0 = none)
+  // XCD-shared copies of the hottest rows (w2b_device.hpp "XHot"): [W2B_NXCD][copies of u rows 1..xhot_u | copies of v rows
+  // 1..xhot_v | entries of the same][dim].  0 / 0 = every row is accessed at its master address.
+  float *xhot;
+  int xhot_u, xhot_v;
+  int hot_period;                 // centre words between two merge events of a worker / workgroup (power of two)
+  int xhot_m;                     // hot rows of each table that one merge event brings up to date
   int exact;                      // serial dot product in the reference's order (plain worker / tuple kernels)
   float starting_alpha, sample, reg;
 };
@@ -67,20 +73,19 @@ struct W2bParams {
 // launchers implemented in w2b_kernels.hip --------------------------------------------------------
 // block size chosen from dim: one thread per 16-byte (or 4-byte) column of a row
 int w2b_block_threads(int dim, int *vec_out);
-size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact = false, int hot_rows = 0);
+size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact = false);
 int w2b_tuple_max_grid(int num_cus);                                   // most workgroups w2b_launch_tuples starts
 hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *center,
                              const int32_t *ctx_off, const int32_t *ctx, const int32_t *neg,
                              float alpha, int grid, int num_cus, int per_cu_override, bool loss,
                              hipStream_t s);
 hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s);
-// sentence-resident variant (w2b_kernels_resident.hip): radius >= 0 when it can run for this shape; *hot_out = how many
-// of the hot_wanted most frequent target rows get a private LDS slot next to the window
-int w2b_resident_plan(int dim, int window, int negative, int hot_wanted, int *hot_out);
-long long w2b_resident_scratch_rows(int radius, int hot);              // scratch rows per worker
-hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int radius, int hot, bool loss, hipStream_t s);
+// sentence-resident variant (w2b_kernels_resident.hip): radius >= 0 when it can run for this shape
+int w2b_resident_plan(int dim, int window, int negative);
+long long w2b_resident_scratch_rows(int radius);                       // scratch rows per worker
+hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int radius, bool loss, hipStream_t s);
 int w2b_workers_per_cu(const W2bParams &p, bool loss);                  // resident workgroups per CU, plain kernel
-int w2b_resident_per_cu(const W2bParams &p, int radius, int hot, bool loss);     // ... sentence-resident kernel
+int w2b_resident_per_cu(const W2bParams &p, int radius, bool loss);     // ... sentence-resident kernel
 hipError_t w2b_launch_init_net(float *u, float *v, long long n_per_table, const float *lut,
                                hipStream_t s);
 hipError_t w2b_launch_export(const float *u, const float *v, float *out, long long n, int bitlevel,
@@ -98,6 +103,8 @@ struct w2b_trainer;
 // what the evaluator needs from a live trainer (w2b_trainer.cpp): device tables, shape, bitlevel, device, stream
 void w2b_internal_trainer_view(w2b_trainer *t, float **u, float **v, long long *V, long long *D, int *bitlevel,
                                int *device, hipStream_t *stream);
+// per-XCD copies of the hottest rows meet their master rows (before / after every training launch; idempotent)
+hipError_t w2b_launch_xhot_fold(const W2bParams &p, hipStream_t s);
 hipError_t w2b_launch_wca_pack(const W2bShared *sh, unsigned long long *buf, hipStream_t s);   // buf[0] = local word count
 hipError_t w2b_launch_wca_unpack(W2bShared *sh, const unsigned long long *buf, hipStream_t s); // from buf[1] = global sum
 hipError_t w2b_launch_sub(float *w, const float *base, long long n, hipStream_t s);       // w -= base

@@ -70,6 +70,37 @@ __global__ void k_scale_snap(float *w, float *base, float s, long long n) {     
     if (base) base[i] = x;
   }
 }
+// ---- XCD-shared hot rows (XHot in w2b_device.hpp): all eight copies of hot row k meet the master row k + 1, with the
+// merge rule of xhot_merge_row, XCD after XCD; afterwards master == every copy == every entry.  One workgroup per hot
+// row (u rows first), 16 bytes per thread.  Runs before and after every training launch: idempotent, and a master that
+// was changed in between (w2b_set_model, a replica exchange) is simply adopted.
+__global__ void k_xhot_fold(const W2bParams P) {
+  const int nu = P.xhot_u, nv = P.xhot_v, dim = P.dim;
+  const int r = blockIdx.x;
+  const bool is_u = r < nu;
+  const int k = is_u ? r : r - nu;
+  w2b_f4 *master = reinterpret_cast<w2b_f4 *>((is_u ? P.u : P.v) + (long long)(k + 1) * dim);
+  const long long per_xcd = 2ll * (nu + nv) * dim, copy_off = (long long)(is_u ? k : nu + k) * dim,
+                  entry_off = copy_off + (long long)(nu + nv) * dim;
+  for (int c = threadIdx.x; c < dim / 4; c += blockDim.x) {
+    w2b_f4 m = master[c];
+    for (int x = 0; x < W2B_NXCD; x++) {
+      const w2b_f4 cv = reinterpret_cast<const w2b_f4 *>(P.xhot + x * per_xcd + copy_off)[c];
+      const w2b_f4 ev = reinterpret_cast<const w2b_f4 *>(P.xhot + x * per_xcd + entry_off)[c];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const bool ce = __float_as_uint(cv[i]) == __float_as_uint(ev[i]);
+        const bool me = __float_as_uint(m[i]) == __float_as_uint(ev[i]);
+        m[i] = me ? cv[i] : (ce ? m[i] : m[i] + (cv[i] - ev[i]));
+      }
+    }
+    master[c] = m;
+    for (int x = 0; x < W2B_NXCD; x++) {
+      reinterpret_cast<w2b_f4 *>(P.xhot + x * per_xcd + copy_off)[c] = m;
+      reinterpret_cast<w2b_f4 *>(P.xhot + x * per_xcd + entry_off)[c] = m;
+    }
+  }
+}
 // progress counters of the replicas (alpha schedule on the GLOBAL word count, ref :391; see W2bShared)
 __global__ void k_wca_pack(const W2bShared *sh, unsigned long long *buf) { buf[0] = sh->word_count_actual; }
 __global__ void k_wca_unpack(W2bShared *sh, const unsigned long long *buf) {
@@ -80,7 +111,6 @@ __global__ void k_wca_unpack(W2bShared *sh, const unsigned long long *buf) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------ launchers
-// ------------------------------------------------------------------------------------ launchers
 int w2b_block_threads(int dim, int *vec_out) {
   const int vec = (dim % 4 == 0) ? 4 : 1;
   const int cols = dim / vec;
@@ -89,7 +119,7 @@ int w2b_block_threads(int dim, int *vec_out) {
   return threads;   // caller rejects > 1024
 }
 
-size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact, int hot_rows) {
+size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact) {
   const int maxc = (2 * window + 1 + 3) & ~3, maxt = (negative + 1 + 3) & ~3;
   int vec;
   const int threads = w2b_block_threads(dim, &vec);
@@ -97,12 +127,8 @@ size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool e
   if (worker_form) ints += ((W2B_MAX_SEN + 3) & ~3) + 4 + (sizeof(WorkerLds) + 3) / 4 + 4;
   else ints += 4;
   if (exact) ints += (size_t)W2B_T * (W2B_EXACT_COLS + 1) + 4;
-  ints = (ints + 3) & ~(size_t)3;                                  // the hot rows start 16-byte aligned
-  ints += (size_t)hot_rows * (dim + W2B_MAXW);                     // private hot rows + their checksums
   return ints * 4;
 }
-
-// grid == 0: as many workgroups as are resident at once (occupancy query for the exact
 
 hipError_t w2b_launch_init_net(float *u, float *v, long long n, const float *lut, hipStream_t s) {
   hipLaunchKernelGGL(k_init_net, dim3(2048), dim3(256), 0, s, u, v, n, lut);
@@ -122,6 +148,11 @@ hipError_t w2b_launch_export(const float *u, const float *v, float *out, long lo
   });
 }
 
+hipError_t w2b_launch_xhot_fold(const W2bParams &p, hipStream_t s) {
+  if (!p.xhot || p.xhot_u + p.xhot_v <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_xhot_fold, dim3(p.xhot_u + p.xhot_v), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
 hipError_t w2b_launch_wca_pack(const W2bShared *sh, unsigned long long *buf, hipStream_t s) {
   hipLaunchKernelGGL(k_wca_pack, dim3(1), dim3(1), 0, s, sh, buf);
   return hipGetLastError();

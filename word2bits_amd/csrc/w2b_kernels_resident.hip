@@ -17,10 +17,11 @@
 //     scratch row is read only in that conflict case, and LDS holds nothing but the fp32 values -- the whole
 //     window (R = window) fits next to a second workgroup up to D = 1000;
 //   * the most frequent target rows of v (rows 1..hot_n: the vocabulary is sorted by frequency; hot_n is chosen
-//     by the host from the word counts, 0 on flat distributions) get private LDS slots of the same kind, merged
-//     with memory every hot_period steps.  Coherent accesses to one embedding row serialise at its memory line
-//     (about 7 M read-modify-writes per second); on Zipf-distributed ids the most frequent word alone is a target
-//     of 0.3 centre words in every position;
+//     by the host from the word counts and the number of workers, 0 on flat distributions) are read and written at
+//     this XCD's copy (XHot in w2b_device.hpp: nt accesses served by the XCD's L2, shared by all workers of the XCD)
+//     and every hot_period steps a worker brings one of the copies up to date with its master row.  Coherent
+//     accesses to one embedding row serialise at its memory line (about 7 M read-modify-writes per second); on
+//     Zipf-distributed ids the most frequent word alone is a target of 0.3 centre words in every position;
 //   * rows are thread-private 16-byte columns of LDS (a thread only ever touches its own 16 bytes of every
 //     slot): no barriers, no bank conflicts; memory is accessed 16 bytes per lane (tools/row_probe.hip: random
 //     3200-byte rows move at 5.8 TB/s with 16-byte lanes against 4.2 TB/s with 8-byte lanes at the same number of
@@ -56,7 +57,6 @@
 #define W2B_RB 5        // rows whose partial dot products are formed and reduced together (bounds the live temporaries)
 #define W2B_NDWMAX 4    // data wavefronts per worker (one thread per 16-byte column: D <= 1024) + 1 producer wavefront
 #define W2B_RCH 2       // window rows moved per trip when many enter/leave at once (sentence boundaries)
-#define W2B_HOTMAX 8    // most target rows with a private LDS slot
 
 namespace {
 
@@ -119,8 +119,8 @@ struct Step2 {
 
 
 struct Win2 {
-  W2B_LDS float *win;             // [S + NH][dim]  current fp32 value of the resident rows (window slots, then hot rows)
-  W2B_LDS unsigned *csum;         // [S + NH][4]    per-wavefront xor checksum of the row bits at entry / last merge
+  W2B_LDS float *win;             // [S][dim]  current fp32 value of the resident rows (window slots)
+  W2B_LDS unsigned *csum;         // [S][4]    per-wavefront xor checksum of the row bits at entry
   W2B_LDS float *red;             // [2][W2B_RT][4]
   W2B_LDS int *slot_row, *slot_ref, *pos_slot, *slot_gen;                      // [S]
   W2B_LDS int *ret_slot, *ret_row, *ret_gen, *adm_slot, *adm_row, *adm_gen;    // [S+2]
@@ -136,12 +136,12 @@ struct Win2 {
 
 __host__ __device__ inline int w2_round4(int x) { return (x + 3) & ~3; }
 
-// LDS bytes of the sentence-resident kernel for radius R and NH hot target rows
-__host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negative, int R, int NH) {
+// LDS bytes of the sentence-resident kernel for radius R
+__host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negative, int R) {
   const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
-  size_t b = (size_t)(S + NH) * dim * 4;                           // win
+  size_t b = (size_t)S * dim * 4;                           // win
   b = (b + 15) & ~(size_t)15;
-  b += (size_t)(S + NH) * W2B_NDWMAX * 4;                          // csum
+  b += (size_t)S * W2B_NDWMAX * 4;                          // csum
   b += 2 * W2B_RT * W2B_NDWMAX * 4;                                // red
   b += (size_t)(4 * w2_round4(S) + maxt + w2_round4(W2B_MAX_SEN)) * 4;               // slot tables, prev, sen
   b += 2 * ((size_t)(6 * w2_round4(S + 2) + maxc + 4 + 3 * maxt) * 4 + sizeof(Step2));  // step lists x 2
@@ -150,13 +150,13 @@ __host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negati
   return b;
 }
 
-__device__ __forceinline__ Win2 carve_win2(W2B_LDS int *base, int dim, int window, int negative, int R, int NH, int buf) {
+__device__ __forceinline__ Win2 carve_win2(W2B_LDS int *base, int dim, int window, int negative, int R, int buf) {
   const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
   Win2 L;
   W2B_LDS char *p = (W2B_LDS char *)base;
-  L.win = (W2B_LDS float *)p; p += (size_t)(S + NH) * dim * 4;
+  L.win = (W2B_LDS float *)p; p += (size_t)S * dim * 4;
   p = (W2B_LDS char *)(((unsigned)(size_t)p + 15u) & ~15u);
-  L.csum = (W2B_LDS unsigned *)p; p += (size_t)(S + NH) * W2B_NDWMAX * 4;
+  L.csum = (W2B_LDS unsigned *)p; p += (size_t)S * W2B_NDWMAX * 4;
   L.red = (W2B_LDS float *)p; p += 2 * W2B_RT * W2B_NDWMAX * 4;
   W2B_LDS int *q = (W2B_LDS int *)p;
   L.slot_row = q; q += w2_round4(S);
@@ -221,13 +221,17 @@ struct Rows {
   static constexpr int M = MM & 7, TB = (MM >> 3) & 1;     // memory mode, table form (1 = per-row descriptors)
   const W2bParams &P;
   long long scratch0;      // first scratch row of this worker
-  int nsh;                 // scratch rows per generation = window slots + hot rows
+  int nsh;                 // scratch rows per generation = window slots
   int dim, col0;
   bool active;
+  float *hot_c, *hot_e;    // this XCD's copies of the hottest rows of v and their entry values (XHot)
+  int nh;
   __device__ __forceinline__ Col4 ld_u(int row) const { return load_col<4, M, TB>(P.u, row, dim, col0, P.tab_bytes); }
   __device__ __forceinline__ Col4 ld_v(int row) const { return load_col<4, M, TB>(P.v, row, dim, col0, P.tab_bytes); }
   __device__ __forceinline__ void st_u(int row, const Col4 &c) const { store_col<4, M, TB>(P.u, row, dim, col0, c, P.tab_bytes); }
   __device__ __forceinline__ void st_v(int row, const Col4 &c) const { store_col<4, M, TB>(P.v, row, dim, col0, c, P.tab_bytes); }
+  __device__ __forceinline__ Col4 ld_hot(int k) const { return xhot_ld(hot_c, k, nh, dim, col0); }
+  __device__ __forceinline__ void st_hot(int k, const Col4 &c) const { xhot_st(hot_c, k, nh, dim, col0, c); }
   // scratch ("entry") rows: written with plain stores, read back (rarely) past the L1
   __device__ __forceinline__ Col4 ld_entry(int gen, int slot) const {
     return load_col<4, 0, 1>(P.entry, scratch0 + (long long)gen * nsh + slot, dim, col0, 0u);
@@ -302,56 +306,6 @@ __device__ __forceinline__ void window_admit(const Rows<MM> &A, const Win2 &L, i
   }
 }
 
-// ---- the private copies of the hottest target rows meet memory: exact value if nobody else changed the row since
-// the last merge, else our contribution since then is added to the current row.  Only workers that actually added
-// something write (a read-modify-write by a worker with nothing to publish could only overwrite a newer value).
-template <int MM>
-__device__ __forceinline__ void hot_merge(const Rows<MM> &A, const Win2 &L, int NS, int NH, unsigned &dirty, int lane, int wave) {
-  // four rows per trip: their current values and (for the rows this worker has touched) their entry rows are
-  // requested together -- one memory round trip per trip instead of up to two per row
-  for (int k0 = 0; k0 < NH; k0 += 4) {
-    Col4 g[4], en[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      g[j] = col_zero(); en[j] = col_zero();
-      if (A.active && k0 + j < NH) {
-        g[j] = A.ld_v(k0 + j + 1);
-        if ((dirty >> (k0 + j)) & 1u) en[j] = A.ld_entry(0, NS + k0 + j);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int k = k0 + j, slot = NS + k;
-      if (k < NH) {
-        const unsigned now = wave_xor(A.active ? col_bits(g[j]) : 0u);
-        if (!((dirty >> k) & 1u)) {                      // nothing of ours: adopt the current row
-          if (A.active) {
-            lds_st(L.win + slot * A.dim + A.col0, g[j]);
-            A.st_entry(0, slot, g[j]);
-          }
-          if (lane == 0) L.csum[slot * W2B_NDWMAX + wave] = now;
-        } else {
-          const bool untouched = (now == L.csum[slot * W2B_NDWMAX + wave]);
-          Col4 val = col_zero();
-          if (A.active) {
-            val = lds_ld(L.win + slot * A.dim + A.col0);
-            if (!untouched) {
-#pragma unroll
-              for (int e = 0; e < 4; e++) val.e[e] = g[j].e[e] + (val.e[e] - en[j].e[e]);
-              lds_st(L.win + slot * A.dim + A.col0, val);
-            }
-            A.st_v(k + 1, val);
-            A.st_entry(0, slot, val);
-          }
-          const unsigned cs = wave_xor(A.active ? col_bits(val) : 0u);
-          if (lane == 0) L.csum[slot * W2B_NDWMAX + wave] = cs;
-        }
-      }
-    }
-  }
-  dirty = 0u;
-}
-
 // --------------------------------------------------------------------------------------------------
 // NDW + 1 wavefronts per worker: wavefronts 0..NDW-1 own the embedding columns (data phase); the last one is the
 // PRODUCER: it walks the sentence, the LCG ledger, the window bookkeeping and the negative draws ONE STEP
@@ -363,7 +317,7 @@ __device__ __forceinline__ void hot_merge(const Rows<MM> &A, const Win2 &L, int 
 // UC: the radius is window-1 (the two outermost context rows of a step are register-held).
 template <int QM, bool LOSS, int MM, bool UC>
 __global__ void __launch_bounds__(W2B_WPG * 64 * (W2B_NDWMAX + 1), W2B_RES_WAVES)
-k_train_resident(const W2bParams P, const long long max_positions, const int R, const int NDW, const int NH,
+k_train_resident(const W2bParams P, const long long max_positions, const int R, const int NDW,
                  const int lds_ints_per_worker) {
   extern __shared__ int smem[];
   const int WPT = (NDW + 1) * 64;                        // threads per worker
@@ -371,8 +325,8 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
   // readfirstlane, or every LDS address and with it the whole control flow would count as divergent
   const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / WPT);
   W2B_LDS int *const smem_lds = (W2B_LDS int *)smem + half * lds_ints_per_worker;
-  const Win2 L0 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, NH, 0);
-  const Win2 L1 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, NH, 1);
+  const Win2 L0 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, 0);
+  const Win2 L1 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, 1);
   const Win2 &L = L0;                                   // everything that is not double buffered
   W2B_LDS WorkerLds *S = &L.S->w;
   W2B_LDS int *s_sen = L.sen;
@@ -386,7 +340,9 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
   qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
   qp.steps_f = (float)qp.steps_i;
   const int NS = 2 * R + 1;
-  const Rows<MM> A{P, (long long)wid * 2 * (NS + NH), NS + NH, P.dim, tid * 4, !producer && tid * 4 < P.dim};
+  const XHot XH = xhot_here(P);
+  const int NH = XH.nv;                     // leading rows of v that live in this XCD's copies
+  const Rows<MM> A{P, (long long)wid * 2 * NS, NS, P.dim, tid * 4, !producer && tid * 4 < P.dim, XH.cv, XH.ev, NH};
   const bool active = A.active;
   if (valid) {
     for (int i = tid; i < G->sen_len; i += WPT) s_sen[i] = G->sen[i];
@@ -420,21 +376,9 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
   // data-wavefront registers: the row that enters the window at the next step, loaded one step early
   Col4 apre = col_zero();
   int apre_row = -1;
-  // data wavefronts: private copies of the hottest target rows (LDS slots NS .. NS+NH-1); bit k of `dirty` = this
-  // worker has updated hot row k since the last merge (wave-uniform)
-  unsigned dirty = 0u;
-  if (!producer) {
-    for (int k = 0; k < NH; k++) {
-      Col4 h = col_zero();
-      if (active) {
-        h = A.ld_v(k + 1);
-        lds_st(L.win + (NS + k) * P.dim + A.col0, h);
-        A.st_entry(0, NS + k, h);
-      }
-      const unsigned c = wave_xor(active ? col_bits(h) : 0u);
-      if (lane == 0) L.csum[(NS + k) * W2B_NDWMAX + wave] = c;
-    }
-  }
+  // data wavefronts: which of the XCD's hot rows this worker brings up to date next (workers take turns: workgroup b
+  // runs on XCD b % 8, so the workers of one XCD start at different rows)
+  int merge_cursor = (wid >> 3) * P.xhot_m;
 
   // ---- the preparation of one pass (producer wavefront only; all 64 lanes, wave-uniform control flow)
   auto prepare = [&](const Win2 &O, const bool last) {
@@ -727,19 +671,13 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
 #pragma unroll
           for (int i = 0; i < W2B_RT; i++) rows[i] = __builtin_amdgcn_readlane(mine, i);
           if (active) {
-            // private hot rows first, from LDS: nothing is in flight towards these registers yet, so the reads need no
-            // memory wait (issued after the loads below they would have to drain every outstanding load first)
-            if (NH > 0) {
-#pragma unroll
-              for (int i = 0; i < W2B_RT; i++) {
-                const unsigned hk = (unsigned)(rows[i] - 1);
-                if (start + i < end && hk < (unsigned)NH) x[i] = lds_ld(L.win + (NS + (int)hk) * dim + col0);
-              }
-            }
 #pragma unroll
             for (int i = 0; i < W2B_RT; i++) {
-              const unsigned hk = (unsigned)(rows[i] - 1);
-              if (start + i < end && !(hk < (unsigned)NH)) x[i] = A.ld_v(rows[i]);
+              const unsigned hk = (unsigned)(rows[i] - 1);      // hot rows at this XCD's copy, the others at their master row
+              if (start + i < end) {
+                if (hk < (unsigned)NH) x[i] = A.ld_hot((int)hk);
+                else x[i] = A.ld_v(rows[i]);
+              }
             }
           }
         }
@@ -901,7 +839,6 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           if (i < n) {
             const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
             const unsigned hk = (unsigned)(rows[i] - 1);
-            if (hk < (unsigned)NH) dirty |= 1u << hk;
             if (active) {
 #pragma unroll
               for (int e = 0; e < 4; e++) {
@@ -911,7 +848,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
                 err.e[e] += g * quant<QM>(xv, qp);
                 x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
               }
-              if (hk < (unsigned)NH) lds_st(L.win + (NS + (int)hk) * dim + col0, x[i]);
+              if (hk < (unsigned)NH) A.st_hot((int)hk, x[i]);
               else A.st_v(rows[i], x[i]);
             }
           }
@@ -964,7 +901,13 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
             __hip_atomic_fetch_add(&L.S->loss_reg, -(double)(P.reg * s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      if (NH > 0 && (stop || (it & (P.hot_period - 1)) == P.hot_period - 1)) hot_merge<MM>(A, L, NS, NH, dirty, lane, wave);
+      if (NH > 0 && !stop && (it & (P.hot_period - 1)) == P.hot_period - 1) {
+        // this worker's turn: xhot_m of the XCD's hot rows meet their master rows (the copies of a launch are folded
+        // into the masters by k_xhot_fold afterwards, so a stop pass has nothing to do)
+        for (int j = 0; j < P.xhot_m && j < NH; j++)
+          xhot_merge_row<Rows<MM>::M, Rows<MM>::TB>(P.v, A.hot_c, A.hot_e, (merge_cursor + j) % NH, NH, dim, col0, active, P.tab_bytes);
+        merge_cursor += P.xhot_m;
+      }
       W2B_TICK(8);
       worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);   // lists of the next step are published; this step is done
       if (stop) break;
@@ -990,35 +933,29 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
 
 static int win2_threads(int dim) { return (((dim / 4) + 63) / 64 + 1) * 64; }
 
-// Geometry of the sentence-resident kernel for a shape: radius (-1: use the plain kernel) and how many of the
-// `hot_wanted` hottest target rows get an LDS slot.  Two workers (one workgroup) share the 160 KiB of a CU.
-int w2b_resident_plan(int dim, int window, int negative, int hot_wanted, int *hot_out) {
-  if (hot_out) *hot_out = 0;
+// Geometry of the sentence-resident kernel for a shape: radius (-1: use the plain kernel).  Two workers (one workgroup
+// each) share the 160 KiB of a CU.
+int w2b_resident_plan(int dim, int window, int negative) {
   if (dim % 4 != 0 || dim > 4 * 64 * W2B_NDWMAX) return -1;     // 16-byte columns, at most 4 data wavefronts
   const size_t budget = 80 * 1024;
-  int R = -1;
-  if (win2_lds_bytes(dim, window, negative, window, 0) <= budget) R = window;
-  else if (window >= 2 && win2_lds_bytes(dim, window, negative, window - 1, 0) <= budget) R = window - 1;
-  if (R < 0) return -1;
-  int nh = hot_wanted < 0 ? 0 : (hot_wanted > W2B_HOTMAX ? W2B_HOTMAX : hot_wanted);
-  while (nh > 0 && win2_lds_bytes(dim, window, negative, R, nh) > budget) nh--;
-  if (hot_out) *hot_out = nh;
-  return R;
+  if (win2_lds_bytes(dim, window, negative, window) <= budget) return window;
+  if (window >= 2 && win2_lds_bytes(dim, window, negative, window - 1) <= budget) return window - 1;
+  return -1;
 }
 
 // rows of scratch ("entry") memory per worker
-long long w2b_resident_scratch_rows(int R, int NH) { return 2ll * (2 * R + 1 + NH); }
+long long w2b_resident_scratch_rows(int R) { return 2ll * (2 * R + 1); }
 
 // workgroups of the sentence-resident kernel that are resident per CU (occupancy query of the instantiation
 // that would run)
-static size_t win2_lds_per_worker(const W2bParams &p, int R, int NH) {
-  return (win2_lds_bytes(p.dim, p.window, p.negative, R, NH) + 15) & ~(size_t)15;
+static size_t win2_lds_per_worker(const W2bParams &p, int R) {
+  return (win2_lds_bytes(p.dim, p.window, p.negative, R) + 15) & ~(size_t)15;
 }
 
 // WORKERS of the sentence-resident kernel that are resident per CU (occupancy query of the instantiation that would
 // run: workgroups per CU x W2B_WPG workers per workgroup)
-int w2b_resident_per_cu(const W2bParams &p, int R, int NH, bool loss) {
-  const size_t lds = W2B_WPG * win2_lds_per_worker(p, R, NH);
+int w2b_resident_per_cu(const W2bParams &p, int R, bool loss) {
+  const size_t lds = W2B_WPG * win2_lds_per_worker(p, R);
   const int threads = W2B_WPG * win2_threads(p.dim);
   int nb = 0;
   (void)dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
@@ -1031,10 +968,10 @@ int w2b_resident_per_cu(const W2bParams &p, int R, int NH, bool loss) {
 }
 
 // Coherent rows only (memory mode 0): with relaxed rows the launcher of the trainer picks the plain kernel.
-hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int R, int NH, bool loss, hipStream_t s) {
+hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int R, bool loss, hipStream_t s) {
   const int wthreads = win2_threads(p.dim);  // data wavefronts (one thread per 16-byte column) + 1 producer wavefront
   const int NDW = wthreads / 64 - 1;
-  const size_t wlds = win2_lds_per_worker(p, R, NH);
+  const size_t wlds = win2_lds_per_worker(p, R);
   const int threads = W2B_WPG * wthreads, grid = (p.num_threads + W2B_WPG - 1) / W2B_WPG;
   const size_t lds = W2B_WPG * wlds;
   const int lds_ints = (int)(wlds / 4);
@@ -1043,12 +980,12 @@ hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int 
     reported = true;
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<1, false, 0, false>, threads, lds);
-    fprintf(stderr, "w2b debug: sentence-resident kernel R=%d hot=%d lds=%zu B/worker threads=%d/worker, %d workers per workgroup, resident workgroups/CU=%d\n", R, NH, wlds, wthreads, W2B_WPG, nb);
+    fprintf(stderr, "w2b debug: sentence-resident kernel R=%d hot=%d lds=%zu B/worker threads=%d/worker, %d workers per workgroup, resident workgroups/CU=%d\n", R, p.xhot ? p.xhot_v : 0, wlds, wthreads, W2B_WPG, nb);
   }
   return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
     constexpr int QM = decltype(qm)::value;
     // template MM carries the memory mode in bits 0-2 (0: agent-scope rows) and "tables >= 2 GiB" (per-row descriptors) in bit 3
-#define W2B_LAUNCH_R(LOSS, MMV, UCV) hipLaunchKernelGGL((k_train_resident<QM, LOSS, MMV, UCV>), dim3(grid), dim3(threads), lds, s, p, max_positions, R, NDW, NH, lds_ints)
+#define W2B_LAUNCH_R(LOSS, MMV, UCV) hipLaunchKernelGGL((k_train_resident<QM, LOSS, MMV, UCV>), dim3(grid), dim3(threads), lds, s, p, max_positions, R, NDW, lds_ints)
 #define W2B_LAUNCH_R2(MMV, UCV) do { if (loss) W2B_LAUNCH_R(true, MMV, UCV); else W2B_LAUNCH_R(false, MMV, UCV); } while (0)
     if (R < p.window) { if (p.tab_bytes) W2B_LAUNCH_R2(0, true); else W2B_LAUNCH_R2(8, true); }
     else { if (p.tab_bytes) W2B_LAUNCH_R2(0, false); else W2B_LAUNCH_R2(8, false); }

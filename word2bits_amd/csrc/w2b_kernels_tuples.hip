@@ -9,26 +9,17 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
                                                       const int32_t *__restrict__ ctx_off,
                                                       const int32_t *__restrict__ ctx,
                                                       const int32_t *__restrict__ neg,
-                                                      const float alpha, const int hot_off) {
+                                                      const float alpha) {
   extern __shared__ int smem[];
   WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
   int *s_cnt = L.cend + round4(P.negative + 1);   // [0] cw, [1] nt
   if (MM == W2B_MM_EXACT) L.xprod = reinterpret_cast<float *>(s_cnt + 4);
   const int tid = threadIdx.x, lane = tid & 63;
-  // private copies of the hottest rows of u and v (16-byte columns, coherent rows, not in the parity mode)
-  HotSet HS;
-  HS.rows = reinterpret_cast<float *>(smem + hot_off);
-  HS.nu = 0; HS.nv = 0; HS.dirty_u = 0u; HS.dirty_v = 0u;
-  HS.csum = nullptr;
-  HS.scratch0 = 0;
-  const bool hot = (VEC == 4 && MM == 0 && P.hot_u + P.hot_v > 0);
-  if (hot) {
-    HS.csum = reinterpret_cast<unsigned *>(HS.rows + (P.hot_u + P.hot_v) * P.dim);
-    HS.nu = P.hot_u; HS.nv = P.hot_v;
-    HS.scratch0 = (long long)blockIdx.x * (P.hot_u + P.hot_v);
-    hot_set_merge<MM>(P, HS, true, tid * VEC < P.dim, tid * VEC, lane, tid >> 6);
-  }
-  int since_merge = 0;
+  // this XCD's copies of the hottest rows of u and v (16-byte columns, coherent rows, not in the parity mode)
+  const bool hot = (VEC == 4 && MM == 0 && P.xhot != nullptr && P.xhot_u + P.xhot_v > 0);
+  XHot XH = xhot_here(P);
+  if (!hot) { XH.nu = 0; XH.nv = 0; }
+  int since_merge = 0, merge_cursor = (int)(blockIdx.x >> 3) * P.xhot_m;   // (workgroup b runs on XCD b % 8: take turns)
   QParam qp;
   qp.bitlevel = P.bitlevel;
   qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
@@ -54,14 +45,13 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     }
     __syncthreads();
     const int cw = s_cnt[0], nt = s_cnt[1];
-    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, HS);
+    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, XH);
     else __syncthreads();
-    if (hot && ++since_merge >= P.hot_period) {
+    if (VEC == 4 && hot && ++since_merge >= P.hot_period) {
       since_merge = 0;
-      hot_set_merge<MM>(P, HS, false, tid * VEC < P.dim, tid * VEC, lane, tid >> 6);
+      xhot_merge_event<MM>(P, XH, merge_cursor, tid * VEC, tid * VEC < P.dim);
     }
   }
-  if (hot) hot_set_merge<MM>(P, HS, false, tid * VEC < P.dim, tid * VEC, lane, tid >> 6);
   if (LOSS) {
     if (tid < 64) {
       const double s = wave_sum_d(loss_acc);
@@ -91,9 +81,7 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
                              int per_cu_override, bool loss, hipStream_t s) {
   int vec;
   const int threads = w2b_block_threads(p.dim, &vec);
-  const int hot = (vec == 4 && threads <= 256 && p.mem_mode == 0 && !p.exact) ? p.hot_u + p.hot_v : 0;
-  const int hot_off = (int)(w2b_lds_bytes(p.dim, p.window, p.negative, false, p.exact != 0, 0) / 4);
-  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, false, p.exact != 0, hot);
+  const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, false, p.exact != 0);
   return dispatch_mm_exact(p.mem_mode, p.exact, [&](auto mm) -> hipError_t {
   constexpr int MM = decltype(mm)::value;
   return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
@@ -102,8 +90,7 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
     do {                                                                                                     \
       auto kern = k_train_tuples<QM, VEC, LOSS, MAXT, MM>;                                                       \
       int g = grid > 0 ? grid : auto_grid(kern, threads, lds, num_cus, per_cu_override, n);                  \
-      if (grid <= 0 && hot > 0 && per_cu_override <= 0 && g > w2b_tuple_max_grid(num_cus)) g = w2b_tuple_max_grid(num_cus); \
-      hipLaunchKernelGGL(kern, dim3(g), dim3(threads), lds, s, p, n, center, ctx_off, ctx, neg, alpha, hot_off); \
+      hipLaunchKernelGGL(kern, dim3(g), dim3(threads), lds, s, p, n, center, ctx_off, ctx, neg, alpha); \
     } while (0)
 #define W2B_LAUNCH_T(VEC, LOSS) \
     do { if (threads <= 256) W2B_LAUNCH_T2(VEC, LOSS, 256); else W2B_LAUNCH_T2(VEC, LOSS, 1024); } while (0)

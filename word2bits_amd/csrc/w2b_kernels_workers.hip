@@ -30,8 +30,11 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
   }
   __syncthreads();
   double loss_acc = 0.0;
-  HotSet no_hot;                 // (the plain worker kernel keeps no private rows)
-  no_hot.rows = nullptr; no_hot.csum = nullptr; no_hot.nu = 0; no_hot.nv = 0; no_hot.dirty_u = 0u; no_hot.dirty_v = 0u; no_hot.scratch0 = 0;
+  // this XCD's copies of the hottest rows of u and v (16-byte columns, coherent rows, not in the parity mode)
+  const bool hot = (VEC == 4 && MM == 0 && P.xhot != nullptr && P.xhot_u + P.xhot_v > 0);
+  XHot XH = xhot_here(P);
+  if (!hot) { XH.nu = 0; XH.nv = 0; }
+  int since_merge = 0, merge_cursor = (wid >> 3) * P.xhot_m;      // (workgroup b runs on XCD b % 8: take turns)
   const int W = P.window, K = P.negative;
   for (long long it = 0; it < max_positions; ++it) {
     if (wave == 0) {
@@ -109,8 +112,12 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     if (S->done) break;
     const int cw = S->cw, nt = S->nt;
     const float alpha = S->alpha;
-    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, no_hot);
+    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, XH);
     else __syncthreads();
+    if (VEC == 4 && hot && ++since_merge >= P.hot_period) {
+      since_merge = 0;
+      xhot_merge_event<MM>(P, XH, merge_cursor, tid * VEC, tid * VEC < P.dim);
+    }
   }
   // save the worker
   __syncthreads();

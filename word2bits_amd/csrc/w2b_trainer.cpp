@@ -47,9 +47,14 @@ struct w2b_trainer {
   float *keep = nullptr;
   float *entry = nullptr;       // scratch rows of the sentence-resident kernel
   size_t entry_floats = 0;
-  int hot_wanted = 0;           // leading rows of v whose target rate justifies a private on-chip copy (from the counts)
-  int hot_wanted_u = 0;         // ... rows of u (context uses per centre word; tuple kernel only -- the sentence-resident
-                                // kernel keeps the whole context window on chip anyway)
+  // XCD-shared copies of the hottest rows (XHot in w2b_device.hpp)
+  w2b_tuning tune{};            // knobs of include/word2bits_hip.h (defaults set in w2b_trainer_create)
+  std::vector<double> rate_v, rate_u;   // [k]: uses of row k + 1 of v (as a target) / of u (as a context row) per centre word
+  float *xhot = nullptr;        // [W2B_NXCD][2][nu + nv][dim]
+  size_t xhot_floats = 0;
+  int xhot_nu = -1, xhot_nv = -1;       // layout the buffer currently has (-1: none)
+  bool xhot_master_changed = true;      // the master rows may differ from what the copies were folded into
+  bool debug = false;           // W2B_DEBUG was set when the trainer was created (diagnostics on stderr)
   const int32_t *corpus = nullptr;
   int32_t *corpus_owned = nullptr;
   long long n_tokens = 0;
@@ -78,7 +83,6 @@ struct w2b_trainer {
   hipEvent_t sync_a = nullptr, sync_b = nullptr;
   double sync_ms = 0;                       // device time of the replica exchanges since the last w2b_sync_stats
   long long sync_count = 0;
-  int grid_per_cu = 0;
 };
 
 // --------------------------------------------------------------------------------- host tables
@@ -167,8 +171,8 @@ static W2bParams make_params(const w2b_trainer *t) {
   {
     const unsigned long long bytes = (unsigned long long)t->table_elems * sizeof(float);
     p.tab_bytes = bytes < 0x7fffffffull ? (unsigned)bytes : 0u;   // signed 32-bit scalar offsets
-    // test hook: run the large-table form (per-row buffer descriptors, what tables >= 2 GiB use) on any table size
-    if (const char *e = getenv("W2B_FORCE_ROW_DESC")) if (atoi(e) != 0) p.tab_bytes = 0u;
+    // w2b_tuning.force_row_desc: run the large-table form (per-row buffer descriptors, what tables >= 2 GiB use) on any size
+    if (t->tune.force_row_desc) p.tab_bytes = 0u;
   }
   p.vocab_size = t->cfg.vocab_size;
   p.train_words = t->cfg.train_words;
@@ -180,15 +184,14 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.num_threads = t->cfg.num_threads;
   p.total_threads = t->cfg.total_threads > 0 ? t->cfg.total_threads : t->cfg.num_threads;
   p.mem_mode = t->cfg.relaxed_coherence;   // 0 coherent (sc1), 1 relaxed (plain); >1 experimental builds only
-  if (const char *e = getenv("W2B_MEM_MODE")) p.mem_mode = atoi(e);
+  if (t->tune.mem_mode >= 0) p.mem_mode = t->tune.mem_mode;
   p.exact = t->cfg.exact_reduction != 0;
   if (p.exact) p.mem_mode = 0;             // the exact mode exists for coherent rows only
   p.entry = t->entry;
-  p.hot_period = 8;                 // steps between two merges of a worker's private hot rows (W2B_HOT_PERIOD overrides)
-  if (const char *e = getenv("W2B_HOT_PERIOD")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= 4096 && (v & (v - 1)) == 0) p.hot_period = v;
-  }
+  p.hot_period = t->tune.hot_period;   // centre words between two merge events of a worker (power of two)
+  p.xhot = nullptr;                    // set by xhot_prepare() for the launch that uses the copies
+  p.xhot_u = p.xhot_v = 0;
+  p.xhot_m = 1;
   p.starting_alpha = t->cfg.alpha;
   p.sample = t->cfg.sample;
   p.reg = t->cfg.reg;
@@ -221,7 +224,14 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
   t->num_cus = prop.multiProcessorCount;
-  if (const char *e = getenv("W2B_GRID_PER_CU")) t->grid_per_cu = atoi(e);
+  t->debug = getenv("W2B_DEBUG") != nullptr;
+  t->tune.struct_size = (int32_t)sizeof(w2b_tuning);
+  t->tune.hot_rows_v = t->tune.hot_rows_u = -1;
+  t->tune.hot_period = 8;
+  t->tune.hot_cap = 64;
+  t->tune.force_row_desc = 0;
+  t->tune.grid_per_cu = 0;
+  t->tune.mem_mode = -1;
   HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
   t->table_elems = (long long)cfg->vocab_size * cfg->layer1_size;
   HIPCHK(hipMalloc(&t->uv, sizeof(float) * 2 * t->table_elems));
@@ -265,7 +275,7 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
-  if (getenv("W2B_DEBUG") && t->shared) {
+  if (t->debug && t->shared) {
     W2bShared sh;
     if (hipMemcpy(&sh, t->shared, sizeof sh, hipMemcpyDeviceToHost) == hipSuccess) {
       fprintf(stderr, "w2b debug: phase ticks (100 MHz wall clock) of workgroup 0:");
@@ -280,12 +290,39 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   if (t->poll_host) (void)hipHostFree(t->poll_host);
   if (t->sync_a) (void)hipEventDestroy(t->sync_a);
   if (t->sync_b) (void)hipEventDestroy(t->sync_b);
-  void *ptrs[] = {t->uv, t->base, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->corpus_owned, t->workers, t->shared,
+  void *ptrs[] = {t->uv, t->base, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->xhot, t->corpus_owned, t->workers, t->shared,
                   t->jump_a, t->jump_c, t->st_center, t->st_off, t->st_ctx, t->st_neg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
+}
+
+// --------------------------------------------------------------------------------- tuning knobs
+extern "C" int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out) {
+  if (!t || !out) return fail(W2B_EINVAL, "w2b_get_tuning: null argument");
+  *out = t->tune;
+  return W2B_OK;
+}
+
+extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
+  if (!t || !in) return fail(W2B_EINVAL, "w2b_set_tuning: null argument");
+  if (in->struct_size != (int32_t)sizeof(w2b_tuning))
+    return fail(W2B_EINVAL, "w2b_set_tuning: struct_size does not match this library's w2b_tuning");
+  if (in->hot_rows_v < -1 || in->hot_rows_v > W2B_XHOT_MAX || in->hot_rows_u < -1 || in->hot_rows_u > W2B_XHOT_MAX)
+    return fail(W2B_EINVAL, "w2b_set_tuning: hot_rows_* must be -1 (automatic) or 0..128");
+  if (in->hot_period < 1 || in->hot_period > 4096 || (in->hot_period & (in->hot_period - 1)) != 0)
+    return fail(W2B_EINVAL, "w2b_set_tuning: hot_period must be a power of two in 1..4096");
+  if (in->hot_cap < 0 || in->hot_cap > W2B_XHOT_MAX) return fail(W2B_EINVAL, "w2b_set_tuning: hot_cap must be 0..128");
+  if (in->grid_per_cu < 0 || in->grid_per_cu > 32) return fail(W2B_EINVAL, "w2b_set_tuning: grid_per_cu must be 0..32");
+#ifdef W2B_EXPERIMENTAL_MEMMODES
+  if (in->mem_mode < -1 || in->mem_mode > 3) return fail(W2B_EINVAL, "w2b_set_tuning: mem_mode must be -1..3");
+#else
+  if (in->mem_mode < -1 || in->mem_mode > 1) return fail(W2B_EINVAL, "w2b_set_tuning: mem_mode must be -1, 0 or 1");
+#endif
+  for (int r : in->reserved) if (r != 0) return fail(W2B_EINVAL, "w2b_set_tuning: reserved fields must be zero");
+  t->tune = *in;
+  return W2B_OK;
 }
 
 #define NEED(t)                                                                  \
@@ -309,6 +346,7 @@ extern "C" int w2b_init_net(w2b_trainer *t) {
   HIPCHK(hipMalloc(&dl, sizeof(float) * 65536));
   HIPCHK(hipMemcpyAsync(dl, lut.data(), sizeof(float) * 65536, hipMemcpyHostToDevice, t->stream));
   HIPCHK(w2b_launch_init_net(t->uv, t->uv + t->table_elems, t->table_elems, dl, t->stream));
+  t->xhot_master_changed = true;
   if (t->base)
     HIPCHK(hipMemcpyAsync(t->base, t->uv, sizeof(float) * 2 * t->table_elems, hipMemcpyDeviceToDevice,
                           t->stream));
@@ -323,6 +361,7 @@ extern "C" int w2b_set_model(w2b_trainer *t, const float *u, const float *v) {
   const size_t bytes = sizeof(float) * t->table_elems;
   HIPCHK(hipMemcpyAsync(t->uv, u, bytes, hipMemcpyHostToDevice, t->stream));
   HIPCHK(hipMemcpyAsync(t->uv + t->table_elems, v, bytes, hipMemcpyHostToDevice, t->stream));
+  t->xhot_master_changed = true;
   if (t->base) HIPCHK(hipMemcpyAsync(t->base, t->uv, 2 * bytes, hipMemcpyDeviceToDevice, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   return W2B_OK;
@@ -339,6 +378,7 @@ extern "C" int w2b_get_model(w2b_trainer *t, float *u, float *v) {
 
 extern "C" int w2b_model_device_ptrs(w2b_trainer *t, void **u_dev, void **v_dev) {
   if (!t) return fail(W2B_EINVAL, "null trainer");
+  t->xhot_master_changed = true;           // the caller may write the tables (replica exchange on a view of them)
   if (u_dev) *u_dev = t->uv;
   if (v_dev) *v_dev = t->uv + t->table_elems;
   return W2B_OK;
@@ -399,30 +439,20 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
   if (!t->keep) HIPCHK(hipMalloc(&t->keep, sizeof(float) * V));
   HIPCHK(hipMemcpy(t->keep, keep.data(), sizeof(float) * V, hipMemcpyHostToDevice));
   {
-    // How often is row i of v a target (ref :450-460)?  Per centre word: negative * cn_i^0.75 / sum cn^0.75 (the
-    // unigram table) + cn_i / train_words (as the centre word itself).  The vocabulary is sorted by count, so the
-    // rows worth a private on-chip copy in the sentence-resident kernel are a prefix 1..hot_wanted: those that are
-    // a target of at least one centre word in 10 (a coherent row sustains ~7 M read-modify-writes per second; at
-    // 25 M words/s that is where its line starts to queue), at most four.  Privatising a row trades freshness for
-    // speed (the first-epoch loss moves with rows x merge period), hence the short list.
-    // (W2B_HOT_CAP raises the cap: 8 gives 7 rows and +15 % at a 60 K-word, 200-float shape for +1 % of first-epoch
-    // loss drift on the text8-sized corpus -- DESIGN.md section 6; the default stays at four)
-    const int W2B_HOT_CAP = getenv("W2B_HOT_CAP") ? atoi(getenv("W2B_HOT_CAP")) : 4;
+    // How often is row i of v a target (ref :450-460)?  Per centre word: negative * cn_i^0.75 / sum cn^0.75 (the unigram
+    // table) + cn_i / train_words (as the centre word itself); and row i of u a context row: (window + 1 on average,
+    // SURVEY A.3) * cn_i / train_words.  The vocabulary is sorted by count, so the rows worth per-XCD copies are a prefix;
+    // how long a prefix is decided per launch from these rates and the number of workers (xhot_plan).
     double pw = 0, tot = 0;
     for (int64_t a = 0; a < V; a++) { pw += pow((double)cn[a], 0.75); tot += (double)cn[a]; }
-    int n = 0;
-    for (int64_t a = 1; a < V && a <= W2B_HOT_CAP; a++) {
-      const double rate = (pw > 0 ? t->cfg.negative * pow((double)cn[a], 0.75) / pw : 0) + (tot > 0 ? cn[a] / tot : 0);
-      if (rate < 0.1) break;
-      n++;
+    const int n = (int)(V - 1 < W2B_XHOT_MAX ? V - 1 : W2B_XHOT_MAX);
+    t->rate_v.assign((size_t)(n > 0 ? n : 0), 0.0);
+    t->rate_u.assign((size_t)(n > 0 ? n : 0), 0.0);
+    for (int k = 0; k < n; k++) {
+      const double c = (double)cn[k + 1];
+      t->rate_v[k] = (pw > 0 ? t->cfg.negative * pow(c, 0.75) / pw : 0) + (tot > 0 ? c / tot : 0);
+      t->rate_u[k] = tot > 0 ? (t->cfg.window + 1) * c / tot : 0;
     }
-    t->hot_wanted = n;
-    n = 0;                       // row i of u is a context row (window + 1 on average) * cn_i / train_words times per word
-    for (int64_t a = 1; a < V && a <= 4; a++) {
-      if (tot <= 0 || (t->cfg.window + 1) * (cn[a] / tot) < 0.1) break;
-      n++;
-    }
-    t->hot_wanted_u = n;
   }
   if (table_size > 0) {
     std::vector<int32_t> tab((size_t)table_size);
@@ -561,28 +591,83 @@ extern "C" int w2b_epoch_begin(w2b_trainer *t) {
 
 // Which worker kernel runs: plain_worker_kernel 0 = automatic (sentence-resident kernel for coherent rows when
 // the window fits in LDS; plain kernel for relaxed rows, where caching in L2 already absorbs the re-reads and
-// four workgroups per CU win), 1 = plain, 2 = sentence-resident whenever it fits.  Returns the radius (-1 = plain
-// kernel) and the number of private hot target rows.
-static int worker_plan(const w2b_trainer *t, int *hot) {
-  if (hot) *hot = 0;
-  int mode = t->cfg.plain_worker_kernel;
-  if (const char *e = getenv("W2B_WORKER_KERNEL")) mode = atoi(e);
+// four workgroups per CU win), 1 = plain, 2 = sentence-resident whenever it fits -- coherent rows only: relaxed rows and
+// the parity mode always run the plain kernel.  Returns the radius (-1 = plain kernel).
+static int worker_plan(const w2b_trainer *t) {
+  const int mode = t->cfg.plain_worker_kernel;
   if (mode == 1 || t->cfg.exact_reduction) return -1;   // the serial reduction lives in the plain kernel
   if (t->cfg.relaxed_coherence) return -1;              // the sentence-resident kernel exists for coherent rows only
-  if (const char *e = getenv("W2B_MEM_MODE")) if (atoi(e) != 0) return -1;
-  int want = t->hot_wanted;
-  if (const char *e = getenv("W2B_HOT_ROWS")) want = atoi(e);          // test hook: explicit number (0 = off)
-  if (want > t->cfg.vocab_size - 1) want = (int)t->cfg.vocab_size - 1;
-  return w2b_resident_plan(t->cfg.layer1_size, t->cfg.window, t->cfg.negative, want, hot);
+  if (t->tune.mem_mode > 0) return -1;
+  return w2b_resident_plan(t->cfg.layer1_size, t->cfg.window, t->cfg.negative);
+}
+
+// How many leading rows of u / v get per-XCD copies for a launch with `workers` concurrent workers / workgroups.
+// Explicit numbers (w2b_tuning.hot_rows_*) win; otherwise a row is taken when its expected load -- uses per centre word
+// x workers x row length -- reaches W2B_HOT_LOAD: a coherent row queues at its memory line (~7 M read-modify-writes per
+// second for a 3200-byte row), workers deliver ~50 K words/s each at 800 floats, and the load should stay well below a
+// tenth of that: rate x workers x floats >= 6400 is rate >= 0.016 for 512 workers of 800 floats (about 45 rows of a
+// 400 K-word Zipf vocabulary), none for 8 workers and none on flat distributions.  Only for 16-byte columns, coherent
+// rows, and not in the parity mode.
+static const double W2B_HOT_LOAD = 6400.0;
+static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv) {
+  *nu = *nv = 0;
+  const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
+  if (t->cfg.layer1_size % 4 != 0 || mem_mode != 0 || t->cfg.exact_reduction) return;
+  const long long vmax = t->cfg.vocab_size - 1 < W2B_XHOT_MAX ? t->cfg.vocab_size - 1 : W2B_XHOT_MAX;
+  auto pick = [&](int explicit_n, const std::vector<double> &rate) -> int {
+    long long n = 0;
+    if (explicit_n >= 0) n = explicit_n;
+    else {
+      const int cap = t->tune.hot_cap < W2B_XHOT_MAX ? t->tune.hot_cap : W2B_XHOT_MAX;
+      while (n < (long long)rate.size() && n < cap && rate[(size_t)n] * (double)workers * t->cfg.layer1_size >= W2B_HOT_LOAD) n++;
+    }
+    return (int)(n < vmax ? n : (vmax > 0 ? vmax : 0));
+  };
+  *nv = pick(t->tune.hot_rows_v, t->rate_v);
+  if (with_u) *nu = pick(t->tune.hot_rows_u, t->rate_u);
+}
+
+// Buffer + parameters of the XCD-shared hot rows for one launch; folds the copies into the masters first when the
+// layout changed or somebody wrote the master rows since the last launch.
+static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool with_u) {
+  int nu = 0, nv = 0;
+  xhot_plan(t, workers, with_u, &nu, &nv);
+  p.xhot = nullptr;
+  p.xhot_u = nu;
+  p.xhot_v = nv;
+  if (nu + nv == 0) return W2B_OK;
+  const size_t need = (size_t)W2B_NXCD * 2 * (nu + nv) * t->cfg.layer1_size;
+  bool fresh = (nu != t->xhot_nu || nv != t->xhot_nv);
+  if (need > t->xhot_floats) {
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if (t->xhot) HIPCHK(hipFree(t->xhot));
+    t->xhot = nullptr;
+    t->xhot_floats = 0;
+    HIPCHK(hipMalloc(&t->xhot, sizeof(float) * need));
+    t->xhot_floats = need;
+    fresh = true;
+  }
+  p.xhot = t->xhot;
+  const long long per_xcd = workers / W2B_NXCD > 0 ? workers / W2B_NXCD : 1;
+  const int most = nu > nv ? nu : nv;
+  p.xhot_m = (int)((most + per_xcd - 1) / per_xcd);       // every copy of an XCD is merged about once per hot_period steps
+  if (fresh) {         // copy == entry (== 0) everywhere: the fold below adopts the master rows
+    HIPCHK(hipMemsetAsync(t->xhot, 0, sizeof(float) * need, t->stream));
+    t->xhot_nu = nu;
+    t->xhot_nv = nv;
+    t->xhot_master_changed = true;
+  }
+  if (t->xhot_master_changed) HIPCHK(w2b_launch_xhot_fold(p, t->stream));
+  t->xhot_master_changed = false;
+  return W2B_OK;
 }
 
 extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
   NEED(t);
   if (!out) return fail(W2B_EINVAL, "w2b_suggested_threads: null");
   const W2bParams p = make_params(t);
-  int hot = 0;
-  const int radius = worker_plan(t, &hot);
-  const int per_cu = radius >= 0 ? w2b_resident_per_cu(p, radius, hot, t->cfg.compute_loss != 0)
+  const int radius = worker_plan(t);
+  const int per_cu = radius >= 0 ? w2b_resident_per_cu(p, radius, t->cfg.compute_loss != 0)
                                  : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
   long long n = (long long)per_cu * t->num_cus;
   // A worker adjusts alpha only after >10000 of its own words (ref :379-393): with shards shorter than that no worker
@@ -602,8 +687,9 @@ extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t
                                       int32_t *workgroups_per_cu, int32_t *hot_rows) {
   NEED(t);
   const W2bParams p = make_params(t);
-  int hot = 0;
-  const int r = worker_plan(t, &hot);
+  const int r = worker_plan(t);
+  int hu = 0, hot = 0;
+  xhot_plan(t, t->cfg.num_threads, r < 0, &hu, &hot);
   if (resident) *resident = r >= 0;
   if (radius) *radius = r;
   if (hot_rows) *hot_rows = hot;
@@ -611,7 +697,7 @@ extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t
   (void)w2b_block_threads(t->cfg.layer1_size, &vec);
   if (column_bytes) *column_bytes = 4 * (r >= 0 ? 4 : vec);
   if (workgroups_per_cu)
-    *workgroups_per_cu = r >= 0 ? w2b_resident_per_cu(p, r, hot, t->cfg.compute_loss != 0)
+    *workgroups_per_cu = r >= 0 ? w2b_resident_per_cu(p, r, t->cfg.compute_loss != 0)
                                 : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
   return W2B_OK;
 }
@@ -620,10 +706,9 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   NEED(t);
   if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_train_step: corpus/shards not set");
   if (max_positions <= 0) return fail(W2B_EINVAL, "w2b_train_step: max_positions must be positive");
-  int hot = 0;
-  const int radius = worker_plan(t, &hot);
+  const int radius = worker_plan(t);
   if (radius >= 0) {                       // scratch rows of the sentence-resident kernel (grown on demand)
-    const size_t need = (size_t)t->cfg.num_threads * (size_t)w2b_resident_scratch_rows(radius, hot) * t->cfg.layer1_size;
+    const size_t need = (size_t)t->cfg.num_threads * (size_t)w2b_resident_scratch_rows(radius) * t->cfg.layer1_size;
     if (need > t->entry_floats) {
       HIPCHK(hipStreamSynchronize(t->stream));
       if (t->entry) HIPCHK(hipFree(t->entry));
@@ -633,11 +718,14 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
       t->entry_floats = need;
     }
   }
-  const W2bParams p = make_params(t);
+  W2bParams p = make_params(t);
+  // per-XCD copies of the hottest rows: v only for the sentence-resident kernel (its context rows live in LDS)
+  if (int rc = xhot_prepare(t, p, t->cfg.num_threads, radius < 0)) return rc;
   HIPCHK(timing_begin(t));
-  if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, hot, t->cfg.compute_loss != 0, t->stream));
+  if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream));
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));
+  HIPCHK(w2b_launch_xhot_fold(p, t->stream));      // the master rows are complete again when the stream is idle
   {   // progress snapshot of this launch for w2b_epoch_poll (asynchronous; pinned host memory)
     if (!t->poll_host) {
       HIPCHK(hipHostMalloc((void **)&t->poll_host, sizeof(W2bShared) * w2b_trainer::kPoll, hipHostMallocDefault));
@@ -702,40 +790,17 @@ extern "C" int w2b_train_tuples_device(w2b_trainer *t, int64_t n, const void *ce
   if (n == 0) return W2B_OK;
   W2bParams p = make_params(t);
   {
-    // private hot rows per workgroup (coherent rows, 16-byte columns, not in the parity mode): at most two of each
-    // table, so that three workgroups still share a CU's LDS; W2B_TUPLE_HOT="u,v" overrides (test hook)
-    int hu = t->hot_wanted_u < 2 ? t->hot_wanted_u : 2, hv = t->hot_wanted < 2 ? t->hot_wanted : 2;
-    if (const char *e = getenv("W2B_TUPLE_HOT")) {
-      if (sscanf(e, "%d,%d", &hu, &hv) != 2) hu = hv = 0;
-      if (hu < 0 || hu > 8) hu = 0;
-      if (hv < 0 || hv > 8) hv = 0;
-    }
-    int vec = 0;
-    const int threads = w2b_block_threads(t->cfg.layer1_size, &vec);
-    if (vec != 4 || threads > 256 || p.mem_mode != 0 || p.exact || t->cfg.vocab_size <= 8) hu = hv = 0;
-    p.hot_u = hu;
-    p.hot_v = hv;
-    if (hu + hv > 0) {
-      long long wgs = w2b_tuple_max_grid(t->num_cus);
-      if (grid > wgs) wgs = grid;
-      if ((long long)t->grid_per_cu * t->num_cus > wgs) wgs = (long long)t->grid_per_cu * t->num_cus;
-      const size_t need = (size_t)wgs * (hu + hv) * t->cfg.layer1_size;
-      if (need > t->entry_floats) {
-        HIPCHK(hipStreamSynchronize(t->stream));
-        if (t->entry) HIPCHK(hipFree(t->entry));
-        t->entry = nullptr;
-        t->entry_floats = 0;
-        HIPCHK(hipMalloc(&t->entry, sizeof(float) * need));
-        t->entry_floats = need;
-      }
-      p.entry = t->entry;
-    }
+    // per-XCD copies of the hottest rows of both tables; the load estimate uses the workgroups that will run
+    long long wgs = grid > 0 ? grid : (long long)(t->tune.grid_per_cu > 0 ? t->tune.grid_per_cu : 4) * t->num_cus;
+    if (wgs > n) wgs = n;
+    if (int rc = xhot_prepare(t, p, wgs, true)) return rc;
   }
   HIPCHK(timing_begin(t));
   HIPCHK(w2b_launch_tuples(p, n, (const int32_t *)center, (const int32_t *)ctx_off, (const int32_t *)ctx,
-                           (const int32_t *)neg, alpha, grid > 0 ? grid : 0, t->num_cus, t->grid_per_cu,
+                           (const int32_t *)neg, alpha, grid > 0 ? grid : 0, t->num_cus, t->tune.grid_per_cu,
                            t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));
+  HIPCHK(w2b_launch_xhot_fold(p, t->stream));
   return W2B_OK;
 }
 
@@ -842,6 +907,7 @@ extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
   if (t->nranks <= 1 || !t->comm) return W2B_OK;
   if (mode != 0 && mode != 1) return fail(W2B_EINVAL, "w2b_sync_replicas: unknown mode");
   const long long n = 2 * t->table_elems;
+  t->xhot_master_changed = true;
   HIPCHK(hipEventRecord(t->sync_a, t->stream));
   // progress first (16 bytes): every replica learns the global word count -- the alpha schedule (ref :391) is exact
   // at every exchange and extrapolates in between (W2bShared::wca_others)

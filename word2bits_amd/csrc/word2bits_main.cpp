@@ -6,7 +6,7 @@
 // happens: the corpus is tokenised once on the host (word2bits_corpus.h) and every epoch is a
 // sequence of GPU launches in which each of the -threads Hogwild workers is one workgroup.
 // GPU-only additions use new flag names: -gpus, -sync-every, -positions, -device, -table-size, -relaxed,
-// -window-cache, -exact, -eval.
+// -window-cache, -exact, -eval, -hot-rows, -hot-period, -row-desc.
 #include <pthread.h>
 #include <unistd.h>
 
@@ -38,6 +38,9 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int window_cache = -1;               // -1 automatic, 0 plain worker kernel, 1 sentence-resident kernel
   int exact = 0;                       // 1: serial dot product in the reference's order (bit parity at -threads 1)
   std::string eval_file;               // -eval FILE: questions to score on the GPU after the final save (-binary 1)
+  int hot_rows = -1;                   // -hot-rows N: leading rows of v (and u) with per-XCD copies; -1 = from the counts
+  int hot_period = 0;                  // -hot-period N: centre words between two merge events of a worker (0 = default)
+  int row_desc = 0;                    // -row-desc 1: the row addressing of tables >= 2 GiB on any table (w2b_tuning.force_row_desc)
 };
 
 // ArgPos, ref :579-589: exact-match search; a flag in last position has no value -> exit(1)
@@ -116,6 +119,9 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-window-cache", argc, argv)) > 0) o.window_cache = atoi(argv[i + 1]);
   if ((i = arg_pos("-exact", argc, argv)) > 0) o.exact = atoi(argv[i + 1]);
   if ((i = arg_pos("-eval", argc, argv)) > 0) o.eval_file = argv[i + 1];
+  if ((i = arg_pos("-hot-rows", argc, argv)) > 0) o.hot_rows = atoi(argv[i + 1]);
+  if ((i = arg_pos("-hot-period", argc, argv)) > 0) o.hot_period = atoi(argv[i + 1]);
+  if ((i = arg_pos("-row-desc", argc, argv)) > 0) o.row_desc = atoi(argv[i + 1]);
 
   // ---- TrainModel, ref :518-577
   printf("Starting training using file %s\n", o.train_file.c_str());
@@ -160,6 +166,13 @@ int main(int argc, char **argv) {
     o.num_threads = per_gpu * o.gpus;
     if (o.debug_mode > 0) printf("Hogwild workers (workgroups): %d\n", o.num_threads);
   }
+  // A worker re-computes alpha only after more than 10000 of its own words (ref :379-393).  The reference has the same
+  // property, but nobody starts it with hundreds of threads on a small file; a GPU invites exactly that.
+  if (o.num_threads > 1 && train_words / o.num_threads < 20000)
+    fprintf(stderr, "word2bits: warning: -threads %d leaves %lld words per worker and epoch; below 20000 the learning "
+                    "rate schedule (re-computed per worker every 10000 words) hardly runs -- -threads 0 picks at most "
+                    "%lld workers for this file\n", o.num_threads, train_words / o.num_threads,
+            train_words / 20000 > 1 ? train_words / 20000 : 1);
   if (o.gpus > 1 && o.num_threads % o.gpus != 0) {
     fprintf(stderr, "word2bits: -threads must be a multiple of -gpus\n");
     return 2;
@@ -200,6 +213,14 @@ int main(int argc, char **argv) {
     cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
+    if (o.hot_rows >= 0 || o.hot_period > 0 || o.row_desc) {
+      w2b_tuning tn;
+      CK(w2b_get_tuning(a->r->t, &tn));
+      if (o.hot_rows >= 0) tn.hot_rows_v = tn.hot_rows_u = o.hot_rows;
+      if (o.hot_period > 0) tn.hot_period = o.hot_period;
+      tn.force_row_desc = o.row_desc ? 1 : 0;
+      CK(w2b_set_tuning(a->r->t, &tn));
+    }
     CK(w2b_init_net(a->r->t));                              // ref :528
     CK(w2b_set_vocab_counts(a->r->t, w2b_corpus_counts(a->c), o.negative > 0 ? o.table_size : 0));  // ref :529
     CK(w2b_set_corpus(a->r->t, w2b_corpus_tokens(a->c), w2b_corpus_num_tokens(a->c)));

@@ -84,9 +84,13 @@ class Corpus:
 class Trainer:
     """One model replica on one GPU (the reference's globals u, v, alpha, word_count_actual, ...)."""
 
+    # knobs of struct w2b_tuning applied to every new Trainer before the keyword arguments (tests re-run whole test
+    # functions under e.g. force_row_desc=1 by patching this dict)
+    default_tuning = {}
+
     def __init__(self, vocab_size, layer1_size=100, window=5, negative=5, bitlevel=1, num_threads=12,
                  iter=5, alpha=0.05, sample=1e-3, reg=0.0, train_words=0, compute_loss=True, device=0,
-                 worker_offset=0, total_threads=0, relaxed_coherence=False, window_cache=None, exact=False):
+                 worker_offset=0, total_threads=0, relaxed_coherence=False, window_cache=None, exact=False, **tuning):
         cfg = Config()
         cfg.vocab_size, cfg.train_words, cfg.iter = int(vocab_size), int(train_words), int(iter)
         cfg.layer1_size, cfg.window, cfg.negative = int(layer1_size), int(window), int(negative)
@@ -104,6 +108,24 @@ class Trainer:
         check(lib().w2b_trainer_create(C.byref(cfg), C.byref(self._h)))
         self.vocab_size, self.layer1_size = int(vocab_size), int(layer1_size)
         self.num_threads = int(num_threads)
+        tuning = dict(self.default_tuning, **tuning)
+        if tuning:                 # hot_rows_v, hot_rows_u, hot_period, hot_cap, force_row_desc, grid_per_cu, mem_mode
+            self.set_tuning(**tuning)
+
+    # ---- tuning knobs (struct w2b_tuning)
+    def get_tuning(self):
+        tn = _lib.Tuning()
+        check(lib().w2b_get_tuning(self._h, C.byref(tn)))
+        return {k: getattr(tn, k) for k, _ in _lib.Tuning._fields_ if k not in ("struct_size", "reserved")}
+
+    def set_tuning(self, **kw):
+        tn = _lib.Tuning()
+        check(lib().w2b_get_tuning(self._h, C.byref(tn)))
+        for k, v in kw.items():
+            if k in ("struct_size", "reserved") or not hasattr(tn, k):
+                raise TypeError("unknown tuning knob %r" % k)
+            setattr(tn, k, int(v))
+        check(lib().w2b_set_tuning(self._h, C.byref(tn)))
 
     # ---- model
     def init_net(self):
