@@ -87,6 +87,8 @@ def parse():
                     help="w2b_tuning.hot_rows_v / hot_rows_u: leading rows with per-XCD copies (-1 = from the word counts)")
     ap.add_argument("--hot-period", type=int, default=0, help="w2b_tuning.hot_period (0 = library default)")
     ap.add_argument("--hot-cap", type=int, default=-1, help="w2b_tuning.hot_cap (-1 = library default)")
+    ap.add_argument("--atomic-rank", type=int, default=-2, help="w2b_tuning.atomic_rank (-2 = library default, -1 = automatic)")
+    ap.add_argument("--atomic-cap", type=int, default=-1, help="w2b_tuning.atomic_cap (-1 = library default)")
     ap.add_argument("--eval-questions", type=int, default=19544, help="--form eval: questions (questions-words.txt)")
     ap.add_argument("--eval-kind", choices=["1bit", "fp"], default="1bit")
     ap.add_argument("--eval-cpu-questions", type=int, default=24)
@@ -367,6 +369,10 @@ def main():
         tune["hot_period"] = args.hot_period
     if args.hot_cap >= 0:
         tune["hot_cap"] = args.hot_cap
+    if args.atomic_rank >= -1:
+        tune["atomic_rank"] = args.atomic_rank
+    if args.atomic_cap >= 0:
+        tune["atomic_cap"] = args.atomic_cap
 
     def make_trainer(relaxed, loss=bool(args.loss), bitlevel=args.bitlevel):
         tr = w2b.Trainer(V, D, W, K, bitlevel, num_threads=nw_local,
@@ -396,13 +402,12 @@ def main():
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0:
-            torch_sync = replicas.TorchReplicaSync(dist, args.sync_mode)
-            model_view = t.model_tensor()
-            base_view = model_view.clone()
-            sync_impl = "torch.distributed all_reduce (%s) on a view of [u||v]%s" % (
+            t.exchange_init()                                   # the replicas are identical here (InitNet)
+            torch_sync = replicas.PhasedReplicaSync(dist, t, args.sync_mode)
+            sync_impl = "library exchange kernels (w2b_exchange_*) + torch.distributed all_reduce (%s)%s" % (
                 "RCCL" if backend == "nccl" else backend, " -- SMOKE TEST: ranks share GPUs, not a measurement" if shared else "")
         else:
-            sync_impl = "library RCCL communicator (w2b_sync_replicas)"
+            sync_impl = "library RCCL communicator (w2b_sync_replicas): chunked, on its own streams, overlapped with training"
 
     nsteps = args.steps + args.warmup
     kinfo = None
@@ -472,9 +477,7 @@ def main():
 
     def exchange():
         if torch_sync is not None:
-            t.synchronize()
-            torch_sync.sync(model_view, base_view)
-            torch.cuda.synchronize()
+            torch_sync.sync()
         else:
             t.sync_replicas(args.sync_mode)
         n_syncs[0] += 1
@@ -503,13 +506,9 @@ def main():
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0 and torch_sync is None:
-            torch_sync = replicas.TorchReplicaSync(dist, args.sync_mode)
-            model_view = t.model_tensor()
-            base_view = model_view.clone()
-            sync_impl = "torch.distributed all_reduce (RCCL) on a view of [u||v] (library exchange failed)"
+            raise SystemExit("library exchange failed after its communicator was created")
         n_syncs[0] = 0
-        if torch_sync is None:
-            t.sync_stats()
+        t.sync_stats()
     t.synchronize()
     t.timing_enable(True)
     t.timing_read()
@@ -522,7 +521,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, launches = t.timing_read()
-    sync_n, sync_ms = t.sync_stats() if (world > 1 and torch_sync is None) else (0, 0.0)
+    sync_n, sync_ms = t.sync_stats() if world > 1 else (0, 0.0)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -582,8 +581,13 @@ def main():
         result["replica_exchange"] = {
             "every_steps": args.sync_every, "mode": "delta-sum" if args.sync_mode == 0 else "average",
             "implementation": sync_impl, "exchanges": n_syncs[0],
-            "bytes_all_reduced_per_exchange": 8 * V * D,
-            "device_ms_per_exchange": (sync_ms / sync_n) if sync_n else None}
+            "bytes": 8 * V * D, "bytes_all_reduced_per_exchange": 8 * V * D,
+            "device_ms": (sync_ms / sync_n) if sync_n else None,
+            "device_ms_per_exchange": (sync_ms / sync_n) if sync_n else None,
+            # the library's own communicator runs the exchange on its own streams next to the training launches; with a
+            # host-driven collective (torch.distributed) the host waits for every chunk
+            "overlapped": torch_sync is None,
+            "chunk_bytes": min(8 * V * D, 256 << 20)}
     t.close()
 
     def timed_leg(tr, wps):

@@ -124,7 +124,13 @@ typedef struct w2b_tuning {
   int32_t force_row_desc;  /* 1: address rows through per-row buffer descriptors (the form tables >= 2 GiB use) on any table */
   int32_t grid_per_cu;     /* tuple form: workgroups per CU (0 = occupancy query) */
   int32_t mem_mode;        /* -1 = from w2b_config.relaxed_coherence (default); 0 / 1 override it */
-  int32_t reserved[8];
+  /* Rows 1..atomic_rank (by count; beyond the hot rows) are updated with fp32 atomic adds at their own address instead of
+   * load / modify / store: nothing another worker adds during the ~10 us a chunk of rows is in flight is lost, at the
+   * price of more memory time per update.  -1 = automatic: the rows whose expected number of concurrent updates reaches
+   * a threshold (computed from the word counts and the number of workers), at most atomic_cap of them. */
+  int32_t atomic_rank;
+  int32_t atomic_cap;
+  int32_t reserved[6];
 } w2b_tuning;
 int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out);
 int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in);
@@ -152,6 +158,12 @@ int w2b_set_exp_table(w2b_trainer *t, const float *exp_table);      /* default: 
  * word maps to (-1: not in vocabulary, -2: seek landed on a token boundary). */
 int w2b_set_corpus(w2b_trainer *t, const int32_t *ids, int64_t n_tokens);
 int w2b_set_corpus_device(w2b_trainer *t, const void *ids_dev, int64_t n_tokens); /* not copied */
+/* Replicas: only the part of the stream a replica's workers read has to be resident -- from its first worker's start to
+ * where its last worker stops (quota train_words/total_threads, ref :414, plus the sentence it is in).  ids[0..n) is
+ * that slice, shard starts are relative to it.  more_follows != 0: the file continues behind the slice; a worker that
+ * reaches the end of the slice anyway (slice cut too short) makes w2b_epoch_poll / w2b_epoch_status fail with
+ * W2B_ESTATE instead of silently ending its shard as if the file had ended. */
+int w2b_set_corpus_slice(w2b_trainer *t, const int32_t *ids, int64_t n_tokens, int32_t more_follows);
 int w2b_set_shards(w2b_trainer *t, const int64_t *starts, const int32_t *first_override /*or NULL*/);
 /* pthread_create of one epoch (ref :535): re-seed every worker (next_random = id, ref :368),
  * rewind it to its shard start.  alpha / word_count_actual keep running across epochs. */
@@ -203,15 +215,38 @@ int w2b_timing_enable(w2b_trainer *t, int32_t on);
 int w2b_timing_read(w2b_trainer *t, double *kernel_ms, int64_t *launches); /* syncs, then resets */
 
 /* ---- multi-GPU: one process per GPU, replicas + periodic all-reduce over RCCL ----------------
- * Replaces the shared-memory Hogwild of ref :535-536 across devices. */
+ * Replaces the shared-memory Hogwild of ref :535-536 across devices.  Every replica keeps `base`, the
+ * state all replicas agreed on at the last exchange.  An exchange sums what every replica has added since:
+ *      d_r = W_r - base;   S = sum_r d_r;   W_r += a * S - d_r;   base += a * S     (a = 1: delta-sum, a = 1/R: average)
+ * chunk by chunk (256 MB) on two exchange streams of its own, so that the elementwise kernels of one chunk overlap with
+ * the collective of the other AND with the training launches issued meanwhile: w2b_sync_replicas returns at once, the
+ * other replicas' contribution lands on top of whatever this replica has trained in between, and only a reader of the
+ * model (w2b_get_model, w2b_export_quantized, w2b_epoch_status, w2b_synchronize, ...) waits for the exchange. */
 #define W2B_UNIQUE_ID_BYTES 128
 int w2b_comm_unique_id(void *out128);                      /* rank 0 creates, others receive */
+/* Call while all replicas hold the same model (after w2b_init_net / w2b_set_model).  nranks == 1 with id128 == NULL
+ * creates no communicator (w2b_sync_replicas is then a no-op); with an id a communicator of size 1 is created and the
+ * whole exchange path runs (a way to exercise it on a one-GPU machine; the model stays bit-identical). */
 int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id128);
-/* mode 0: delta-sum  W = base + sum_r (W_r - base);  mode 1: average  W = mean_r W_r.
- * A communicator of size 1 (or none) is a no-op that leaves the model bit-identical. */
+/* mode 0: delta-sum;  mode 1: average of the deltas.  Asynchronous (see above). */
 int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
-/* exchanges since the last call and (when w2b_timing_enable is on) their summed device time; resets both */
+/* exchanges since the last call and their summed device time (begin of the first chunk -> end of the last; waits for
+ * the exchanges in flight); resets both */
 int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
+
+/* The same exchange for hosts that bring their own collective (MPI, torch.distributed over gloo or RCCL, ...):
+ *   w2b_exchange_init once, while all replicas hold the same model; then per exchange
+ *   w2b_exchange_begin(&n_chunks, &my_words)
+ *   for c in [0, n_chunks): w2b_exchange_delta(c, &buf, &n)   -- buf[0..n) = this replica's delta (device memory, complete
+ *                            on return);  the host sums buf over all replicas IN PLACE with its collective;
+ *                           w2b_exchange_apply(c, a)          -- expects the sum to be complete
+ *   w2b_exchange_end(sum of all replicas' my_words, or -1)     -- the alpha schedule (ref :391) runs on the global count
+ * Chunks c and c + 1 use different staging buffers and streams, so a host may pipeline them. */
+int w2b_exchange_init(w2b_trainer *t);
+int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count /* or NULL */);
+int w2b_exchange_delta(w2b_trainer *t, int64_t chunk, void **buf_dev, int64_t *elems);
+int w2b_exchange_apply(w2b_trainer *t, int64_t chunk, float scale);
+int w2b_exchange_end(w2b_trainer *t, int64_t word_count_all_replicas);
 
 #ifdef __cplusplus
 }

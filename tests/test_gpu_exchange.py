@@ -1,0 +1,217 @@
+"""-m gpu: the replica exchange of the library (w2b_sync_replicas / w2b_exchange_*), as far as ONE GPU allows.
+
+RCCL does not put two ranks on one device, so the N > 1 collective itself cannot run on this pool.  Everything around
+it can:
+  * a communicator of size 1 (w2b_comm_init with an id) drives the whole RCCL path -- base snapshot, delta kernel,
+    ncclAllReduce, apply kernel, the progress counters, two exchange streams, fences -- and must leave training
+    bit-identical to a trainer without a communicator;
+  * the phase API (w2b_exchange_begin / delta / apply / end) is the same code with the sum supplied by the host: R
+    replicas live in this process on one GPU and the "collective" is a torch sum of their delta buffers.  That pins the
+    arithmetic (W_r += sum - d_r, base += sum) against host copies, and -- the point of this file -- the TRAINING EFFECT of
+    exchanging only every k launches: 2 and 4 replicas against one replica with the same total number of workers on the
+    text8-sized corpus (ref src/word2bits.cpp:535-536 runs all threads on one shared model; delta-sum adds every
+    replica's update of a hot row on top of the others', which is where a too lazy exchange would show)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import word2bits_amd as w2b
+from word2bits_amd import replicas
+from w2b_testlib import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def small_setup(nw, total, offset, seed=3, V=3000, D=64, n=60000, **kw):
+    rng = np.random.default_rng(seed)
+    ids = (rng.zipf(1.3, n) % (V - 1) + 1).astype(np.int32)
+    ids[49::50] = 0
+    counts = np.maximum(np.bincount(ids, minlength=V), 1).astype(np.int64)
+    t = w2b.Trainer(V, D, 5, 5, 1, num_threads=nw, iter=1, sample=0.0, train_words=int(counts.sum()),
+                    compute_loss=True, worker_offset=offset, total_threads=total, **kw)
+    t.init_net()
+    t.set_vocab_counts(counts, 100000)
+    t.set_corpus(ids)
+    t.set_shards(replicas.token_shard_starts(len(ids), total, offset, nw))
+    return t
+
+
+def flat(t):
+    return np.concatenate([x.ravel() for x in t.get_model()])
+
+
+def test_size_one_communicator_runs_the_whole_exchange_and_changes_nothing(gpu):
+    """the RCCL exchange path had never executed.  One rank, a real communicator: every exchange must
+    leave the model bit-identical, the alpha schedule untouched (wca_others = 0), and the run equal to a trainer that
+    never exchanges -- deterministic here because there is one worker."""
+    res = []
+    for with_comm in (False, True):
+        t = small_setup(1, 1, 0)
+        if with_comm:
+            t.comm_init(1, 0, w2b.comm_unique_id())
+        t.epoch_begin()
+        for k in range(12):
+            t.train_step(300)
+            if with_comm and k % 3 == 2:
+                before = None
+                if k == 5:
+                    t.synchronize()
+                    before = flat(t)
+                t.sync_replicas(k % 2)                       # both modes
+                if before is not None:
+                    assert np.array_equal(before.view(np.uint32), flat(t).view(np.uint32))
+        fin, wca, alpha, loss = t.epoch_status()
+        res.append((flat(t), wca, alpha, loss))
+        if with_comm:
+            n, ms = t.sync_stats()
+            assert n == 4 and ms > 0
+        t.close()
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    assert res[0][1:] == res[1][1:]
+
+
+def local_exchange(ts, mode=0):
+    """the host-supplied collective of the phase API for replicas that live in this process: sum of the delta buffers"""
+    import torch
+    begun = [t.exchange_begin() for t in ts]
+    n_chunks = begun[0][0]
+    scale = 1.0 if mode == 0 else 1.0 / len(ts)
+    for c in range(n_chunks):
+        bufs = [t.device_tensor(*t.exchange_delta(c)) for t in ts]
+        total = torch.stack(bufs).sum(0)
+        for b in bufs:
+            b.copy_(total)
+        torch.cuda.synchronize()
+        for t in ts:
+            t.exchange_apply(c, scale)
+    words = sum(b[1] for b in begun)
+    for t in ts:
+        t.exchange_end(words)
+    return words
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_phase_api_arithmetic_two_replicas(gpu, mode):
+    """W_r += a * sum - d_r on top of the CURRENT rows, base += a * sum: against host arithmetic on copies of both
+    replicas, with training launches issued between the delta and the read-back (they must survive the exchange)."""
+    R, nw = 2, 4
+    ts = [small_setup(nw, R * nw, r * nw, seed=3) for r in range(R)]
+    for t in ts:
+        t.exchange_init()
+        t.epoch_begin()
+    base = flat(ts[0])
+    assert np.array_equal(base, flat(ts[1]))
+    a = 1.0 if mode == 0 else 1.0 / R
+    for rnd in range(3):
+        for t in ts:
+            for _ in range(3):
+                t.train_step(150)
+        mine = [flat(t) for t in ts]
+        d = [m - base for m in mine]
+        total = np.float32(a) * (d[0] + d[1])
+        words = local_exchange(ts, mode)
+        got = [flat(t) for t in ts]
+        for r in range(R):
+            want = mine[r] + (total - d[r])
+            assert np.abs(got[r] - want).max() <= 2e-6, (rnd, r)
+            assert np.abs(got[r] - mine[r]).max() > 0            # the other replica's work arrived
+        base = base + total
+        assert words == sum(t.epoch_status(want_loss=False)[1] for t in ts)
+    if mode == 0:
+        assert np.abs(got[0] - got[1]).max() <= 4e-6             # delta-sum: the replicas agree after every exchange
+    for t in ts:
+        t.close()
+
+
+def test_exchange_needs_init(gpu):
+    t = small_setup(2, 2, 0)
+    with pytest.raises(w2b.W2bError) as e:
+        t.exchange_begin()
+    assert "exchange_init" in str(e.value)
+    t.close()
+
+
+# ---------------------------------------------------------------------------------------------- training effect
+def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=True):
+    """one epoch over `corpus` with R replicas of workers_total / R workers each, exchanged every sync_every launches
+    and at the end; returns the summed epoch loss"""
+    per = workers_total // R
+    starts, ov = corpus.shards(workers_total)
+    tokens = corpus.tokens()
+    quota = corpus.train_words // workers_total
+    ts = []
+    for r in range(R):
+        t = w2b.Trainer(corpus.vocab_size, flags["size"], flags["window"], flags["negative"], flags["bitlevel"],
+                        num_threads=per, iter=1, train_words=corpus.train_words, compute_loss=True,
+                        worker_offset=r * per, total_threads=workers_total)
+        t.init_net()
+        t.set_vocab_counts(corpus.counts(), 100_000_000)
+        st = starts[r * per:(r + 1) * per]
+        if slices and R > 1:
+            lo, hi, more = replicas.replica_token_slice(tokens, st, quota)
+            t.set_corpus_slice(tokens[lo:hi], more)
+            t.set_shards(st - lo, ov[r * per:(r + 1) * per])
+        else:
+            t.set_corpus(tokens)
+            t.set_shards(st, ov[r * per:(r + 1) * per])
+        if R > 1:
+            t.exchange_init()
+        t.epoch_begin()
+        ts.append(t)
+    launches = 0
+    while True:
+        for t in ts:
+            t.train_step(positions)
+        launches += 1
+        done = all(t.epoch_poll(0)[0] for t in ts)
+        if R > 1 and (done or launches % sync_every == 0):
+            local_exchange(ts, 0)
+        if done:
+            break
+    loss = sum(t.epoch_status()[3] for t in ts)
+    models = [flat(t) for t in ts] if R > 1 else None
+    for t in ts:
+        t.close()
+    if models:                                  # after the final exchange every replica holds the same model
+        for m in models[1:]:
+            assert np.abs(m - models[0]).max() <= 1e-4
+    return loss, launches
+
+
+def test_training_effect_of_the_exchange_text8_size(gpu, tmp_path_factory):
+    """17 M tokens, 70 K words, bitlevel 1, size 200, window 8, negative 24, one epoch.  The number of workers is what
+    `./word2bits -threads 0` picks for the file; it is split over 1, 2 and 4 replicas, which exchange every 1 / 8 / 32
+    launches (and at the end).  A replica sees the other replicas' updates of a row only at an exchange, and delta-sum
+    adds all replicas' updates of a hot row up, so a lazy exchange trains the hot rows with an R times larger effective
+    step between two exchanges: asserted is that the epoch loss stays within EXCHANGE_RTOL of the single replica's, and
+    within the band of the reference's own runs (tests/golden/fidelity_bands.json) widened by the same amount."""
+    from w2b_testlib import write_zipf_text_corpus
+    d = tmp_path_factory.mktemp("xchg")
+    path = write_zipf_text_corpus(str(d / "c.txt"))
+    corpus = w2b.Corpus(path, 5)
+    flags = dict(bitlevel=1, size=200, window=8, negative=24)
+    probe = w2b.Trainer(2, 200, 8, 24, 1, num_threads=1, train_words=corpus.train_words)
+    workers = probe.suggested_threads()
+    probe.close()
+    workers -= workers % 4
+    positions = 1024
+    one, launches = run_replicas(corpus, 1, workers, 1, positions, flags)
+    print("EXCHANGE text8size workers=%d launches/epoch=%d: 1 replica loss %.0f" % (workers, launches, one))
+    res = {}
+    for R in (2, 4):
+        for every in (1, 8, 32):
+            loss, _ = run_replicas(corpus, R, workers, every, positions, flags)
+            res[(R, every)] = loss
+            print("EXCHANGE text8size replicas=%d sync-every=%d: loss %.0f (%+.2f %% vs 1 replica)" %
+                  (R, every, loss, 100 * (loss - one) / abs(one)))
+    for (R, every), loss in res.items():
+        assert abs(loss - one) <= EXCHANGE_RTOL[every] * abs(one), (R, every, loss, one)
+    corpus.close()
+
+
+# epoch-loss tolerance against the single replica, by launches between two exchanges (one epoch is ~20 launches of 1024
+# positions per worker here, so 32 means "only at the end of the epoch": the replicas train independently on their
+# quarter of the corpus and are summed once)
+EXCHANGE_RTOL = {1: 0.02, 8: 0.04, 32: 0.10}

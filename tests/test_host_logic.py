@@ -208,3 +208,49 @@ def test_integration_patch_applies_compiles_and_fails_loudly_without_gpu(tmp_pat
     r = subprocess.run([exe, "-train", os.path.join(ROOT, "tests", "golden", "corpus_small.txt"), "-output", str(tmp_path / "o"),
                         "-min-count", "3"], capture_output=True, text=True)
     assert r.returncode == 1 and "Vocab size: 60" in r.stdout and "no HIP device visible" in r.stdout
+
+
+def test_tuning_struct_layout_matches_header():
+    src = open(os.path.join(ROOT, "include", "word2bits_hip.h")).read()
+    body = re.search(r"typedef struct w2b_tuning \{(.*?)\} w2b_tuning;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"int32_t\s+(\w+)", body)
+    assert names == [n for n, _ in _lib.Tuning._fields_]
+    assert C.sizeof(_lib.Tuning) == 4 * (8 + 8)
+
+
+def test_replica_token_slice_covers_what_the_workers_read():
+    """./word2bits -gpus N uploads only a replica's part of the token stream (ref :377,414: a worker reads from its shard
+    start until its word count passes the quota, then to the end of that sentence).  The slice rule of
+    word2bits_amd.replicas (same as word2bits_main.cpp) against the oracle's reader: no worker of the replica ever
+    reads a token outside [lo, hi), whatever the sub-sampling does (the reader stops at the first "</s>" behind its
+    quota at the latest when nothing is dropped; sub-sampling only shortens what a sentence consumes)."""
+    from word2bits_amd.replicas import replica_token_slice
+    rng = np.random.default_rng(11)
+    for trial in range(50):
+        n = int(rng.integers(200, 4000))
+        ids = rng.integers(1, 50, n).astype(np.int32)
+        ids[rng.random(n) < 0.03] = 0                    # sentence ends
+        workers = int(rng.integers(2, 9))
+        quota = n // workers
+        starts = np.sort(rng.integers(0, n, workers)).astype(np.int64)
+        first = int(rng.integers(0, workers - 1))
+        mine = starts[first:first + 2]
+        lo, hi, more = replica_token_slice(ids, mine, quota)
+        assert lo == mine.min() and hi <= n and more == (hi < n)
+        for s in mine:                                     # what the reference's loop consumes (ref :394-423), no sub-sampling
+            wc, cur = 0, int(s)
+            while True:
+                kept = 0
+                while cur < n:                             # one sentence: up to "</s>" or 1000 kept words
+                    tok = ids[cur]
+                    cur += 1
+                    wc += 1
+                    if tok == 0:
+                        break
+                    kept += 1
+                    if kept >= 1000:
+                        break
+                if cur >= n or wc > quota:
+                    break
+            assert cur <= hi, (trial, s, cur, hi)

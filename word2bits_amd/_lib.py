@@ -39,7 +39,7 @@ class Tuning(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("hot_rows_v", C.c_int32), ("hot_rows_u", C.c_int32), ("hot_period", C.c_int32),
         ("hot_cap", C.c_int32), ("force_row_desc", C.c_int32), ("grid_per_cu", C.c_int32), ("mem_mode", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("atomic_rank", C.c_int32), ("atomic_cap", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "w2b_set_exp_table": (C.c_int, [vp, f32p]),
     "w2b_set_corpus": (C.c_int, [vp, i32p, C.c_int64]),
     "w2b_set_corpus_device": (C.c_int, [vp, vp, C.c_int64]),
+    "w2b_set_corpus_slice": (C.c_int, [vp, i32p, C.c_int64, C.c_int32]),
     "w2b_set_shards": (C.c_int, [vp, i64p, i32p]),
     "w2b_epoch_begin": (C.c_int, [vp]),
     "w2b_train_step": (C.c_int, [vp, C.c_int64]),
@@ -85,6 +86,11 @@ SIGNATURES = {
     "w2b_comm_init": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
     "w2b_sync_replicas": (C.c_int, [vp, C.c_int32]),
     "w2b_sync_stats": (C.c_int, [vp, i64p, f64p]),
+    "w2b_exchange_init": (C.c_int, [vp]),
+    "w2b_exchange_begin": (C.c_int, [vp, i64p, i64p]),
+    "w2b_exchange_delta": (C.c_int, [vp, C.c_int64, C.POINTER(vp), i64p]),
+    "w2b_exchange_apply": (C.c_int, [vp, C.c_int64, C.c_float]),
+    "w2b_exchange_end": (C.c_int, [vp, C.c_int64]),
     # include/word2bits_corpus.h
     "w2b_corpus_load": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(vp)]),
     "w2b_corpus_free": (None, [vp]),

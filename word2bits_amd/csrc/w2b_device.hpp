@@ -284,28 +284,55 @@ __device__ __forceinline__ int prep_lists(IP tgt, IP prev, IP cend, int nt, IP c
   return k;     // number of chunks
 }
 
-// ------------------------------------------------------------------------------------ XCD-shared hot rows
+// ------------------------------------------------------------------------------------ atomic row updates
+// tab[row] += d, element by element, as fp32 atomic adds performed by the memory system (no read-modify-write window in
+// the kernel: nothing another worker adds meanwhile is lost).  When nobody else touches the row the result is
+// fl(x + d) -- the very value a load / add / store sequence produces, so a single worker stays bit-identical.
+template <int VEC, int TB = -1>
+__device__ __forceinline__ void add_col(float *tab, long long row, int dim, int col0, const Col<VEC> &d, unsigned tab_bytes) {
+  const int urow = __builtin_amdgcn_readfirstlane((int)row);
+  __amdgpu_buffer_rsrc_t r;
+  int soff;
+  if (TB == 0 || (TB < 0 && tab_bytes)) {
+    r = __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, (int)tab_bytes, 0x27000);
+    soff = urow * dim * 4;
+  } else {
+    r = __builtin_amdgcn_make_buffer_rsrc((void *)(tab + urow * (long long)dim), 0, dim * 4, 0x27000);
+    soff = 0;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; e++) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(d.e[e], r, (col0 + e) * 4, soff, 0);
+}
+
+// ------------------------------------------------------------------------------------ XCD-local copies of the hot rows
 // With coherent (agent-scope) rows every access to a row goes to its memory line, and the few most frequent rows of
 // u (context words) and v (targets) queue there: a 3200-byte row sustains ~7 M read-modify-writes per second, against
-// e.g. 0.32 target uses of row 1 per centre word on Zipf(1) ids at 25 M words/s.  Rounds 1-2 gave every worker PRIVATE
-// copies of a handful of such rows (LDS) and merged them every few steps.  Now every XCD owns ONE copy of rows 1..nu of u
-// and 1..nv of v (the vocabulary is sorted by count; the numbers come from the word counts and the number of workers)
-// in global memory, accessed with `nt` loads and stores: they bypass the CU's L1 and are served by / stay in the XCD's
-// L2 (MI355X_MICROARCH.md, inter-workgroup visibility: measured in tools/coherence_probe2.hip as "all workgroups of an
-// XCD see each other's read-modify-writes").  All workers of an XCD therefore share a hot row coherently at L2 speed,
-// and only the eight copies have to meet: a MERGE of one row loads the XCD's copy c, the value e the copy had at its
-// last merge ("entry") and the master row m, and stores, per element,
-//      n = c              if m == e   (nobody else changed the master: the exact value -- one worker stays bit-identical
-//                                      to a run without copies)
-//          m              if c == e   (nothing of ours: adopt)
-//          m + (c - e)    otherwise   (our contribution since the last merge on top of the others')
-// to master, copy and entry (stores whose value cannot differ are skipped per wavefront).  Workers take turns: every
-// hot_period centre words a worker merges xhot_m rows, rotating through the set.  k_xhot_fold (w2b_kernels_misc.hip)
-// applies the same rule for all eight copies before and after every launch, so between launches the master rows are
-// complete and copy == entry == master.  16-byte columns only (VEC == 4).
+// e.g. 0.32 target uses of row 1 per centre word on Zipf(1) ids at 25 M words/s.  Every XCD therefore works on ITS OWN
+// COPY of rows 1..nu of u and 1..nv of v (the vocabulary is sorted by count; the numbers come from the word counts and
+// the number of workers): an eighth of the traffic per address.  What makes shared copies safe at this concurrency --
+// dozens of workers have the same hot row in flight at any moment, so a load / modify / store would overwrite most of
+// what the others add (and an adopted value with it: the first version of this scheme, plain stores, turned lost
+// adoptions into negative deltas and un-trained the hot rows) -- is that NOTHING is ever stored into a copy:
+//   * a worker's update of a hot row is an atomic add of its delta to the XCD's copy (add_col);
+//   * a MERGE brings one copy and the master row together.  One wavefront at a time per 1 KiB segment of a copy
+//     (try-lock; a wavefront that finds it taken skips its turn).  With c = copy, e = the copy's value at its last
+//     merge ("entry"), per element:
+//        publish   m = CAS(master, e, c): where the master still holds e nobody else has published, and the exact
+//                  value c goes in -- a single worker stays bit-identical to a run without copies; where it does not,
+//                  the master gets an atomic add of c - e instead;
+//        adopt     what the others have published since the last merge, o = m - e, is atomically added to the copy;
+//        entry  <- c + o (so copy - entry is exactly what this XCD has added since).
+//     No update is lost or counted twice, whatever the interleaving.  Workers take turns: every hot_period centre words a
+//     worker merges xhot_m rows, rotating through the set.
+//   * k_xhot_fold (w2b_kernels_misc.hip) does the same for all eight copies before and after every launch (alone on
+//     the device, so with plain loads and stores): between launches the master rows are complete and copy == entry ==
+//     master.
+// Copies are read with `nt` loads (past the CU's L1; served by the XCD's L2 when the line is there -- an atomic drops
+// it).  16-byte columns only (VEC == 4).
 #define W2B_MM_XCD 5          // Aux<>: nt loads + nt stores (XCD scope)
 struct XHot {
   float *cu, *cv, *eu, *ev;    // this XCD's copies of the hot rows of u / v, and their entry values
+  unsigned *lu, *lv;           // merge locks [row][W2B_MAXW]
   int nu, nv;
 };
 __device__ __forceinline__ XHot xhot_here(const W2bParams &P) {
@@ -314,54 +341,58 @@ __device__ __forceinline__ XHot xhot_here(const W2bParams &P) {
   X.nv = P.xhot ? P.xhot_v : 0;
   // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): the XCD this workgroup runs on (a different placement would only be slower)
   const int xcd = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (W2B_NXCD - 1);
-  float *base = P.xhot + (long long)xcd * 2 * (X.nu + X.nv) * P.dim;
+  const long long rows = X.nu + X.nv;
+  float *base = P.xhot + (long long)xcd * (2 * rows * P.dim + rows * W2B_MAXW);
   X.cu = base;
   X.cv = base + (long long)X.nu * P.dim;
   X.eu = X.cv + (long long)X.nv * P.dim;
   X.ev = X.eu + (long long)X.nu * P.dim;
+  X.lu = reinterpret_cast<unsigned *>(X.ev + (long long)X.nv * P.dim);
+  X.lv = X.lu + (long long)X.nu * W2B_MAXW;
   return X;
 }
 __device__ __forceinline__ Col<4> xhot_ld(const float *rows, int k, int n, int dim, int col0) {
   return load_col<4, W2B_MM_XCD, 0>(rows, k, dim, col0, (unsigned)(n * dim * 4));
 }
-__device__ __forceinline__ void xhot_st(float *rows, int k, int n, int dim, int col0, const Col<4> &c) {
-  store_col<4, W2B_MM_XCD, 0>(rows, k, dim, col0, c, (unsigned)(n * dim * 4));
+__device__ __forceinline__ void xhot_add(float *rows, int k, int n, int dim, int col0, const Col<4> &d) {
+  add_col<4, 0>(rows, k, dim, col0, d, (unsigned)(n * dim * 4));
 }
-// hot row k (master row k + 1 of `tab`) of this XCD meets memory.  MM / TB: how the master rows are accessed.
-template <int MM, int TB>
-__device__ __forceinline__ void xhot_merge_row(float *tab, float *copy, float *entry, int k, int n, int dim, int col0,
-                                               bool active, unsigned tab_bytes) {
-  Col<4> c, e, m, o;
-#pragma unroll
-  for (int i = 0; i < 4; i++) { c.e[i] = 0.f; e.e[i] = 0.f; m.e[i] = 0.f; }
+// hot row k (master row k + 1 of `tab`) of this XCD meets memory: this wavefront's segment of the row.
+__device__ __forceinline__ void xhot_merge_row(float *tab, float *copy, float *entry, unsigned *locks, int k, int n, int dim,
+                                               int col0, bool active, int wave, int lane) {
+  unsigned *lock = locks + k * W2B_MAXW + wave;
+  unsigned got = 1u;
+  if (lane == 0) got = __hip_atomic_exchange(lock, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__builtin_amdgcn_readfirstlane((int)got) != 0) return;       // somebody is merging this segment right now
   if (active) {
-    c = xhot_ld(copy, k, n, dim, col0);
-    e = xhot_ld(entry, k, n, dim, col0);
-    m = load_col<4, MM, TB>(tab, k + 1, dim, col0, tab_bytes);
-  }
-  bool own = false, oth = false;
+    const Col<4> c = xhot_ld(copy, k, n, dim, col0);
+    const Col<4> e = load_col<4, 0, 0>(entry, k, dim, col0, (unsigned)(n * dim * 4));
+    float *mrow = tab + (long long)(k + 1) * dim + col0;
+    Col<4> en;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const bool ce = __float_as_uint(c.e[i]) == __float_as_uint(e.e[i]);
-    const bool me = __float_as_uint(m.e[i]) == __float_as_uint(e.e[i]);
-    own = own || !ce;
-    oth = oth || !me;
-    o.e[i] = me ? c.e[i] : (ce ? m.e[i] : m.e[i] + (c.e[i] - e.e[i]));
+    for (int i = 0; i < 4; i++) {
+      const unsigned eb = __float_as_uint(e.e[i]), cb = __float_as_uint(c.e[i]);
+      unsigned mb = eb;          // (value of the master; when nothing of ours is to be published a load would do as well)
+      __hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned *>(mrow + i), &mb, cb, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+      const float m = __uint_as_float(mb);
+      if (mb != eb && cb != eb) (void)__hip_atomic_fetch_add(mrow + i, c.e[i] - e.e[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float o = m - e.e[i];
+      en.e[i] = (mb == eb) ? c.e[i] : c.e[i] + o;
+      if (mb != eb) (void)__hip_atomic_fetch_add(copy + (long long)k * dim + col0 + i, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    store_col<4, 0, 0>(entry, k, dim, col0, en, (unsigned)(n * dim * 4));
   }
-  const bool any_own = __ballot(own) != 0ull, any_oth = __ballot(oth) != 0ull;      // wave-uniform
-  if (active) {
-    if (any_own) store_col<4, MM, TB>(tab, k + 1, dim, col0, o, tab_bytes);
-    if (any_oth) xhot_st(copy, k, n, dim, col0, o);
-    if (any_own || any_oth) xhot_st(entry, k, n, dim, col0, o);
-  }
+  __builtin_amdgcn_s_waitcnt(0);                                    // everything above has reached the memory system
+  if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one merge event of a workgroup of the plain kernels: P.xhot_m rows of each table, rotating through the sets
-template <int MM>
 __device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot &X, int &cursor, int col0, bool active) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int j = 0; j < P.xhot_m; j++) {
     const int i = cursor + j;
-    if (X.nu > 0 && j < X.nu) xhot_merge_row<MM, -1>(P.u, X.cu, X.eu, i % X.nu, X.nu, P.dim, col0, active, P.tab_bytes);
-    if (X.nv > 0 && j < X.nv) xhot_merge_row<MM, -1>(P.v, X.cv, X.ev, i % X.nv, X.nv, P.dim, col0, active, P.tab_bytes);
+    if (X.nu > 0 && j < X.nu) xhot_merge_row(P.u, X.cu, X.eu, X.lu, i % X.nu, X.nu, P.dim, col0, active, wave, lane);
+    if (X.nv > 0 && j < X.nv) xhot_merge_row(P.v, X.cv, X.ev, X.lv, i % X.nv, X.nv, P.dim, col0, active, wave, lane);
   }
   cursor += P.xhot_m;
 }
@@ -371,7 +402,8 @@ __device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot 
 // cw >= 1, nt >= 1.
 // Ends with a __syncthreads() (lists may be overwritten afterwards).
 // X: this XCD's copies of the hottest rows (nu = nv = 0: none; VEC == 4 only): a row k <= nu of u / k <= nv of v is read
-// and written at its copy instead of its master address.  Passed by reference, so that its fields stay in registers.
+// at its copy instead of its master address and updated there with atomic adds.  Passed by reference, so that its
+// fields stay in registers.  P.atomic_rank: rows 1..atomic_rank are updated with atomic adds at their master address.
 template <int QM, int VEC, bool LOSS, int MM>
 __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &L, const QParam &qp,
                                              const int cw, const int nt, const float alpha,
@@ -397,17 +429,21 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) return xhot_ld(X.cu, row - 1, nhu, dim, col0); }
     return load_col<VEC, MM>(P.u, row, dim, col0, P.tab_bytes);
   };
-  auto st_u = [&](int row, const Col<VEC> &c) {
-    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) { xhot_st(X.cu, row - 1, nhu, dim, col0, c); return; } }
-    store_col<VEC, MM>(P.u, row, dim, col0, c, P.tab_bytes);
+  // row <- val (= old + d): a store for ordinary rows, an atomic add of d for hot rows and in the atomic-rows mode
+  const int atomic_rank = P.atomic_rank;
+  auto up_u = [&](int row, const Col<VEC> &val, const Col<VEC> &d) {
+    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) { xhot_add(X.cu, row - 1, nhu, dim, col0, d); return; } }
+    if (row <= atomic_rank) add_col<VEC>(P.u, row, dim, col0, d, P.tab_bytes);
+    else store_col<VEC, MM>(P.u, row, dim, col0, val, P.tab_bytes);
   };
   auto ld_v = [&](int row) -> Col<VEC> {
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) return xhot_ld(X.cv, row - 1, nhv, dim, col0); }
     return load_col<VEC, MM>(P.v, row, dim, col0, P.tab_bytes);
   };
-  auto st_v = [&](int row, const Col<VEC> &c) {
-    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) { xhot_st(X.cv, row - 1, nhv, dim, col0, c); return; } }
-    store_col<VEC, MM>(P.v, row, dim, col0, c, P.tab_bytes);
+  auto up_v = [&](int row, const Col<VEC> &val, const Col<VEC> &d) {
+    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) { xhot_add(X.cv, row - 1, nhv, dim, col0, d); return; } }
+    if (row <= atomic_rank) add_col<VEC>(P.v, row, dim, col0, d, P.tab_bytes);
+    else store_col<VEC, MM>(P.v, row, dim, col0, val, P.tab_bytes);
   };
   // one chunk of target rows
   auto load_targets = [&](bool zero) {
@@ -548,6 +584,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
       if (i < n) {
         const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
         if (active) {
+          Col<VEC> dl;
 #pragma unroll
           for (int e = 0; e < VEC; e++) {
             float xv = x[i].e[e];
@@ -555,9 +592,10 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
             // row alive since the dot product (halves the register footprint of a chunk)
             if (QM != 0) asm volatile("" : "+v"(xv));
             err.e[e] += g * quant<QM>(xv, qp);
-            x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
+            dl.e[e] = g * avg.e[e] - ar2 * xv;
+            x[i].e[e] = xv + dl.e[e];
           }
-          st_v(rows[i], x[i]);
+          up_v(rows[i], x[i], dl);
         }
       }
     }
@@ -588,11 +626,18 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
       if (active && j0 + jj < cw) {
         const int m = L.umult[j0 + jj];
         if (m > 0) {
+          const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
+          const bool by_add = crow <= atomic_rank || (VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu);
+          Col<VEC> dl;
           for (int k = 0; k < m; k++) {      // a row that occurs m times in the window is updated m times
 #pragma unroll
-            for (int e = 0; e < VEC; e++) r[jj].e[e] = r[jj].e[e] + (err.e[e] - ar2 * r[jj].e[e]);
+            for (int e = 0; e < VEC; e++) {
+              dl.e[e] = err.e[e] - ar2 * r[jj].e[e];
+              r[jj].e[e] = r[jj].e[e] + dl.e[e];
+            }
+            if (by_add && k + 1 < m) up_u(crow, r[jj], dl);    // (every one of the m updates is an add of its own)
           }
-          st_u(__builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]), r[jj]);
+          up_u(crow, r[jj], dl);
         }
       }
   }
@@ -676,7 +721,10 @@ __device__ __forceinline__ void read_sentence(const W2bParams &P, int *s_sen, un
     if (sub) rng = lcg_jump(P, rng, __popcll(mw & cmask));
     if (e < 64) {
       stop = true;
-      if (!((min_ >> e) & 1ull)) eof = 1;
+      if (!((min_ >> e) & 1ull)) {
+        eof = 1;
+        if (P.corpus_more && lane == 0) P.shared->corpus_overrun = 1;   // end of the resident slice, not of the file
+      }
     }
   }
   len_out = len;

@@ -19,7 +19,7 @@ struct W2bShared {
   unsigned long long word_count_actual;
   double loss_tuples;   // loss sum of the tuple form (form ii)
   int workers_done;
-  int pad1;
+  int corpus_overrun;   // a worker reached the end of a corpus SLICE (w2b_set_corpus_slice) before its quota: the slice was cut too short
   // replicas (one per GPU): word_count_actual above is LOCAL.  The alpha schedule (ref :391) runs on the global count:
   // what the other replicas had done at the last exchange + the assumption that each of them has advanced like this
   // one since (exact at every exchange; single replica: both fields stay 0 and the schedule is the reference's).
@@ -50,6 +50,7 @@ struct W2bParams {
   const float *keep;              // sub-sampling threshold per word (nullptr when sample <= 0)
   const int32_t *corpus;          // token ids, 0 = </s>
   long long n_tokens;
+  int corpus_more;                // the resident tokens are a slice and the file goes on behind them (end of slice != EOF)
   W2bWorker *workers;
   W2bShared *shared;
   const unsigned long long *jump_a, *jump_c;   // LCG jump-ahead: x_{n+k} = jump_a[k]*x_n + jump_c[k]
@@ -61,11 +62,13 @@ struct W2bParams {
   int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
   float *entry;                   // sentence-resident kernel: scratch rows [num_threads][2][slots][dim] (see w2b_kernels_resident.hip)
   // XCD-shared copies of the hottest rows (w2b_device.hpp "XHot"): [W2B_NXCD][copies of u rows 1..xhot_u | copies of v rows
-  // 1..xhot_v | entries of the same][dim].  0 / 0 = every row is accessed at its master address.
+  // 1..xhot_v | entries of the same][dim], then the merge locks [rows][W2B_MAXW].  0 / 0 = every row is accessed at its
+  // master address.
   float *xhot;
   int xhot_u, xhot_v;
   int hot_period;                 // centre words between two merge events of a worker / workgroup (power of two)
   int xhot_m;                     // hot rows of each table that one merge event brings up to date
+  int atomic_rank;                // rows 1..atomic_rank (by count) are updated with fp32 atomic adds: no lost updates (see w2b_tuning)
   int exact;                      // serial dot product in the reference's order (plain worker / tuple kernels)
   float starting_alpha, sample, reg;
 };
@@ -107,6 +110,6 @@ void w2b_internal_trainer_view(w2b_trainer *t, float **u, float **v, long long *
 hipError_t w2b_launch_xhot_fold(const W2bParams &p, hipStream_t s);
 hipError_t w2b_launch_wca_pack(const W2bShared *sh, unsigned long long *buf, hipStream_t s);   // buf[0] = local word count
 hipError_t w2b_launch_wca_unpack(W2bShared *sh, const unsigned long long *buf, hipStream_t s); // from buf[1] = global sum
-hipError_t w2b_launch_sub(float *w, const float *base, long long n, hipStream_t s);       // w -= base
-hipError_t w2b_launch_add_snap(float *w, float *base, long long n, hipStream_t s);        // w += base; base = w
-hipError_t w2b_launch_scale_snap(float *w, float *base, float s, long long n, hipStream_t st); // w *= s; base = w
+// replica exchange, one chunk (w2b_kernels_misc.hip): d = s = w - base;  w += a * s - d, base += a * s
+hipError_t w2b_launch_xchg_delta(float *w, const float *base, float *d, float *s_, long long n, hipStream_t s);
+hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n, hipStream_t s);

@@ -32,46 +32,65 @@ __global__ void k_export(const float *__restrict__ u, const float *__restrict__ 
     out[i] = quant<QM>(u[i] + v[i], qp);
 }
 
-// ---- replica exchange (delta-sum), 16 bytes per lane; n4 = number of float4 (the tables are float4-aligned and
-// their length is padded by the callers' tail loop below)
+// ---- replica exchange (w2b_trainer.cpp, "multi-GPU"): one CHUNK of [u || v] at a time, 16 bytes per lane, on the
+// exchange streams WHILE the training kernels keep updating the same rows.  The model is therefore read and written at
+// agent scope (sc1 buffer accesses, like the training kernels' own row accesses); base / d / s belong to the exchange.
 typedef float w2b_f4 __attribute__((ext_vector_type(4)));
-__global__ void k_sub(float *w, const float *__restrict__ base, long long n) {          // w -= base
+__device__ __forceinline__ w2b_f4 xchg_ld_sc1(__amdgpu_buffer_rsrc_t r, long long i) {
+  const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i * 16), 0, 16);
+  w2b_f4 o;
+  o.x = __uint_as_float(t.x); o.y = __uint_as_float(t.y); o.z = __uint_as_float(t.z); o.w = __uint_as_float(t.w);
+  return o;
+}
+__device__ __forceinline__ void xchg_st_sc1(__amdgpu_buffer_rsrc_t r, long long i, const w2b_f4 &v) {
+  u32x4 t;
+  t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)(i * 16), 0, 16);
+}
+// d = s = w - base: what this replica has added to the chunk since the last exchange (n = floats, a multiple of 4,
+// n * 4 < 2^31; every pointer 16-byte aligned).  s is what the collective then sums in place over all replicas.
+__global__ void k_xchg_delta(float *w, const float *__restrict__ base, float *__restrict__ d, float *__restrict__ s, long long n) {
   const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
-  w2b_f4 *w4 = reinterpret_cast<w2b_f4 *>(w);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (int)(n * 4), 0x27000);
   const w2b_f4 *b4 = reinterpret_cast<const w2b_f4 *>(base);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) w4[i] = w4[i] - b4[i];
-  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] -= base[i];
-}
-__global__ void k_add_snap(float *w, float *base, long long n) {                          // w += base; base = w
-  const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
-  w2b_f4 *w4 = reinterpret_cast<w2b_f4 *>(w), *b4 = reinterpret_cast<w2b_f4 *>(base);
+  w2b_f4 *d4 = reinterpret_cast<w2b_f4 *>(d), *s4 = reinterpret_cast<w2b_f4 *>(s);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const w2b_f4 x = w4[i] + b4[i];
-    w4[i] = x;
-    b4[i] = x;
+    const w2b_f4 x = xchg_ld_sc1(rw, i) - b4[i];
+    d4[i] = x;
+    s4[i] = x;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {   // (n % 4 floats)
+    const float x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (int)(i * 4), 0, 16)) - base[i];
+    d[i] = x;
+    s[i] = x;
+  }
+}
+// s now holds the sum over all replicas.  What the OTHER replicas added, a * s - d (a = 1: delta-sum, a = 1 / replicas:
+// average of the deltas), goes on top of the rows as they are NOW -- whatever this replica has trained since the delta
+// was taken stays -- and base becomes the common state base + a * s.  Elements nobody else touched are not written.
+__global__ void k_xchg_apply(float *w, float *__restrict__ base, const float *__restrict__ d, const float *__restrict__ s,
+                             float a, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (int)(n * 4), 0x27000);
+  w2b_f4 *b4 = reinterpret_cast<w2b_f4 *>(base);
+  const w2b_f4 *d4 = reinterpret_cast<const w2b_f4 *>(d), *s4 = reinterpret_cast<const w2b_f4 *>(s);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const w2b_f4 sum = s4[i] * a, others = sum - d4[i];
+    b4[i] = b4[i] + sum;
+    if (others.x != 0.f || others.y != 0.f || others.z != 0.f || others.w != 0.f) xchg_st_sc1(rw, i, xchg_ld_sc1(rw, i) + others);
   }
   for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float x = w[i] + base[i];
-    w[i] = x;
-    base[i] = x;
+    const float sum = s[i] * a, others = sum - d[i];
+    base[i] += sum;
+    if (others != 0.f) {
+      const float x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (int)(i * 4), 0, 16)) + others;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rw, (int)(i * 4), 0, 16);
+    }
   }
 }
-__global__ void k_scale_snap(float *w, float *base, float s, long long n) {               // w *= s; base = w
-  const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
-  w2b_f4 *w4 = reinterpret_cast<w2b_f4 *>(w), *b4 = reinterpret_cast<w2b_f4 *>(base);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const w2b_f4 x = w4[i] * s;
-    w4[i] = x;
-    if (base) b4[i] = x;
-  }
-  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float x = w[i] * s;
-    w[i] = x;
-    if (base) base[i] = x;
-  }
-}
-// ---- XCD-shared hot rows (XHot in w2b_device.hpp): all eight copies of hot row k meet the master row k + 1, with the
-// merge rule of xhot_merge_row, XCD after XCD; afterwards master == every copy == every entry.  One workgroup per hot
+// ---- XCD-local copies of the hot rows (XHot in w2b_device.hpp): all eight copies of hot row k meet the master row k + 1,
+// with the merge rule of xhot_merge_row (exact value where the master still holds the copy's entry, else the copy's
+// delta on top), XCD after XCD; afterwards master == every copy == every entry.  One workgroup per hot
 // row (u rows first), 16 bytes per thread.  Runs before and after every training launch: idempotent, and a master that
 // was changed in between (w2b_set_model, a replica exchange) is simply adopted.
 __global__ void k_xhot_fold(const W2bParams P) {
@@ -80,8 +99,11 @@ __global__ void k_xhot_fold(const W2bParams P) {
   const bool is_u = r < nu;
   const int k = is_u ? r : r - nu;
   w2b_f4 *master = reinterpret_cast<w2b_f4 *>((is_u ? P.u : P.v) + (long long)(k + 1) * dim);
-  const long long per_xcd = 2ll * (nu + nv) * dim, copy_off = (long long)(is_u ? k : nu + k) * dim,
-                  entry_off = copy_off + (long long)(nu + nv) * dim;
+  const long long per_xcd = 2ll * (nu + nv) * dim + (long long)(nu + nv) * W2B_MAXW,      // copies, entries, merge locks
+                  copy_off = (long long)(is_u ? k : nu + k) * dim, entry_off = copy_off + (long long)(nu + nv) * dim;
+  if (threadIdx.x < W2B_MAXW)                      // (no merge is in progress between launches)
+    for (int x = 0; x < W2B_NXCD; x++)
+      reinterpret_cast<unsigned *>(P.xhot + x * per_xcd + 2ll * (nu + nv) * dim)[(is_u ? k : nu + k) * W2B_MAXW + threadIdx.x] = 0u;
   for (int c = threadIdx.x; c < dim / 4; c += blockDim.x) {
     w2b_f4 m = master[c];
     for (int x = 0; x < W2B_NXCD; x++) {
@@ -161,16 +183,11 @@ hipError_t w2b_launch_wca_unpack(W2bShared *sh, const unsigned long long *buf, h
   hipLaunchKernelGGL(k_wca_unpack, dim3(1), dim3(1), 0, s, sh, buf);
   return hipGetLastError();
 }
-hipError_t w2b_launch_sub(float *w, const float *base, long long n, hipStream_t s) {
-  hipLaunchKernelGGL(k_sub, dim3(2048), dim3(256), 0, s, w, base, n);
+hipError_t w2b_launch_xchg_delta(float *w, const float *base, float *d, float *s_, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_xchg_delta, dim3(1024), dim3(256), 0, s, w, base, d, s_, n);
   return hipGetLastError();
 }
-hipError_t w2b_launch_add_snap(float *w, float *base, long long n, hipStream_t s) {
-  hipLaunchKernelGGL(k_add_snap, dim3(2048), dim3(256), 0, s, w, base, n);
+hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_xchg_apply, dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n);
   return hipGetLastError();
 }
-hipError_t w2b_launch_scale_snap(float *w, float *base, float sc, long long n, hipStream_t s) {
-  hipLaunchKernelGGL(k_scale_snap, dim3(2048), dim3(256), 0, s, w, base, sc, n);
-  return hipGetLastError();
-}
-

@@ -118,72 +118,52 @@ struct Step2 {
 };
 
 
+// LDS record of one worker: every list has a compile-time capacity, so every field is a CONSTANT offset from the
+// worker's LDS base (round 2 carved run-time sized arrays: 40-odd LDS pointers in SGPRs, 119 of them spilled to VGPR
+// lanes in the benchmarked instantiation).  The kernel therefore runs for window <= W2B_WMAX and negative < W2B_TMAX;
+// wider shapes use the plain worker kernel.
+#define W2B_WMAX 16                     // radius <= window <= 16: at most 33 window slots
+#define W2B_SMAX (2 * W2B_WMAX + 1 + 3) // window slots / retire + admit lists (S + 2 entries), padded
+#define W2B_TMAX 64                     // negative + 1 targets
+#define W2B_NJ 66                       // LCG jump-ahead entries (read_sentence jumps up to 64 draws; negative + 2)
+struct StepRec {          // what the producer wavefront hands to the data wavefronts for ONE step (double buffered)
+  Step2 st;
+  int ret_slot[W2B_SMAX], ret_row[W2B_SMAX], ret_gen[W2B_SMAX];
+  int adm_slot[W2B_SMAX], adm_row[W2B_SMAX], adm_gen[W2B_SMAX];
+  int cslot[W2B_SMAX];    // slot of every context position; -1-k = k-th register-held row
+  int uc_row[4];          // rows of the (at most two) context positions outside the radius
+  int tgt[W2B_TMAX], cend[W2B_TMAX];
+  float lossf[W2B_TMAX];  // dot products f of this step's targets, for the loss bookkeeping
+};
+struct WorkRec {
+  Win2Lds S;
+  int slot_row[W2B_SMAX], slot_ref[W2B_SMAX], pos_slot[W2B_SMAX], slot_gen[W2B_SMAX];
+  int prev[W2B_TMAX];
+  float red[2][W2B_RT][W2B_NDWMAX];
+  unsigned csum[W2B_SMAX][W2B_NDWMAX];   // per-wavefront xor checksum of the row bits at entry
+  unsigned long long ja[W2B_NJ], jc[W2B_NJ];   // LCG jump-ahead table (copy of P.jump_a / P.jump_c)
+  int sen[(W2B_MAX_SEN + 3) & ~3];
+  StepRec step[2];
+};
+// view of a worker's LDS: the record, one of its two step buffers, and the window rows behind the record
 struct Win2 {
-  W2B_LDS float *win;             // [S][dim]  current fp32 value of the resident rows (window slots)
-  W2B_LDS unsigned *csum;         // [S][4]    per-wavefront xor checksum of the row bits at entry
-  W2B_LDS float *red;             // [2][W2B_RT][4]
-  W2B_LDS int *slot_row, *slot_ref, *pos_slot, *slot_gen;                      // [S]
-  W2B_LDS int *ret_slot, *ret_row, *ret_gen, *adm_slot, *adm_row, *adm_gen;    // [S+2]
-  W2B_LDS int *cslot;             // [maxc] slot of every context position; -1-k = k-th register-held row
-  W2B_LDS int *uc_row;            // [2]   rows of the (at most two) context positions outside the radius
-  W2B_LDS int *tgt, *prev, *cend; // [maxt]
-  W2B_LDS float *lossf;           // [maxt] dot products f of this step's targets, for the loss bookkeeping (per step buffer)
-  W2B_LDS int *sen;               // [1000]
-  W2B_LDS unsigned long long *ja, *jc;   // [nj] LCG jump-ahead table (copy of P.jump_a / P.jump_c)
-  W2B_LDS Win2Lds *S;
-  W2B_LDS Step2 *St;              // per-step scalars (this struct exists twice: one per step buffer)
+  W2B_LDS WorkRec *w;
+  W2B_LDS StepRec *s;
+  W2B_LDS float *win;     // [S][dim] current fp32 value of the resident rows (thread-private 16-byte columns)
 };
 
-__host__ __device__ inline int w2_round4(int x) { return (x + 3) & ~3; }
-
+__host__ __device__ inline size_t win2_rec_bytes() { return (sizeof(WorkRec) + 15) & ~(size_t)15; }
 // LDS bytes of the sentence-resident kernel for radius R
 __host__ __device__ inline size_t win2_lds_bytes(int dim, int window, int negative, int R) {
-  const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
-  size_t b = (size_t)S * dim * 4;                           // win
-  b = (b + 15) & ~(size_t)15;
-  b += (size_t)S * W2B_NDWMAX * 4;                          // csum
-  b += 2 * W2B_RT * W2B_NDWMAX * 4;                                // red
-  b += (size_t)(4 * w2_round4(S) + maxt + w2_round4(W2B_MAX_SEN)) * 4;               // slot tables, prev, sen
-  b += 2 * ((size_t)(6 * w2_round4(S + 2) + maxc + 4 + 3 * maxt) * 4 + sizeof(Step2));  // step lists x 2
-  b += sizeof(Win2Lds) + 16;
-  b += (size_t)2 * 8 * (negative + 2 > 66 ? negative + 2 : 66) + 16;   // LCG jump tables
-  return b;
+  (void)window; (void)negative;
+  return win2_rec_bytes() + (size_t)(2 * R + 1) * dim * 4;
 }
 
-__device__ __forceinline__ Win2 carve_win2(W2B_LDS int *base, int dim, int window, int negative, int R, int buf) {
-  const int S = 2 * R + 1, maxc = w2_round4(2 * window + 1), maxt = w2_round4(negative + 1);
+__device__ __forceinline__ Win2 carve_win2(W2B_LDS int *base, int buf) {
   Win2 L;
-  W2B_LDS char *p = (W2B_LDS char *)base;
-  L.win = (W2B_LDS float *)p; p += (size_t)S * dim * 4;
-  p = (W2B_LDS char *)(((unsigned)(size_t)p + 15u) & ~15u);
-  L.csum = (W2B_LDS unsigned *)p; p += (size_t)S * W2B_NDWMAX * 4;
-  L.red = (W2B_LDS float *)p; p += 2 * W2B_RT * W2B_NDWMAX * 4;
-  W2B_LDS int *q = (W2B_LDS int *)p;
-  L.slot_row = q; q += w2_round4(S);
-  L.slot_ref = q; q += w2_round4(S);
-  L.pos_slot = q; q += w2_round4(S);
-  L.slot_gen = q; q += w2_round4(S);
-  L.prev = q; q += maxt;
-  L.sen = q; q += w2_round4(W2B_MAX_SEN);
-  const int per_buf = 6 * w2_round4(S + 2) + maxc + 4 + 3 * maxt + (int)(sizeof(Step2) / 4);
-  q += buf * per_buf;                                  // the per-step lists exist twice
-  L.ret_slot = q; q += w2_round4(S + 2);
-  L.ret_row = q; q += w2_round4(S + 2);
-  L.ret_gen = q; q += w2_round4(S + 2);
-  L.adm_slot = q; q += w2_round4(S + 2);
-  L.adm_row = q; q += w2_round4(S + 2);
-  L.adm_gen = q; q += w2_round4(S + 2);
-  L.cslot = q; q += maxc;
-  L.uc_row = q; q += 4;
-  L.tgt = q; q += maxt;
-  L.cend = q; q += maxt;
-  L.lossf = (W2B_LDS float *)q; q += maxt;
-  L.St = (W2B_LDS Step2 *)q; q += sizeof(Step2) / 4;
-  q += (1 - buf) * per_buf;
-  L.S = (W2B_LDS Win2Lds *)(((unsigned)(size_t)q + 15u) & ~15u);
-  const int nj = negative + 2 > 66 ? negative + 2 : 66;
-  L.ja = (W2B_LDS unsigned long long *)(((unsigned)(size_t)(L.S + 1) + 15u) & ~15u);
-  L.jc = L.ja + nj;
+  L.w = (W2B_LDS WorkRec *)base;
+  L.s = &L.w->step[buf];
+  L.win = (W2B_LDS float *)((W2B_LDS char *)base + win2_rec_bytes());
   return L;
 }
 
@@ -225,13 +205,15 @@ struct Rows {
   int dim, col0;
   bool active;
   float *hot_c, *hot_e;    // this XCD's copies of the hottest rows of v and their entry values (XHot)
+  unsigned *hot_l;         // their merge locks
   int nh;
   __device__ __forceinline__ Col4 ld_u(int row) const { return load_col<4, M, TB>(P.u, row, dim, col0, P.tab_bytes); }
   __device__ __forceinline__ Col4 ld_v(int row) const { return load_col<4, M, TB>(P.v, row, dim, col0, P.tab_bytes); }
   __device__ __forceinline__ void st_u(int row, const Col4 &c) const { store_col<4, M, TB>(P.u, row, dim, col0, c, P.tab_bytes); }
   __device__ __forceinline__ void st_v(int row, const Col4 &c) const { store_col<4, M, TB>(P.v, row, dim, col0, c, P.tab_bytes); }
   __device__ __forceinline__ Col4 ld_hot(int k) const { return xhot_ld(hot_c, k, nh, dim, col0); }
-  __device__ __forceinline__ void st_hot(int k, const Col4 &c) const { xhot_st(hot_c, k, nh, dim, col0, c); }
+  __device__ __forceinline__ void add_hot(int k, const Col4 &d) const { xhot_add(hot_c, k, nh, dim, col0, d); }
+  __device__ __forceinline__ void add_v(int row, const Col4 &d) const { add_col<4, TB>(P.v, row, dim, col0, d, P.tab_bytes); }
   // scratch ("entry") rows: written with plain stores, read back (rarely) past the L1
   __device__ __forceinline__ Col4 ld_entry(int gen, int slot) const {
     return load_col<4, 0, 1>(P.entry, scratch0 + (long long)gen * nsh + slot, dim, col0, 0u);
@@ -269,15 +251,15 @@ __device__ __forceinline__ void window_retire(const Rows<MM> &A, const Win2 &L, 
     for (int i = 0; i < W2B_RCH; i++) {
       rw[i] = col_zero(); g[i] = col_zero();
       if (i0 + i < n_ret && A.active) {
-        rw[i] = lds_ld(L.win + L.ret_slot[i0 + i] * A.dim + A.col0);
-        g[i] = A.ld_u(L.ret_row[i0 + i]);
+        rw[i] = lds_ld(L.win + L.s->ret_slot[i0 + i] * A.dim + A.col0);
+        g[i] = A.ld_u(L.s->ret_row[i0 + i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < W2B_RCH; i++)
       if (i0 + i < n_ret) {
-        const int s = L.ret_slot[i0 + i];
-        retire_finish<MM>(A, L.ret_row[i0 + i], L.ret_gen[i0 + i], s, L.csum[s * W2B_NDWMAX + wave], g[i], rw[i]);
+        const int s = L.s->ret_slot[i0 + i];
+        retire_finish<MM>(A, L.s->ret_row[i0 + i], L.s->ret_gen[i0 + i], s, L.w->csum[s][wave], g[i], rw[i]);
       }
   }
 }
@@ -290,17 +272,17 @@ __device__ __forceinline__ void window_admit(const Rows<MM> &A, const Win2 &L, i
 #pragma unroll
     for (int i = 0; i < W2B_RCH; i++) {
       a[i] = col_zero();
-      if (i0 + i < n_adm && A.active) a[i] = A.ld_u(L.adm_row[i0 + i]);
+      if (i0 + i < n_adm && A.active) a[i] = A.ld_u(L.s->adm_row[i0 + i]);
     }
 #pragma unroll
     for (int i = 0; i < W2B_RCH; i++)
       if (i0 + i < n_adm) {
-        const int s = L.adm_slot[i0 + i];
+        const int s = L.s->adm_slot[i0 + i];
         const unsigned cs = wave_xor(A.active ? col_bits(a[i]) : 0u);
-        if (lane == 0) L.csum[s * W2B_NDWMAX + wave] = cs;
+        if (lane == 0) L.w->csum[s][wave] = cs;
         if (A.active) {
           lds_st(L.win + s * A.dim + A.col0, a[i]);
-          A.st_entry(L.adm_gen[i0 + i], s, a[i]);
+          A.st_entry(L.s->adm_gen[i0 + i], s, a[i]);
         }
       }
   }
@@ -325,11 +307,11 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
   // readfirstlane, or every LDS address and with it the whole control flow would count as divergent
   const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / WPT);
   W2B_LDS int *const smem_lds = (W2B_LDS int *)smem + half * lds_ints_per_worker;
-  const Win2 L0 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, 0);
-  const Win2 L1 = carve_win2(smem_lds, P.dim, P.window, P.negative, R, 1);
+  const Win2 L0 = carve_win2(smem_lds, 0);
+  const Win2 L1 = carve_win2(smem_lds, 1);
   const Win2 &L = L0;                                   // everything that is not double buffered
-  W2B_LDS WorkerLds *S = &L.S->w;
-  W2B_LDS int *s_sen = L.sen;
+  W2B_LDS WorkerLds *S = &L.w->S.w;
+  W2B_LDS int *s_sen = L.w->sen;
   const int tid = (int)threadIdx.x - half * WPT, lane = tid & 63, wave = tid >> 6;
   const bool producer = (wave == NDW);
   const int wid = (int)blockIdx.x * W2B_WPG + half;
@@ -342,24 +324,24 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
   const int NS = 2 * R + 1;
   const XHot XH = xhot_here(P);
   const int NH = XH.nv;                     // leading rows of v that live in this XCD's copies
-  const Rows<MM> A{P, (long long)wid * 2 * NS, NS, P.dim, tid * 4, !producer && tid * 4 < P.dim, XH.cv, XH.ev, NH};
+  const Rows<MM> A{P, (long long)wid * 2 * NS, NS, P.dim, tid * 4, !producer && tid * 4 < P.dim, XH.cv, XH.ev, XH.lv, NH};
   const bool active = A.active;
   if (valid) {
     for (int i = tid; i < G->sen_len; i += WPT) s_sen[i] = G->sen[i];
-    for (int i = tid; i < NS; i += WPT) { L.slot_row[i] = -1; L.slot_ref[i] = 0; L.pos_slot[i] = 0; L.slot_gen[i] = 0; }
-    for (int i = tid; i < (P.negative + 2 > 66 ? P.negative + 2 : 66); i += WPT) { L.ja[i] = P.jump_a[i]; L.jc[i] = P.jump_c[i]; }
+    for (int i = tid; i < NS; i += WPT) { L.w->slot_row[i] = -1; L.w->slot_ref[i] = 0; L.w->pos_slot[i] = 0; L.w->slot_gen[i] = 0; }
+    for (int i = tid; i < W2B_NJ; i += WPT) { L.w->ja[i] = P.jump_a[i]; L.w->jc[i] = P.jump_c[i]; }
     if (tid == 0) {
       S->rng = G->rng; S->cursor = G->cursor; S->wc = G->word_count; S->last_wc = G->last_word_count;
       S->sen_len = G->sen_len; S->sen_pos = G->sen_pos; S->override_ = G->first_override;
       S->eof = 0; S->done = 0; S->cw = 0; S->nt = 0; S->alpha = 0.f;
-      L.S->clo = 0; L.S->chi = -1;
-      L.S->bar_step = 0u; L.S->bar_chunk = 0u;
-      L.S->loss_reg = 0.0;
+      L.w->S.clo = 0; L.w->S.chi = -1;
+      L.w->S.bar_step = 0u; L.w->S.bar_chunk = 0u;
+      L.w->S.loss_reg = 0.0;
     }
   }
   __syncthreads();            // the only workgroup-wide barrier: every wavefront of both workers is still here
   if (!valid) return;
-  W2B_LDS unsigned *const bar_step = &L.S->bar_step, *const bar_chunk = &L.S->bar_chunk;
+  W2B_LDS unsigned *const bar_step = &L.w->S.bar_step, *const bar_chunk = &L.w->S.bar_chunk;
   unsigned n_step = 0u, n_chunk = 0u;       // barriers passed so far (identical in every wavefront of the worker)
 #ifdef W2B_PHASE_TIMERS
   const bool timing_ = (wid == 0) && (wave == 0 || wave == NDW) && lane == 0;
@@ -426,15 +408,15 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
         }
       }
       // ---------------- window bookkeeping: make the resident range [lo, hi]
-      int clo = L.S->clo, chi = L.S->chi, n_ret = 0, n_adm = 0;
+      int clo = L.w->S.clo, chi = L.w->S.chi, n_ret = 0, n_adm = 0;
       if (new_sentence || !train) {
-        if (lane < NS) L.slot_ref[lane] = 0;              // every resident position belonged to the old sentence
+        if (lane < NS) L.w->slot_ref[lane] = 0;              // every resident position belonged to the old sentence
         clo = 0; chi = -1;
         W2B_WAVE_SYNC();
       } else {
         for (int q = clo; q <= chi; q++) {                // positions that leave: [clo, lo) and (hi, chi]
           if (q >= lo && q <= hi) { q = hi; continue; }
-          if (lane == 0) L.slot_ref[L.pos_slot[q % NS]]--;
+          if (lane == 0) L.w->slot_ref[L.w->pos_slot[q % NS]]--;
           W2B_WAVE_SYNC();
         }
       }
@@ -445,42 +427,42 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
       for (int pass = 0; pass < 2; pass++) {
         for (int q = lo; q <= hi; q++) {
           if (q >= clo && q <= chi) { q = chi; continue; }                 // already resident
-          if (pass == 1 && L.pos_slot[q % NS] >= 0) continue;             // resolved in pass 1
+          if (pass == 1 && L.w->pos_slot[q % NS] >= 0) continue;             // resolved in pass 1
           const int w = s_sen[q];
-          const bool match = (lane < NS) && (L.slot_row[lane] == w);
+          const bool match = (lane < NS) && (L.w->slot_row[lane] == w);
           const unsigned long long mm = __ballot(match);
           int s = -1;
           if (mm) {                                                       // the word is resident: share its slot
             s = __ffsll((long long)mm) - 1;
-            if (lane == 0) L.slot_ref[s]++;
+            if (lane == 0) L.w->slot_ref[s]++;
           } else if (pass == 1) {
-            const unsigned long long fr = __ballot((lane < NS) && (L.slot_row[lane] == -1));
+            const unsigned long long fr = __ballot((lane < NS) && (L.w->slot_row[lane] == -1));
             if (fr) s = __ffsll((long long)fr) - 1;
             else {                                                         // recycle the slot of a leaving row
-              const unsigned long long pend = __ballot((lane < NS) && (L.slot_ref[lane] == 0));
+              const unsigned long long pend = __ballot((lane < NS) && (L.w->slot_ref[lane] == 0));
               s = __ffsll((long long)pend) - 1;
-              if (lane == 0) { O.ret_slot[n_ret] = s; O.ret_row[n_ret] = L.slot_row[s]; O.ret_gen[n_ret] = L.slot_gen[s]; }
+              if (lane == 0) { O.s->ret_slot[n_ret] = s; O.s->ret_row[n_ret] = L.w->slot_row[s]; O.s->ret_gen[n_ret] = L.w->slot_gen[s]; }
               n_ret++;
             }
             if (lane == 0) {
-              const int gen = L.slot_gen[s] ^ 1;          // the scratch row of the previous tenant stays readable
-              L.slot_gen[s] = gen;
-              L.slot_row[s] = w; L.slot_ref[s] = 1;
-              O.adm_slot[n_adm] = s; O.adm_row[n_adm] = w; O.adm_gen[n_adm] = gen;
+              const int gen = L.w->slot_gen[s] ^ 1;          // the scratch row of the previous tenant stays readable
+              L.w->slot_gen[s] = gen;
+              L.w->slot_row[s] = w; L.w->slot_ref[s] = 1;
+              O.s->adm_slot[n_adm] = s; O.s->adm_row[n_adm] = w; O.s->adm_gen[n_adm] = gen;
             }
             n_adm++;
           }
-          if (lane == 0) L.pos_slot[q % NS] = s;
+          if (lane == 0) L.w->pos_slot[q % NS] = s;
           W2B_WAVE_SYNC();
         }
       }
       {                                                                  // whatever is unreferenced leaves
-        const bool leaving = (lane < NS) && (L.slot_row[lane] != -1) && (L.slot_ref[lane] == 0);
+        const bool leaving = (lane < NS) && (L.w->slot_row[lane] != -1) && (L.w->slot_ref[lane] == 0);
         const unsigned long long ml = __ballot(leaving);
         if (leaving) {
           const int k = n_ret + __popcll(ml & lane_lt_mask(lane));
-          O.ret_slot[k] = lane; O.ret_row[k] = L.slot_row[lane]; O.ret_gen[k] = L.slot_gen[lane];
-          L.slot_row[lane] = -1;
+          O.s->ret_slot[k] = lane; O.s->ret_row[k] = L.w->slot_row[lane]; O.s->ret_gen[k] = L.w->slot_gen[lane];
+          L.w->slot_row[lane] = -1;
         }
         n_ret += __popcll(ml);
         W2B_WAVE_SYNC();
@@ -494,14 +476,14 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           const unsigned long long m = __ballot(ok);
           int slot = 0;
           if (ok) {
-            if (c >= lo && c <= hi) slot = L.pos_slot[c % NS];
+            if (c >= lo && c <= hi) slot = L.w->pos_slot[c % NS];
             else {                                     // outside the radius (|c - p| == window): resident anyway?
               const int w = s_sen[c];
               slot = (c < p) ? -1 : -2;                // provisional: register-held row (left / right)
-              for (int s2 = 0; s2 < NS; s2++) slot = (L.slot_row[s2] == w) ? s2 : slot;
+              for (int s2 = 0; s2 < NS; s2++) slot = (L.w->slot_row[s2] == w) ? s2 : slot;
             }
           }
-          if (ok) O.cslot[cw + __popcll(m & lane_lt_mask(lane))] = slot;
+          if (ok) O.s->cslot[cw + __popcll(m & lane_lt_mask(lane))] = slot;
           cw += __popcll(m);
         }
         W2B_WAVE_SYNC();
@@ -509,14 +491,14 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           // The radius is window-1: the two outermost context positions (only present when b == 0) are
           // not resident.  They are the first / last entry of the context list; each one that is not
           // resident through another position becomes a register-held row of this step.
-          const int first = O.cslot[0], lastc = O.cslot[cw - 1];
+          const int first = O.s->cslot[0], lastc = O.s->cslot[cw - 1];
           int wl = -1;
-          if (first == -1) { wl = s_sen[p - W]; if (lane == 0) O.uc_row[0] = wl; uc_n = 1; }
+          if (first == -1) { wl = s_sen[p - W]; if (lane == 0) O.s->uc_row[0] = wl; uc_n = 1; }
           if (lastc == -2) {
             const int wr = s_sen[p + W];
-            if (uc_n == 1 && wr == wl) { if (lane == 0) O.cslot[cw - 1] = -1; }       // same word on both ends
+            if (uc_n == 1 && wr == wl) { if (lane == 0) O.s->cslot[cw - 1] = -1; }       // same word on both ends
             else {
-              if (lane == 0) { O.uc_row[uc_n] = wr; O.cslot[cw - 1] = -1 - uc_n; }
+              if (lane == 0) { O.s->uc_row[uc_n] = wr; O.s->cslot[cw - 1] = -1 - uc_n; }
               uc_n++;
             }
           }
@@ -527,7 +509,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           // its updates strictly in order; otherwise it may keep several LDS rows in flight.
           int dupf = 0;
           for (int j0 = 0; j0 < cw; j0 += 64) {
-            const int mine = (j0 + lane < cw) ? O.cslot[j0 + lane] : -100 - lane;
+            const int mine = (j0 + lane < cw) ? O.s->cslot[j0 + lane] : -100 - lane;
             for (int j = 0; j < min(64, cw - j0); j++) {
               const int sj = __builtin_amdgcn_readlane(mine, j);
               dupf |= (__ballot(lane > j && mine == sj) != 0ull) ? 1 : 0;
@@ -543,23 +525,23 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
             bool keep = false;
             int t = 0;
             if (d <= K) {
-              const unsigned long long x = (L.ja[d] * rng + L.jc[d]);
+              const unsigned long long x = (L.w->ja[d] * rng + L.w->jc[d]);
               t = (pref_ok && d0 == 1) ? t_pref : P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
               if (t == 0) t = (int)(x % (unsigned long long)(P.vocab_size - 1)) + 1;
               keep = (t != word);
             }
             const unsigned long long m = __ballot(keep);
-            if (keep) O.tgt[1 + cnt + __popcll(m & lane_lt_mask(lane))] = t;
+            if (keep) O.s->tgt[1 + cnt + __popcll(m & lane_lt_mask(lane))] = t;
             cnt += __popcll(m);
           }
-          if (lane == 0) O.tgt[0] = word;
+          if (lane == 0) O.s->tgt[0] = word;
           nt = 1 + cnt;
-          rng = (L.ja[K] * rng + L.jc[K]);
+          rng = (L.w->ja[K] * rng + L.w->jc[K]);
           alpha = alpha_set ? alpha_own
                             : (alpha_pref_ok ? alpha_pref
                                              : __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT));
-          nck = prep_lists<W2B_RT, W2B_LDS int *>(O.tgt, L.prev, O.cend, nt, (W2B_LDS int *)nullptr, (W2B_LDS int *)nullptr, 0, lane);
+          nck = prep_lists<W2B_RT, W2B_LDS int *>(O.s->tgt, L.w->prev, O.s->cend, nt, (W2B_LDS int *)nullptr, (W2B_LDS int *)nullptr, 0, lane);
         }
         const int nq = p + 1 + R;                                        // enters the window at the next step
         next_row = (p + 1 < sen_len && nq < sen_len) ? s_sen[nq] : -1;
@@ -570,7 +552,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
         pref_ok = (sen_len != 0);
         if (pref_ok && lane < K) {                                       // lane l serves draw d = l + 1
           const unsigned long long xb = rng * W2B_LCG_A + W2B_LCG_C;     // the next step's window draw
-          const unsigned long long x = (L.ja[lane + 1] * xb + L.jc[lane + 1]);
+          const unsigned long long x = (L.w->ja[lane + 1] * xb + L.w->jc[lane + 1]);
           t_pref = P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
         }
         alpha_pref = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -581,11 +563,11 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
       if (lane == 0) {
         S->rng = rng; S->cursor = cursor; S->wc = wc; S->last_wc = last_wc;
         S->sen_len = sen_len; S->sen_pos = sen_pos; S->override_ = ovr; S->eof = eof;
-        L.S->clo = lo; L.S->chi = hi;
-        O.St->stop = (done || last) ? 1 : 0; O.St->cw = cw; O.St->nt = nt; O.St->uc_n = uc_n;
-        O.St->n_ret = n_ret; O.St->n_adm = n_adm; O.St->next_row = next_row; O.St->nck = (cw > 0) ? nck : 0;
-        O.St->alpha = alpha;
-        O.St->cdup = cdup;
+        L.w->S.clo = lo; L.w->S.chi = hi;
+        O.s->st.stop = (done || last) ? 1 : 0; O.s->st.cw = cw; O.s->st.nt = nt; O.s->st.uc_n = uc_n;
+        O.s->st.n_ret = n_ret; O.s->st.n_adm = n_adm; O.s->st.next_row = next_row; O.s->st.nck = (cw > 0) ? nck : 0;
+        O.s->st.alpha = alpha;
+        O.s->st.cdup = cdup;
         if (done) S->done = 1;
       }
   };
@@ -599,16 +581,16 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
     worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);
     for (long long it = 0;; ++it) {
       const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
-      const bool stop = I.St->stop != 0;
+      const bool stop = I.s->st.stop != 0;
       W2B_TICK(1);
       if (LOSS && it > 0) {
         // The log-sigmoid bookkeeping (ref :480-483) of the PREVIOUS step happens here, off the data wavefronts'
         // registers (expf/logf cost them ~40 VGPRs): wavefront 0 left the dot products f of that step's targets in the
         // step buffer, which nobody writes again before this wavefront has passed the next end-of-step barrier.
         const Win2 &Q = (it & 1) ? L0 : L1;               // the previous step's lists
-        const int ntp = Q.St->cw > 0 ? Q.St->nt : 0;
+        const int ntp = Q.s->st.cw > 0 ? Q.s->st.nt : 0;
         for (int i = lane; i < ntp; i += 64) {
-          const float f = Q.lossf[i];
+          const float f = Q.s->lossf[i];
           const float dp = (i == 0) ? f : -f;                           // target 0 is the centre word (label 1)
           float sg;
           if (dp > 6.f) sg = 1.f;
@@ -621,7 +603,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
       if (!stop) prepare((it & 1) ? L0 : L1, it + 1 == max_positions);
       W2B_TICK(0);
 #if W2B_WPG == 1
-      for (int i = 0; i < I.St->nck; i++) __syncthreads();               // s_barrier counts every wavefront: the chunk barriers too
+      for (int i = 0; i < I.s->st.nck; i++) __syncthreads();               // s_barrier counts every wavefront: the chunk barriers too
 #endif
       worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);   // lists of the next step are published; this step is done
       if (stop) break;                                    // (a stop pass trains nothing: no loss terms are left over)
@@ -630,17 +612,17 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
     worker_barrier(bar_step, (unsigned)(NDW + 1) * ++n_step, lane);
     for (long long it = 0;; ++it) {
       const Win2 &I = (it & 1) ? L1 : L0;                 // this step's lists
-      const bool stop = I.St->stop != 0;
+      const bool stop = I.s->st.stop != 0;
       W2B_TICK(9);
       W2B_COUNT(10);
       // ---------------- data phase.  cslot[j] >= 0: LDS slot; -1-k: register-held row k.
-      const W2B_LDS int *const tgt = I.tgt, *const cend = I.cend, *const cslot = I.cslot;
-      const bool word_step = !stop && I.St->cw > 0;
-      const int nt = I.St->nt, cw = I.St->cw, dim = P.dim, col0 = A.col0;
-      const int uc_n = UC ? I.St->uc_n : 0;
-      const float alpha = I.St->alpha;
+      const W2B_LDS int *const tgt = I.s->tgt, *const cend = I.s->cend, *const cslot = I.s->cslot;
+      const bool word_step = !stop && I.s->st.cw > 0;
+      const int nt = I.s->st.nt, cw = I.s->st.cw, dim = P.dim, col0 = A.col0;
+      const int uc_n = UC ? I.s->st.uc_n : 0;
+      const float alpha = I.s->st.alpha;
       const float ar2 = (2.f * alpha) * P.reg;
-      const int n_ret = I.St->n_ret, n_adm = I.St->n_adm;
+      const int n_ret = I.s->st.n_ret, n_adm = I.s->st.n_adm;
       bool deferred = false;                    // steady state: the leaving row is merged back AFTER the step
       int d_row = -1, d_gen = 0, d_slot = 0;
       unsigned d_csum = 0;
@@ -687,10 +669,10 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           // ---- window exchange
           if (n_ret <= 1 && n_adm <= 1) {
             if (n_ret == 1) {
-              d_slot = I.ret_slot[0];
-              d_row = I.ret_row[0];
-              d_gen = I.ret_gen[0];
-              d_csum = L.csum[d_slot * W2B_NDWMAX + wave];
+              d_slot = I.s->ret_slot[0];
+              d_row = I.s->ret_row[0];
+              d_gen = I.s->ret_gen[0];
+              d_csum = L.w->csum[d_slot][wave];
               if (active) {
                 d_rw = lds_ld(L.win + d_slot * dim + col0);
                 d_g = A.ld_u(d_row);                                               // consumed after the step: no stall
@@ -698,27 +680,27 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
               deferred = true;
             }
             if (n_adm == 1) {
-              const int s = I.adm_slot[0], row = I.adm_row[0];
+              const int s = I.s->adm_slot[0], row = I.s->adm_row[0];
               Col4 a = apre;                                                       // loaded during the previous step
               if (row != apre_row) {
                 a = col_zero();
                 if (active) a = A.ld_u(row);
               }
               const unsigned cs = wave_xor(active ? col_bits(a) : 0u);
-              if (lane == 0) L.csum[s * W2B_NDWMAX + wave] = cs;
+              if (lane == 0) L.w->csum[s][wave] = cs;
               if (active) {
                 lds_st(L.win + s * dim + col0, a);
-                A.st_entry(I.adm_gen[0], s, a);
+                A.st_entry(I.s->adm_gen[0], s, a);
               }
             }
             // a register-held outer row of this step that is the row leaving right now must see the merge
-            if (UC && deferred && ((uc_n > 0 && I.uc_row[0] == d_row) || (uc_n > 1 && I.uc_row[1] == d_row))) {
+            if (UC && deferred && ((uc_n > 0 && I.s->uc_row[0] == d_row) || (uc_n > 1 && I.s->uc_row[1] == d_row))) {
               retire_finish<MM>(A, d_row, d_gen, d_slot, d_csum, d_g, d_rw);
               deferred = false;
             }
             // prefetch the row that enters at the next step (never one whose store is still ahead of us)
-            const int nr = I.St->next_row;
-            const bool is_uc = UC && ((uc_n > 0 && I.uc_row[0] == nr) || (uc_n > 1 && I.uc_row[1] == nr));
+            const int nr = I.s->st.next_row;
+            const bool is_uc = UC && ((uc_n > 0 && I.s->uc_row[0] == nr) || (uc_n > 1 && I.s->uc_row[1] == nr));
             apre_row = (nr >= 0 && !(deferred && nr == d_row) && !is_uc) ? nr : -1;
             if (apre_row >= 0 && active) apre = A.ld_u(apre_row);
           } else {
@@ -728,8 +710,8 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           }
           if (word_step) {
             // the (at most two) context rows outside the radius live in registers for this step
-            if (UC && active && uc_n > 0) ur0 = A.ld_u(I.uc_row[0]);
-            if (UC && active && uc_n > 1) ur1 = A.ld_u(I.uc_row[1]);
+            if (UC && active && uc_n > 0) ur0 = A.ld_u(I.s->uc_row[0]);
+            if (UC && active && uc_n > 1) ur1 = A.ld_u(I.s->uc_row[1]);
             // ---- phase A from LDS (ref :431-449), window order
             if (active) {
               for (int j0 = 0; j0 < cw; j0 += 4) {          // four rows requested together, summed in window order
@@ -771,7 +753,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
 
         // ---- phase B (ref :450-492): the W2B_RT rows of this chunk are in registers
         const int n = end - start;
-        W2B_LDS float *red = L.red + par * (W2B_RT * W2B_NDWMAX);
+        W2B_LDS float *red = &L.w->red[par][0][0];
         // partial dot products, W2B_RB rows at a time: W2B_RB independent reduction chains interleave, and the
         // scheduling barrier keeps the compiler from forming all W2B_RT x 4 products first (that is 100 live VGPRs)
 #pragma unroll
@@ -815,7 +797,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           else if (f < -6.f) g = label * alpha;
           else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
           gl = g;
-          if (LOSS && wave == 0) I.lossf[start + lane] = f;     // the producer wavefront books log(sigmoid) next step
+          if (LOSS && wave == 0) I.s->lossf[start + lane] = f;     // the producer wavefront books log(sigmoid) next step
         }
         if (LOSS && P.reg != 0.f) {            // reg * sum q^2 over the chunk's target rows (ref :469,481), re-derived
           float s2 = 0.f;                      // from the rows in registers: one running sum, one reduction per chunk
@@ -831,7 +813,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
               }
             }
           s2 = wave_sum(active ? s2 : 0.f);
-          if (lane == 0) __hip_atomic_fetch_add(&L.S->loss_reg, -(double)(P.reg * s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (lane == 0) __hip_atomic_fetch_add(&L.w->S.loss_reg, -(double)(P.reg * s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         // error accumulation + row update, in target order (ref :486-491)
 #pragma unroll
@@ -840,16 +822,30 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
             const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
             const unsigned hk = (unsigned)(rows[i] - 1);
             if (active) {
+              if (hk < (unsigned)NH || rows[i] <= P.atomic_rank) {
+                // a hot row: its delta is atomically added to this XCD's copy (dozens of workers have the row in
+                // flight); a frequent row below that (w2b_tuning.atomic_rank): atomically added to the row itself
+                Col4 dl;
 #pragma unroll
-              for (int e = 0; e < 4; e++) {
-                float xv = x[i].e[e];
-                // opaque copy: re-derive the quantized value here instead of keeping 4 extra registers per row alive
-                if (QM != 0) asm volatile("" : "+v"(xv));
-                err.e[e] += g * quant<QM>(xv, qp);
-                x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
+                for (int e = 0; e < 4; e++) {
+                  float xv = x[i].e[e];
+                  if (QM != 0) asm volatile("" : "+v"(xv));
+                  err.e[e] += g * quant<QM>(xv, qp);
+                  dl.e[e] = g * avg.e[e] - ar2 * xv;
+                }
+                if (hk < (unsigned)NH) A.add_hot((int)hk, dl);
+                else A.add_v(rows[i], dl);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  float xv = x[i].e[e];
+                  // opaque copy: re-derive the quantized value here instead of keeping 4 extra registers per row alive
+                  if (QM != 0) asm volatile("" : "+v"(xv));
+                  err.e[e] += g * quant<QM>(xv, qp);
+                  x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
+                }
+                A.st_v(rows[i], x[i]);
               }
-              if (hk < (unsigned)NH) A.st_hot((int)hk, x[i]);
-              else A.st_v(rows[i], x[i]);
             }
           }
         }
@@ -862,7 +858,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
 
       if (word_step) {
         // ---- phase C on the resident rows (ref :494-503), window order; duplicates hit the same slot twice
-        if (active && !UC && !I.St->cdup) {
+        if (active && !UC && !I.s->st.cdup) {
           // no slot twice: the read-modify-writes are independent, four rows in flight
           for (int j0 = 0; j0 < cw; j0 += 4) {
             Col4 w[4];
@@ -892,20 +888,20 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
               for (int e = 0; e < 4; e++) ur1.e[e] = ur1.e[e] + (err.e[e] - ar2 * ur1.e[e]);
             }
           }
-          if (UC && uc_n > 0) A.st_u(I.uc_row[0], ur0);
-          if (UC && uc_n > 1) A.st_u(I.uc_row[1], ur1);
+          if (UC && uc_n > 0) A.st_u(I.s->uc_row[0], ur0);
+          if (UC && uc_n > 1) A.st_u(I.s->uc_row[1], ur1);
         }
         if (LOSS && P.reg != 0.f) {
           const float s = wave_sum(regsq);
           if (lane == 0)                                              // ref :437-445 (summed over the window)
-            __hip_atomic_fetch_add(&L.S->loss_reg, -(double)(P.reg * s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&L.w->S.loss_reg, -(double)(P.reg * s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
       if (NH > 0 && !stop && (it & (P.hot_period - 1)) == P.hot_period - 1) {
         // this worker's turn: xhot_m of the XCD's hot rows meet their master rows (the copies of a launch are folded
         // into the masters by k_xhot_fold afterwards, so a stop pass has nothing to do)
         for (int j = 0; j < P.xhot_m && j < NH; j++)
-          xhot_merge_row<Rows<MM>::M, Rows<MM>::TB>(P.v, A.hot_c, A.hot_e, (merge_cursor + j) % NH, NH, dim, col0, active, P.tab_bytes);
+          xhot_merge_row(P.v, A.hot_c, A.hot_e, A.hot_l, (merge_cursor + j) % NH, NH, dim, col0, active, wave, lane);
         merge_cursor += P.xhot_m;
       }
       W2B_TICK(8);
@@ -918,8 +914,8 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
   if (LOSS && producer) {       // producer lanes hold the log-sigmoid terms; the regularisation terms were summed in LDS
     const double lsum = wave_sum_d(loss_acc);
     if (lane == 0) {
-      atomicAdd(&G->loss, lsum + L.S->loss_reg);
-      atomicAdd(&P.shared->loss_epoch, lsum + L.S->loss_reg);       // what w2b_epoch_poll reports without a per-worker copy
+      atomicAdd(&G->loss, lsum + L.w->S.loss_reg);
+      atomicAdd(&P.shared->loss_epoch, lsum + L.w->S.loss_reg);       // what w2b_epoch_poll reports without a per-worker copy
     }
   }
   if (tid == 0) {
@@ -937,6 +933,7 @@ static int win2_threads(int dim) { return (((dim / 4) + 63) / 64 + 1) * 64; }
 // each) share the 160 KiB of a CU.
 int w2b_resident_plan(int dim, int window, int negative) {
   if (dim % 4 != 0 || dim > 4 * 64 * W2B_NDWMAX) return -1;     // 16-byte columns, at most 4 data wavefronts
+  if (window > W2B_WMAX || negative + 1 > W2B_TMAX) return -1;   // capacities of the worker's LDS record (WorkRec / StepRec)
   const size_t budget = 80 * 1024;
   if (win2_lds_bytes(dim, window, negative, window) <= budget) return window;
   if (window >= 2 && win2_lds_bytes(dim, window, negative, window - 1) <= budget) return window - 1;

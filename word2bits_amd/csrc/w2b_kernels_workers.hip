@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     else __syncthreads();
     if (VEC == 4 && hot && ++since_merge >= P.hot_period) {
       since_merge = 0;
-      xhot_merge_event<MM>(P, XH, merge_cursor, tid * VEC, tid * VEC < P.dim);
+      xhot_merge_event(P, XH, merge_cursor, tid * VEC, tid * VEC < P.dim);
     }
   }
   // save the worker

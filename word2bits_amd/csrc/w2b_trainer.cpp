@@ -50,7 +50,9 @@ struct w2b_trainer {
   // XCD-shared copies of the hottest rows (XHot in w2b_device.hpp)
   w2b_tuning tune{};            // knobs of include/word2bits_hip.h (defaults set in w2b_trainer_create)
   std::vector<double> rate_v, rate_u;   // [k]: uses of row k + 1 of v (as a target) / of u (as a context row) per centre word
-  float *xhot = nullptr;        // [W2B_NXCD][2][nu + nv][dim]
+  std::vector<int64_t> counts;          // vocab[].cn as given to w2b_set_vocab_counts (sorted by count behind row 0)
+  double counts_pw = 0, counts_tot = 0; // sum cn^0.75, sum cn
+  float *xhot = nullptr;        // [W2B_NXCD]{copies [nu + nv][dim], entries [nu + nv][dim], merge locks [nu + nv][W2B_MAXW]}
   size_t xhot_floats = 0;
   int xhot_nu = -1, xhot_nv = -1;       // layout the buffer currently has (-1: none)
   bool xhot_master_changed = true;      // the master rows may differ from what the copies were folded into
@@ -58,6 +60,7 @@ struct w2b_trainer {
   const int32_t *corpus = nullptr;
   int32_t *corpus_owned = nullptr;
   long long n_tokens = 0;
+  bool corpus_more = false;     // the tokens are a slice of the file and the file continues behind it
   W2bWorker *workers = nullptr;
   W2bShared *shared = nullptr;
   unsigned long long *jump_a = nullptr, *jump_c = nullptr;
@@ -80,9 +83,16 @@ struct w2b_trainer {
   hipEvent_t poll_ev[kPoll] = {nullptr, nullptr, nullptr, nullptr};
   long long launches = 0;                  // w2b_train_step calls since w2b_epoch_begin
   unsigned long long *wca_buf = nullptr;   // [2]: this replica's word_count_actual, the sum over all replicas
-  hipEvent_t sync_a = nullptr, sync_b = nullptr;
-  double sync_ms = 0;                       // device time of the replica exchanges since the last w2b_sync_stats
+  // replica exchange (see "multi-GPU" below): two exchange streams, chunk staging buffers, events
+  hipStream_t xs[2] = {nullptr, nullptr};
+  float *xd[2] = {nullptr, nullptr}, *xsum[2] = {nullptr, nullptr};   // per slot: own delta / sum over the replicas
+  long long xchunk = 0;                     // floats per chunk
+  hipEvent_t x_train = nullptr;             // "the launches issued so far": the exchange streams wait for it
+  hipEvent_t x_done[2] = {nullptr, nullptr};     // last operation of the latest exchange on each exchange stream
+  bool x_pending = false;                   // the training stream has not yet waited for x_done
+  std::vector<hipEvent_t> x_ev;             // (begin, end) pairs of the exchanges since the last w2b_sync_stats
   long long sync_count = 0;
+  long long sync_bytes = 0;
 };
 
 // --------------------------------------------------------------------------------- host tables
@@ -162,6 +172,7 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.keep = (t->cfg.sample > 0) ? t->keep : nullptr;
   p.corpus = t->corpus;
   p.n_tokens = t->n_tokens;
+  p.corpus_more = t->corpus_more ? 1 : 0;
   p.workers = t->workers;
   p.shared = t->shared;
   p.jump_a = t->jump_a;
@@ -192,6 +203,7 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.xhot = nullptr;                    // set by xhot_prepare() for the launch that uses the copies
   p.xhot_u = p.xhot_v = 0;
   p.xhot_m = 1;
+  p.atomic_rank = 0;
   p.starting_alpha = t->cfg.alpha;
   p.sample = t->cfg.sample;
   p.reg = t->cfg.reg;
@@ -232,6 +244,8 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
   t->tune.force_row_desc = 0;
   t->tune.grid_per_cu = 0;
   t->tune.mem_mode = -1;
+  t->tune.atomic_rank = -1;
+  t->tune.atomic_cap = 0;         // (set from measurements: DESIGN.md section 6)
   HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
   t->table_elems = (long long)cfg->vocab_size * cfg->layer1_size;
   HIPCHK(hipMalloc(&t->uv, sizeof(float) * 2 * t->table_elems));
@@ -288,15 +302,20 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   for (hipEvent_t e : t->ev_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : t->poll_ev) if (e) (void)hipEventDestroy(e);
   if (t->poll_host) (void)hipHostFree(t->poll_host);
-  if (t->sync_a) (void)hipEventDestroy(t->sync_a);
-  if (t->sync_b) (void)hipEventDestroy(t->sync_b);
-  void *ptrs[] = {t->uv, t->base, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->xhot, t->corpus_owned, t->workers, t->shared,
+  for (hipStream_t q : t->xs) if (q) (void)hipStreamSynchronize(q);
+  for (hipEvent_t e : t->x_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : t->x_done) if (e) (void)hipEventDestroy(e);
+  if (t->x_train) (void)hipEventDestroy(t->x_train);
+  for (hipStream_t q : t->xs) if (q) (void)hipStreamDestroy(q);
+  void *ptrs[] = {t->xd[0], t->xd[1], t->xsum[0], t->xsum[1], t->uv, t->base, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->xhot, t->corpus_owned, t->workers, t->shared,
                   t->jump_a, t->jump_c, t->st_center, t->st_off, t->st_ctx, t->st_neg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
 }
+
+static int xchg_fence(w2b_trainer *t);      // the training stream waits for a replica exchange in flight (below)
 
 // --------------------------------------------------------------------------------- tuning knobs
 extern "C" int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out) {
@@ -320,6 +339,7 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
 #else
   if (in->mem_mode < -1 || in->mem_mode > 1) return fail(W2B_EINVAL, "w2b_set_tuning: mem_mode must be -1, 0 or 1");
 #endif
+  if (in->atomic_rank < -1 || in->atomic_cap < 0) return fail(W2B_EINVAL, "w2b_set_tuning: atomic_rank >= -1, atomic_cap >= 0");
   for (int r : in->reserved) if (r != 0) return fail(W2B_EINVAL, "w2b_set_tuning: reserved fields must be zero");
   t->tune = *in;
   return W2B_OK;
@@ -334,6 +354,7 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
 // --------------------------------------------------------------------------------- model
 extern "C" int w2b_init_net(w2b_trainer *t) {
   NEED(t);
+  if (int rc = xchg_fence(t)) return rc;
   // ref :343-361: value_k = ((x_k & 0xFFFF) / 65536.f) - 0.5 with x_0 = 1; the low 16 bits have
   // period 65536, so a LUT indexed by the draw number modulo 65536 reproduces the sequence.
   std::vector<float> lut(65536);
@@ -358,6 +379,7 @@ extern "C" int w2b_init_net(w2b_trainer *t) {
 extern "C" int w2b_set_model(w2b_trainer *t, const float *u, const float *v) {
   NEED(t);
   if (!u || !v) return fail(W2B_EINVAL, "w2b_set_model: null table");
+  if (int rc = xchg_fence(t)) return rc;
   const size_t bytes = sizeof(float) * t->table_elems;
   HIPCHK(hipMemcpyAsync(t->uv, u, bytes, hipMemcpyHostToDevice, t->stream));
   HIPCHK(hipMemcpyAsync(t->uv + t->table_elems, v, bytes, hipMemcpyHostToDevice, t->stream));
@@ -370,6 +392,7 @@ extern "C" int w2b_set_model(w2b_trainer *t, const float *u, const float *v) {
 extern "C" int w2b_get_model(w2b_trainer *t, float *u, float *v) {
   NEED(t);
   const size_t bytes = sizeof(float) * t->table_elems;
+  if (int rc = xchg_fence(t)) return rc;
   HIPCHK(hipStreamSynchronize(t->stream));
   if (u) HIPCHK(hipMemcpy(u, t->uv, bytes, hipMemcpyDeviceToHost));
   if (v) HIPCHK(hipMemcpy(v, t->uv + t->table_elems, bytes, hipMemcpyDeviceToHost));
@@ -377,7 +400,9 @@ extern "C" int w2b_get_model(w2b_trainer *t, float *u, float *v) {
 }
 
 extern "C" int w2b_model_device_ptrs(w2b_trainer *t, void **u_dev, void **v_dev) {
-  if (!t) return fail(W2B_EINVAL, "null trainer");
+  NEED(t);
+  if (int rc = xchg_fence(t)) return rc;
+  HIPCHK(hipStreamSynchronize(t->stream));
   t->xhot_master_changed = true;           // the caller may write the tables (replica exchange on a view of them)
   if (u_dev) *u_dev = t->uv;
   if (v_dev) *v_dev = t->uv + t->table_elems;
@@ -386,6 +411,7 @@ extern "C" int w2b_model_device_ptrs(w2b_trainer *t, void **u_dev, void **v_dev)
 
 void w2b_internal_trainer_view(w2b_trainer *t, float **u, float **v, long long *V, long long *D, int *bitlevel,
                                int *device, hipStream_t *stream) {
+  (void)xchg_fence(t);
   *u = t->uv;
   *v = t->uv + t->table_elems;
   *V = t->cfg.vocab_size;
@@ -398,6 +424,7 @@ void w2b_internal_trainer_view(w2b_trainer *t, float **u, float **v, long long *
 extern "C" int w2b_export_quantized(w2b_trainer *t, float *out) {
   NEED(t);
   if (!out) return fail(W2B_EINVAL, "w2b_export_quantized: null output");
+  if (int rc = xchg_fence(t)) return rc;
   // exported in slabs so that a 14.8 GB table does not need a second full-size device buffer
   const long long slab = 64ll << 20;
   float *tmp = nullptr;
@@ -445,6 +472,9 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
     // how long a prefix is decided per launch from these rates and the number of workers (xhot_plan).
     double pw = 0, tot = 0;
     for (int64_t a = 0; a < V; a++) { pw += pow((double)cn[a], 0.75); tot += (double)cn[a]; }
+    t->counts.assign(cn, cn + V);
+    t->counts_pw = pw;
+    t->counts_tot = tot;
     const int n = (int)(V - 1 < W2B_XHOT_MAX ? V - 1 : W2B_XHOT_MAX);
     t->rate_v.assign((size_t)(n > 0 ? n : 0), 0.0);
     t->rate_u.assign((size_t)(n > 0 ? n : 0), 0.0);
@@ -517,14 +547,22 @@ extern "C" int w2b_timing_read(w2b_trainer *t, double *kernel_ms, int64_t *launc
 
 extern "C" int w2b_synchronize(w2b_trainer *t) {
   NEED(t);
+  if (int rc = xchg_fence(t)) return rc;
   HIPCHK(hipStreamSynchronize(t->stream));
   return W2B_OK;
 }
 
 // --------------------------------------------------------------------------------- form (i): workers
+extern "C" int w2b_set_corpus_slice(w2b_trainer *t, const int32_t *ids, int64_t n, int32_t more_follows) {
+  int rc = w2b_set_corpus(t, ids, n);
+  if (rc == W2B_OK) t->corpus_more = more_follows != 0;
+  return rc;
+}
+
 extern "C" int w2b_set_corpus(w2b_trainer *t, const int32_t *ids, int64_t n) {
   NEED(t);
   if (!ids || n < 0) return fail(W2B_EINVAL, "w2b_set_corpus: bad argument");
+  t->corpus_more = false;
   for (int64_t i = 0; i < n; i++)       // a bad id would be an out-of-bounds row access on the device
     if (ids[i] < 0 || ids[i] >= t->cfg.vocab_size) return fail(W2B_EINVAL, "w2b_set_corpus: token id out of range");
   HIPCHK(hipStreamSynchronize(t->stream));
@@ -544,6 +582,7 @@ extern "C" int w2b_set_corpus_device(w2b_trainer *t, const void *ids_dev, int64_
   if (t->corpus_owned) HIPCHK(hipFree(t->corpus_owned));
   t->corpus_owned = nullptr;
   t->corpus = (const int32_t *)ids_dev;
+  t->corpus_more = false;
   t->n_tokens = n;
   return W2B_OK;
 }
@@ -627,6 +666,32 @@ static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int 
   if (with_u) *nu = pick(t->tune.hot_rows_u, t->rate_u);
 }
 
+// Rows 1..n (by count) whose updates are atomic adds at their master address (w2b_tuning.atomic_rank).  Automatic: a
+// load / modify / store of a row is open for about 10 us on this machine (the rows of a chunk are loaded together and
+// written after their dot products), during which every other worker's update of the same row is lost; a row that is
+// a target of `rate` centre words is hit rate x words/s times a second, i.e. about 0.6 x workers x rate times per
+// window.  Rows for which that reaches W2B_ATOMIC_LOAD are updated atomically, at most atomic_cap of them (an atomic
+// update costs more memory time than a store).
+static const double W2B_ATOMIC_LOAD = 0.25;
+static int atomic_plan(const w2b_trainer *t, long long workers) {
+  if (t->cfg.exact_reduction) return 0;
+  const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
+  if (mem_mode != 0) return 0;
+  const long long V = t->cfg.vocab_size;
+  if (t->tune.atomic_rank >= 0) return (int)(t->tune.atomic_rank < V - 1 ? t->tune.atomic_rank : V - 1);
+  if (t->counts.empty() || t->counts_pw <= 0 || t->counts_tot <= 0) return 0;
+  auto rate = [&](long long r) {           // uses of row r of v as a target per centre word (monotone: counts are sorted)
+    const double c = (double)t->counts[(size_t)r];
+    return t->cfg.negative * pow(c, 0.75) / t->counts_pw + c / t->counts_tot;
+  };
+  long long lo = 0, hi = V - 1;            // largest r in [1, V-1] with 0.6 * workers * rate(r) >= W2B_ATOMIC_LOAD
+  while (lo < hi) {
+    const long long mid = (lo + hi + 1) / 2;
+    if (0.6 * (double)workers * rate(mid) >= W2B_ATOMIC_LOAD) lo = mid; else hi = mid - 1;
+  }
+  return (int)(lo < t->tune.atomic_cap ? lo : t->tune.atomic_cap);
+}
+
 // Buffer + parameters of the XCD-shared hot rows for one launch; folds the copies into the masters first when the
 // layout changed or somebody wrote the master rows since the last launch.
 static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool with_u) {
@@ -635,8 +700,9 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   p.xhot = nullptr;
   p.xhot_u = nu;
   p.xhot_v = nv;
+  p.atomic_rank = atomic_plan(t, workers);
   if (nu + nv == 0) return W2B_OK;
-  const size_t need = (size_t)W2B_NXCD * 2 * (nu + nv) * t->cfg.layer1_size;
+  const size_t need = (size_t)W2B_NXCD * ((size_t)2 * (nu + nv) * t->cfg.layer1_size + (size_t)(nu + nv) * W2B_MAXW);
   bool fresh = (nu != t->xhot_nu || nv != t->xhot_nv);
   if (need > t->xhot_floats) {
     HIPCHK(hipStreamSynchronize(t->stream));
@@ -753,6 +819,8 @@ extern "C" int w2b_epoch_poll(w2b_trainer *t, int32_t lag, int32_t *finished, in
   const int slot = (int)((t->launches - 1 - lag) % w2b_trainer::kPoll);
   HIPCHK(hipEventSynchronize(t->poll_ev[slot]));
   const W2bShared &sh = t->poll_host[slot];
+  if (sh.corpus_overrun)
+    return fail(W2B_ESTATE, "a worker reached the end of its corpus slice before its quota (w2b_set_corpus_slice: slice too short)");
   if (finished) *finished = (sh.workers_done >= t->cfg.num_threads) ? 1 : 0;
   if (wca) *wca = (int64_t)sh.word_count_actual;
   if (alpha) *alpha = sh.alpha;
@@ -763,9 +831,12 @@ extern "C" int w2b_epoch_poll(w2b_trainer *t, int32_t lag, int32_t *finished, in
 extern "C" int w2b_epoch_status(w2b_trainer *t, int32_t *finished, int64_t *wca, float *alpha,
                                 double *loss_sum) {
   NEED(t);
+  if (int rc = xchg_fence(t)) return rc;
   HIPCHK(hipStreamSynchronize(t->stream));
   W2bShared sh;
   HIPCHK(hipMemcpy(&sh, t->shared, sizeof sh, hipMemcpyDeviceToHost));
+  if (sh.corpus_overrun)
+    return fail(W2B_ESTATE, "a worker reached the end of its corpus slice before its quota (w2b_set_corpus_slice: slice too short)");
   if (finished) *finished = (sh.workers_done >= t->cfg.num_threads) ? 1 : 0;
   if (wca) *wca = (int64_t)sh.word_count_actual;
   if (alpha) *alpha = sh.alpha;
@@ -871,81 +942,206 @@ extern "C" int w2b_comm_unique_id(void *out128) {
   return W2B_OK;
 }
 
+// Buffers, streams and events of the replica exchange (first use).
+static int xchg_setup(w2b_trainer *t) {
+  if (t->base) return W2B_OK;
+  const long long n = 2 * t->table_elems;
+  // chunks of at most 64 M floats (256 MB): small enough that the elementwise kernels of one chunk overlap with the
+  // collective of the other, large enough that a ring all-reduce over xGMI runs at its bus bandwidth
+  t->xchunk = n < (64ll << 20) ? ((n + 3) & ~3ll) : (64ll << 20);
+  hipError_t e = hipMalloc(&t->base, sizeof(float) * n);
+  for (int k = 0; k < 2 && e == hipSuccess; k++) {
+    e = hipMalloc(&t->xd[k], sizeof(float) * t->xchunk);
+    if (e == hipSuccess) e = hipMalloc(&t->xsum[k], sizeof(float) * t->xchunk);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->xs[k], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_done[k], hipEventDisableTiming);
+  }
+  if (e == hipSuccess && !t->wca_buf) e = hipMalloc(&t->wca_buf, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_train, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->base, t->uv, sizeof(float) * n, hipMemcpyDeviceToDevice, t->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  if (e != hipSuccess) {
+    for (int k = 0; k < 2; k++) {
+      if (t->xd[k]) (void)hipFree(t->xd[k]);
+      if (t->xsum[k]) (void)hipFree(t->xsum[k]);
+      t->xd[k] = t->xsum[k] = nullptr;
+    }
+    if (t->base) (void)hipFree(t->base);
+    t->base = nullptr;
+    return fail(W2B_EHIP, std::string("replica exchange setup: ") + hipGetErrorString(e));
+  }
+  return W2B_OK;
+}
+
+// The training stream (and with it every reader of the model) waits for the exchange in flight.
+static int xchg_fence(w2b_trainer *t) {
+  if (!t->x_pending) return W2B_OK;
+  for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->stream, t->x_done[k], 0));
+  t->x_pending = false;
+  t->xhot_master_changed = true;
+  return W2B_OK;
+}
+
 extern "C" int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id128) {
   NEED(t);
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(W2B_EINVAL, "w2b_comm_init: bad rank");
   t->nranks = nranks;
   t->rank = rank;
-  if (nranks == 1) return W2B_OK;   // replicas of one: nothing to exchange
+  // replicas of one and no id: nothing to exchange.  With an id a communicator of size 1 is created all the same, so
+  // that the whole exchange path (delta, all-reduce, apply, progress counters) can run on a one-GPU machine.
+  if (nranks == 1 && !id128) return W2B_OK;
   if (!id128) return fail(W2B_EINVAL, "w2b_comm_init: null id");
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
   NCCLCHK(ncclCommInitRank(&t->comm, nranks, id, rank));
-  hipError_t e = hipMalloc(&t->base, sizeof(float) * 2 * t->table_elems);
-  if (e == hipSuccess) e = hipMalloc(&t->wca_buf, 2 * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipEventCreate(&t->sync_a);
-  if (e == hipSuccess) e = hipEventCreate(&t->sync_b);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(t->base, t->uv, sizeof(float) * 2 * t->table_elems, hipMemcpyDeviceToDevice, t->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
-  if (e != hipSuccess) {                     // leave the trainer as a single replica, not half-initialised
-    if (t->base) (void)hipFree(t->base);
-    t->base = nullptr;
-    if (t->wca_buf) (void)hipFree(t->wca_buf);
-    t->wca_buf = nullptr;
+  if (int rc = xchg_setup(t)) {                 // leave the trainer as a single replica, not half-initialised
     ncclCommDestroy(t->comm);
     t->comm = nullptr;
     t->nranks = 1;
     t->rank = 0;
-    return fail(W2B_EHIP, std::string("w2b_comm_init: ") + hipGetErrorString(e));
+    return rc;
   }
+  return W2B_OK;
+}
+
+// ---- the exchange in phases (include/word2bits_hip.h).  Chunk c lives on exchange stream c % 2 with its own staging
+// buffers, so consecutive chunks overlap: while the collective of one chunk runs, the delta of the next is computed
+// and the sum of the previous one is applied.
+static long long xchg_chunks(const w2b_trainer *t) { return (2 * t->table_elems + t->xchunk - 1) / t->xchunk; }
+
+extern "C" int w2b_exchange_init(w2b_trainer *t) {
+  NEED(t);
+  return xchg_setup(t);
+}
+
+static int xchg_begin(w2b_trainer *t) {
+  if (!t->base) return fail(W2B_ESTATE, "replica exchange: w2b_comm_init / w2b_exchange_init first (while all replicas "
+                                        "still hold the same model)");
+  while (t->x_ev.size() >= 512) {            // nobody reads the timings (w2b_sync_stats): keep the list bounded
+    HIPCHK(hipEventSynchronize(t->x_ev[1]));
+    (void)hipEventDestroy(t->x_ev[0]);
+    (void)hipEventDestroy(t->x_ev[1]);
+    t->x_ev.erase(t->x_ev.begin(), t->x_ev.begin() + 2);
+  }
+  // the exchange sees every launch issued so far (and nothing forces the launches issued later to wait for it)
+  HIPCHK(hipEventRecord(t->x_train, t->stream));
+  for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->xs[k], t->x_train, 0));
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  t->x_ev.push_back(a);
+  t->x_ev.push_back(b);
+  HIPCHK(hipEventRecord(a, t->xs[0]));
+  return W2B_OK;
+}
+static int xchg_delta(w2b_trainer *t, long long c) {
+  const long long n = 2 * t->table_elems, o = c * t->xchunk, m = (n - o < t->xchunk) ? n - o : t->xchunk;
+  const int k = (int)(c & 1);
+  HIPCHK(w2b_launch_xchg_delta(t->uv + o, t->base + o, t->xd[k], t->xsum[k], m, t->xs[k]));
+  return W2B_OK;
+}
+static int xchg_apply(w2b_trainer *t, long long c, float scale) {
+  const long long n = 2 * t->table_elems, o = c * t->xchunk, m = (n - o < t->xchunk) ? n - o : t->xchunk;
+  const int k = (int)(c & 1);
+  HIPCHK(w2b_launch_xchg_apply(t->uv + o, t->base + o, t->xd[k], t->xsum[k], scale, m, t->xs[k]));
+  return W2B_OK;
+}
+static int xchg_end(w2b_trainer *t) {
+  // x_ev.back() = the end of this exchange: stream 0 waits for stream 1's last operation first
+  HIPCHK(hipEventRecord(t->x_done[1], t->xs[1]));
+  HIPCHK(hipStreamWaitEvent(t->xs[0], t->x_done[1], 0));
+  HIPCHK(hipEventRecord(t->x_ev.back(), t->xs[0]));
+  HIPCHK(hipEventRecord(t->x_done[0], t->xs[0]));
+  t->x_pending = true;
+  t->sync_count++;
+  t->sync_bytes += 2 * t->table_elems * (long long)sizeof(float);
   return W2B_OK;
 }
 
 extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
   NEED(t);
-  if (t->nranks <= 1 || !t->comm) return W2B_OK;
+  if (!t->comm) return W2B_OK;             // a single replica without a communicator: nothing to exchange
   if (mode != 0 && mode != 1) return fail(W2B_EINVAL, "w2b_sync_replicas: unknown mode");
-  const long long n = 2 * t->table_elems;
-  t->xhot_master_changed = true;
-  HIPCHK(hipEventRecord(t->sync_a, t->stream));
+  if (int rc = xchg_begin(t)) return rc;
   // progress first (16 bytes): every replica learns the global word count -- the alpha schedule (ref :391) is exact
   // at every exchange and extrapolates in between (W2bShared::wca_others)
-  HIPCHK(w2b_launch_wca_pack(t->shared, t->wca_buf, t->stream));
-  NCCLCHK(ncclAllReduce(t->wca_buf, t->wca_buf + 1, 1, ncclUint64, ncclSum, t->comm, t->stream));
-  HIPCHK(w2b_launch_wca_unpack(t->shared, t->wca_buf, t->stream));
-  // one all-reduce over [u || v]; chunked so that each RCCL call stays below 2^31 elements
-  const long long chunk = 1ll << 30;
-  if (mode == 0) {
-    HIPCHK(w2b_launch_sub(t->uv, t->base, n, t->stream));             // W <- W - base
-    for (long long o = 0; o < n; o += chunk) {
-      const long long m = (n - o < chunk) ? n - o : chunk;
-      NCCLCHK(ncclAllReduce(t->uv + o, t->uv + o, (size_t)m, ncclFloat, ncclSum, t->comm, t->stream));
-    }
-    HIPCHK(w2b_launch_add_snap(t->uv, t->base, n, t->stream));        // W <- base + sum; base <- W
-  } else if (mode == 1) {
-    for (long long o = 0; o < n; o += chunk) {
-      const long long m = (n - o < chunk) ? n - o : chunk;
-      NCCLCHK(ncclAllReduce(t->uv + o, t->uv + o, (size_t)m, ncclFloat, ncclSum, t->comm, t->stream));
-    }
-    HIPCHK(w2b_launch_scale_snap(t->uv, t->base, 1.f / (float)t->nranks, n, t->stream));
+  HIPCHK(w2b_launch_wca_pack(t->shared, t->wca_buf, t->xs[0]));
+  NCCLCHK(ncclAllReduce(t->wca_buf, t->wca_buf + 1, 1, ncclUint64, ncclSum, t->comm, t->xs[0]));
+  HIPCHK(w2b_launch_wca_unpack(t->shared, t->wca_buf, t->xs[0]));
+  const float scale = mode == 0 ? 1.f : 1.f / (float)t->nranks;
+  const long long nc = xchg_chunks(t), n = 2 * t->table_elems;
+  for (long long c = 0; c < nc; c++) {
+    const long long o = c * t->xchunk, m = (n - o < t->xchunk) ? n - o : t->xchunk;
+    const int k = (int)(c & 1);
+    if (int rc = xchg_delta(t, c)) return rc;
+    NCCLCHK(ncclAllReduce(t->xsum[k], t->xsum[k], (size_t)m, ncclFloat, ncclSum, t->comm, t->xs[k]));
+    if (int rc = xchg_apply(t, c, scale)) return rc;
   }
-  HIPCHK(hipEventRecord(t->sync_b, t->stream));
-  t->sync_count++;
-  if (t->timing) {                      // device time of the exchange (bench.py reports the cost per exchange)
-    HIPCHK(hipEventSynchronize(t->sync_b));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, t->sync_a, t->sync_b));
-    t->sync_ms += ms;
+  return xchg_end(t);
+}
+
+// ---- the same exchange for a host that brings its own collective (MPI, torch.distributed over gloo / RCCL, ...):
+//   w2b_exchange_begin -> for every chunk: w2b_exchange_delta, <sum *buf over the replicas, in place>, w2b_exchange_apply
+//   -> w2b_exchange_end.  The buffer handed out is device memory; the library's kernels run on its exchange streams, so
+// w2b_exchange_delta returns after the delta is complete (the host's collective may use any stream or the CPU) and
+// w2b_exchange_apply expects the sum to be complete when it is called.
+extern "C" int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count) {
+  NEED(t);
+  if (int rc = xchg_begin(t)) return rc;
+  if (n_chunks) *n_chunks = xchg_chunks(t);
+  if (local_word_count) {
+    HIPCHK(w2b_launch_wca_pack(t->shared, t->wca_buf, t->xs[0]));
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, t->wca_buf, sizeof v, hipMemcpyDeviceToHost, t->xs[0]));
+    HIPCHK(hipStreamSynchronize(t->xs[0]));
+    *local_word_count = (int64_t)v;
   }
   return W2B_OK;
+}
+extern "C" int w2b_exchange_delta(w2b_trainer *t, int64_t chunk, void **buf_dev, int64_t *elems) {
+  NEED(t);
+  if (!t->base || t->x_ev.empty()) return fail(W2B_ESTATE, "w2b_exchange_delta: w2b_exchange_begin first");
+  if (chunk < 0 || chunk >= xchg_chunks(t) || !buf_dev || !elems) return fail(W2B_EINVAL, "w2b_exchange_delta: bad argument");
+  if (int rc = xchg_delta(t, chunk)) return rc;
+  HIPCHK(hipStreamSynchronize(t->xs[chunk & 1]));
+  const long long n = 2 * t->table_elems, o = chunk * t->xchunk;
+  *buf_dev = t->xsum[chunk & 1];
+  *elems = (n - o < t->xchunk) ? n - o : t->xchunk;
+  return W2B_OK;
+}
+extern "C" int w2b_exchange_apply(w2b_trainer *t, int64_t chunk, float scale) {
+  NEED(t);
+  if (!t->base || t->x_ev.empty()) return fail(W2B_ESTATE, "w2b_exchange_apply: w2b_exchange_begin first");
+  if (chunk < 0 || chunk >= xchg_chunks(t)) return fail(W2B_EINVAL, "w2b_exchange_apply: bad chunk");
+  return xchg_apply(t, chunk, scale);
+}
+extern "C" int w2b_exchange_end(w2b_trainer *t, int64_t word_count_all_replicas) {
+  NEED(t);
+  if (!t->base || t->x_ev.empty()) return fail(W2B_ESTATE, "w2b_exchange_end: w2b_exchange_begin first");
+  if (word_count_all_replicas >= 0) {        // the alpha schedule runs on the global count (ref :391)
+    unsigned long long v = (unsigned long long)word_count_all_replicas;
+    HIPCHK(hipMemcpyAsync(t->wca_buf + 1, &v, sizeof v, hipMemcpyHostToDevice, t->xs[0]));
+    HIPCHK(hipStreamSynchronize(t->xs[0]));
+    HIPCHK(w2b_launch_wca_unpack(t->shared, t->wca_buf, t->xs[0]));
+  }
+  return xchg_end(t);
 }
 
 extern "C" int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms) {
   if (!t) return fail(W2B_EINVAL, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
   if (exchanges) *exchanges = t->sync_count;
-  if (device_ms) *device_ms = t->sync_ms;
+  double ms = 0;
+  for (size_t i = 0; i + 1 < t->x_ev.size(); i += 2) {      // begin -> end of every exchange, read after the fact
+    HIPCHK(hipEventSynchronize(t->x_ev[i + 1]));
+    float m = 0;
+    HIPCHK(hipEventElapsedTime(&m, t->x_ev[i], t->x_ev[i + 1]));
+    ms += m;
+  }
+  for (hipEvent_t e : t->x_ev) (void)hipEventDestroy(e);
+  t->x_ev.clear();
+  if (device_ms) *device_ms = ms;
   t->sync_count = 0;
-  t->sync_ms = 0;
+  t->sync_bytes = 0;
   return W2B_OK;
 }

@@ -6,7 +6,7 @@
 // happens: the corpus is tokenised once on the host (word2bits_corpus.h) and every epoch is a
 // sequence of GPU launches in which each of the -threads Hogwild workers is one workgroup.
 // GPU-only additions use new flag names: -gpus, -sync-every, -positions, -device, -table-size, -relaxed,
-// -window-cache, -exact, -eval, -hot-rows, -hot-period, -row-desc.
+// -window-cache, -exact, -eval, -hot-rows, -hot-period, -row-desc, -atomic-rank, -atomic-cap.
 #include <pthread.h>
 #include <unistd.h>
 
@@ -40,6 +40,8 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   std::string eval_file;               // -eval FILE: questions to score on the GPU after the final save (-binary 1)
   int hot_rows = -1;                   // -hot-rows N: leading rows of v (and u) with per-XCD copies; -1 = from the counts
   int hot_period = 0;                  // -hot-period N: centre words between two merge events of a worker (0 = default)
+  int atomic_rank = -2;                // -atomic-rank N: rows 1..N are updated with atomic adds (-1 automatic; default: library's)
+  int atomic_cap = -1;                 // -atomic-cap N: most rows the automatic choice takes
   int row_desc = 0;                    // -row-desc 1: the row addressing of tables >= 2 GiB on any table (w2b_tuning.force_row_desc)
 };
 
@@ -122,6 +124,8 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-hot-rows", argc, argv)) > 0) o.hot_rows = atoi(argv[i + 1]);
   if ((i = arg_pos("-hot-period", argc, argv)) > 0) o.hot_period = atoi(argv[i + 1]);
   if ((i = arg_pos("-row-desc", argc, argv)) > 0) o.row_desc = atoi(argv[i + 1]);
+  if ((i = arg_pos("-atomic-rank", argc, argv)) > 0) o.atomic_rank = atoi(argv[i + 1]);
+  if ((i = arg_pos("-atomic-cap", argc, argv)) > 0) o.atomic_cap = atoi(argv[i + 1]);
 
   // ---- TrainModel, ref :518-577
   printf("Starting training using file %s\n", o.train_file.c_str());
@@ -213,18 +217,49 @@ int main(int argc, char **argv) {
     cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
-    if (o.hot_rows >= 0 || o.hot_period > 0 || o.row_desc) {
+    if (o.hot_rows >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0) {
       w2b_tuning tn;
       CK(w2b_get_tuning(a->r->t, &tn));
       if (o.hot_rows >= 0) tn.hot_rows_v = tn.hot_rows_u = o.hot_rows;
       if (o.hot_period > 0) tn.hot_period = o.hot_period;
       tn.force_row_desc = o.row_desc ? 1 : 0;
+      if (o.atomic_rank >= -1) tn.atomic_rank = o.atomic_rank;
+      if (o.atomic_cap >= 0) tn.atomic_cap = o.atomic_cap;
       CK(w2b_set_tuning(a->r->t, &tn));
     }
     CK(w2b_init_net(a->r->t));                              // ref :528
     CK(w2b_set_vocab_counts(a->r->t, w2b_corpus_counts(a->c), o.negative > 0 ? o.table_size : 0));  // ref :529
-    CK(w2b_set_corpus(a->r->t, w2b_corpus_tokens(a->c), w2b_corpus_num_tokens(a->c)));
-    CK(w2b_set_shards(a->r->t, a->st + a->r->index * a->per_gpu, a->ov + a->r->index * a->per_gpu));
+    if (o.gpus == 1) {
+      CK(w2b_set_corpus(a->r->t, w2b_corpus_tokens(a->c), w2b_corpus_num_tokens(a->c)));
+      CK(w2b_set_shards(a->r->t, a->st, a->ov));
+    } else {
+      // Replicas: only the tokens this replica's workers read go to its GPU (the reference's threads share one file and
+      // read file_size / num_threads bytes each, ref :377,414).  A worker starts at its shard start and stops after the
+      // sentence in which its word count passes train_words / num_threads -- which may lie beyond the next shard's
+      // start -- so the slice ends where the last of them can stop: quota + 1 tokens, then on to the next "</s>", at
+      // most 64000 tokens further (a sentence is 1000 KEPT tokens; sub-sampling may drop many in between).  Should
+      // that ever be too short the library reports it (w2b_set_corpus_slice) instead of ending the shard early.
+      const int32_t *tok = w2b_corpus_tokens(a->c);
+      const int64_t n = w2b_corpus_num_tokens(a->c);
+      const int64_t quota = a->tw / o.num_threads;
+      const int64_t *st = a->st + a->r->index * a->per_gpu;
+      int64_t lo = n, hi = 0;
+      for (int w = 0; w < a->per_gpu; w++) {
+        if (st[w] < lo) lo = st[w];
+        int64_t e = st[w] + quota + 2;
+        const int64_t cap = e + 64000;
+        while (e < n && e < cap && tok[e - 1] != 0) e++;
+        if (e > n) e = n;
+        if (e > hi) hi = e;
+      }
+      if (lo > hi) lo = hi;
+      std::vector<int64_t> rel(a->per_gpu);
+      for (int w = 0; w < a->per_gpu; w++) rel[w] = st[w] - lo;
+      CK(w2b_set_corpus_slice(a->r->t, tok + lo, hi - lo, hi < n));
+      CK(w2b_set_shards(a->r->t, rel.data(), a->ov + a->r->index * a->per_gpu));
+      if (o.debug_mode > 1) fprintf(stderr, "word2bits: replica %d holds tokens [%lld, %lld) of %lld\n", a->r->index,
+                                    (long long)lo, (long long)hi, (long long)n);
+    }
     if (o.gpus > 1) CK(w2b_comm_init(a->r->t, o.gpus, a->r->index, a->uid));
     return nullptr;
   };
@@ -247,10 +282,11 @@ int main(int argc, char **argv) {
     double last_loss = 0, epoch_loss = 0;
     bool finished = false;
     long long launches = 0;
-    // One replica: the host stays one launch behind the device (w2b_epoch_poll with lag 1 waits for the previous launch
-    // only, the next one is already queued; the launch after the last one finds every worker done and returns at once).
-    // Replicas: the exchange is a rendezvous of all GPUs anyway, the state is read right after each launch (lag 0).
-    const int lag = (o.gpus == 1) ? 1 : 0;
+    // The host stays one launch behind the device (w2b_epoch_poll with lag 1 waits for the previous launch only, the
+    // next one is already queued; the launch after the last one finds every worker done and returns at once).  With
+    // replicas the exchange runs on streams of its own next to the following launches (w2b_sync_replicas returns at
+    // once); the end of an epoch (w2b_epoch_status below) waits for it.
+    const int lag = 1;
     while (!finished) {
       for (auto &r : reps) CK(w2b_train_step(r.t, o.positions));
       finished = true;
@@ -272,7 +308,8 @@ int main(int argc, char **argv) {
       if (o.gpus > 1 && (finished || launches % (o.sync_every > 0 ? o.sync_every : 1) == 0)) {
         // replicas: periodic delta-sum all-reduce of [u||v] over RCCL (and always at the end of an epoch)
         std::vector<pthread_t> th(o.gpus);
-        auto sync = [](void *p) -> void * { CK(w2b_sync_replicas((w2b_trainer *)p, 0)); CK(w2b_synchronize((w2b_trainer *)p)); return nullptr; };
+        // (one host thread per replica: the collectives of one process's communicators must be issued concurrently)
+        auto sync = [](void *p) -> void * { CK(w2b_sync_replicas((w2b_trainer *)p, 0)); return nullptr; };
         for (int g = 0; g < o.gpus; g++) pthread_create(&th[g], nullptr, sync, reps[g].t);
         for (int g = 0; g < o.gpus; g++) pthread_join(th[g], nullptr);
       }

@@ -5,11 +5,14 @@ shared memory, so each rank trains a full replica on its own corpus shard and th
 summed as DELTAS:  W <- base + sum_r (W_r - base)  -- the closest analogue of all threads adding
 their updates into one shared table.
 
-Two interchangeable implementations of the exchange:
+Three drivers of the same exchange:
   * the library's own RCCL communicator (w2b_comm_init / w2b_sync_replicas) -- used by the CLI
-    and by bench.py on GPUs;
-  * `TorchReplicaSync` below, the same protocol on torch.distributed tensors -- it runs on CPU
-    tensors over gloo, which is how the N>1 logic is tested without GPUs.
+    and by bench.py on GPUs: asynchronous, chunked, overlapped with the training launches;
+  * `PhasedReplicaSync` below: the library's exchange kernels (w2b_exchange_begin / delta / apply / end)
+    with a torch.distributed collective for the sum -- RCCL when every rank has a GPU, gloo when several
+    ranks share one GPU (how the training effect of the exchange is tested on a one-GPU box);
+  * `TorchReplicaSync`: the protocol restated on plain torch tensors -- it runs on CPU tensors over gloo,
+    which is how the N>1 arithmetic is tested without any GPU.
 """
 import numpy as np
 
@@ -28,6 +31,26 @@ def token_shard_starts(n_tokens, total_workers, worker_offset, num_workers):
     total_workers equal shards (the token-stream analogue of file_size/num_threads*id, ref :377)."""
     ids = np.arange(worker_offset, worker_offset + num_workers, dtype=np.int64)
     return ids * (n_tokens // total_workers)
+
+
+def replica_token_slice(tokens, starts, quota, slack=64000):
+    """The part [lo, hi) of the token stream that the workers starting at `starts` (one replica's) read, and whether the
+    stream goes on behind it.  A worker stops after the sentence in which its word count passes `quota`
+    (train_words / total_threads, ref :414-423), which may lie beyond the next worker's start: quota + 2 tokens, then on
+    to the next "</s>" (id 0), at most `slack` tokens further.  Same rule as ./word2bits -gpus N (word2bits_main.cpp)."""
+    n = len(tokens)
+    lo, hi = n, 0
+    for s in starts:
+        s = int(s)
+        lo = min(lo, s)
+        e = s + int(quota) + 2
+        cap = min(n, e + slack)
+        if e < cap:                                   # first e' >= e with tokens[e' - 1] == 0, else cap
+            z = np.flatnonzero(np.asarray(tokens[e - 1:cap - 1]) == 0)
+            e = e + int(z[0]) if len(z) else cap
+        hi = max(hi, min(e, n))
+    lo = min(lo, hi)
+    return lo, hi, hi < n
 
 
 def exchange_unique_id(dist, rank, make_id):
@@ -64,6 +87,40 @@ class TorchReplicaSync:
         else:
             raise ValueError("unknown sync mode")
         return model
+
+
+class PhasedReplicaSync:
+    """The library's exchange (delta / apply kernels, base snapshot, progress counters) around a torch.distributed
+    all-reduce.  `trainer.exchange_init()` must have been called while the replicas were identical."""
+
+    def __init__(self, dist, trainer, mode=0):
+        self.dist, self.t, self.mode = dist, trainer, mode
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.on_device = dist.is_initialized() and dist.get_backend() == "nccl"
+
+    def sync(self):
+        import torch
+        n_chunks, words = self.t.exchange_begin()
+        scale = 1.0 if self.mode == 0 else 1.0 / self.world
+        for c in range(n_chunks):
+            ptr, n = self.t.exchange_delta(c)                 # complete on return
+            buf = self.t.device_tensor(ptr, n)
+            if self.world > 1:
+                if self.on_device:
+                    self.dist.all_reduce(buf)
+                    torch.cuda.synchronize(buf.device)
+                else:                                         # gloo: through host memory
+                    host = buf.cpu()
+                    self.dist.all_reduce(host)
+                    buf.copy_(host)
+                    torch.cuda.synchronize(buf.device)
+            self.t.exchange_apply(c, scale)
+        total = torch.tensor([words], dtype=torch.int64)
+        if self.world > 1:
+            if self.on_device:
+                total = total.to(buf.device)
+            self.dist.all_reduce(total)
+        self.t.exchange_end(int(total.item()))
 
 
 def global_progress_alpha(starting_alpha, words_done_all_ranks, iters, train_words):

@@ -182,6 +182,11 @@ class Trainer:
         ids = np.ascontiguousarray(ids, np.int32)
         check(lib().w2b_set_corpus(self._h, _i32(ids), len(ids)))
 
+    def set_corpus_slice(self, ids, more_follows):
+        """the part of the token stream this replica's workers read (shard starts are relative to it)"""
+        ids = np.ascontiguousarray(ids, np.int32)
+        check(lib().w2b_set_corpus_slice(self._h, _i32(ids), len(ids), int(bool(more_follows))))
+
     def set_corpus_device(self, dev_ptr, n_tokens):
         check(lib().w2b_set_corpus_device(self._h, _lib.vp(dev_ptr), int(n_tokens)))
 
@@ -270,6 +275,37 @@ class Trainer:
         n, ms = C.c_int64(0), C.c_double(0)
         check(lib().w2b_sync_stats(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    # ---- the exchange in phases, for a host-supplied collective (include/word2bits_hip.h)
+    def exchange_init(self):
+        """call while all replicas hold the same model"""
+        check(lib().w2b_exchange_init(self._h))
+
+    def exchange_begin(self):
+        """-> (number of chunks, this replica's word_count_actual)"""
+        n, w = C.c_int64(0), C.c_int64(0)
+        check(lib().w2b_exchange_begin(self._h, C.byref(n), C.byref(w)))
+        return n.value, w.value
+
+    def exchange_delta(self, chunk):
+        """-> (device pointer, floats) of this replica's delta of the chunk; sum it over the replicas in place"""
+        p, n = _lib.vp(), C.c_int64(0)
+        check(lib().w2b_exchange_delta(self._h, int(chunk), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def exchange_apply(self, chunk, scale=1.0):
+        check(lib().w2b_exchange_apply(self._h, int(chunk), float(scale)))
+
+    def exchange_end(self, word_count_all_replicas=-1):
+        check(lib().w2b_exchange_end(self._h, int(word_count_all_replicas)))
+
+    def device_tensor(self, ptr, n):
+        """torch view (no copy) of n floats of library-owned device memory"""
+        import torch
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_View(), device=torch.device("cuda", self.cfg.device))
 
     def close(self):
         if self._h:
