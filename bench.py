@@ -61,7 +61,8 @@ def parse():
     ap.add_argument("--zipf-shift", type=int, default=0,
                     help="experiment: Zipf weights 1/(rank + N) instead of 1/rank (a Zipf stream without its N hottest words)")
     ap.add_argument("--sync-every", type=int, default=16)
-    ap.add_argument("--sync-mode", type=int, default=0)
+    ap.add_argument("--sync-mode", type=int, default=2,
+                    help="0 delta-sum, 1 average, 2 contributor average (what ./word2bits -gpus N uses)")
     ap.add_argument("--sync-impl", choices=["lib", "torch"], default="lib",
                     help="replica exchange: lib = the library's own RCCL communicator (w2b_comm_init / "
                          "w2b_sync_replicas: what the CLI uses; falls back to torch if its initialisation fails on any "
@@ -76,6 +77,10 @@ def parse():
                     help="N=1, worker form only: after the headline, time the same steps (a) with the loss bookkeeping "
                          "on (the instantiation ./word2bits runs: it prints 'Epoch Loss') and (b) at bitlevel 2, and "
                          "report both as extra objects")
+    ap.add_argument("--also-shapes", type=int, default=1,
+                    help="N=1, default workload only: after the headline, run the other measured shapes (form (ii) tuples, "
+                         "BASELINE configs[4] shape at bitlevel 1 and 0, configs[0] / configs[2] row lengths) as short "
+                         "sub-runs of this script and report each with its own value, roofline fraction and kernel")
     ap.add_argument("--loss", type=int, default=0, help="1: headline run with the loss bookkeeping on")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--window-cache", type=int, default=-1,
@@ -89,6 +94,8 @@ def parse():
     ap.add_argument("--hot-cap", type=int, default=-1, help="w2b_tuning.hot_cap (-1 = library default)")
     ap.add_argument("--atomic-rank", type=int, default=-2, help="w2b_tuning.atomic_rank (-2 = library default, -1 = automatic)")
     ap.add_argument("--atomic-cap", type=int, default=-1, help="w2b_tuning.atomic_cap (-1 = library default)")
+    ap.add_argument("--hot-weight", type=int, default=0, help="w2b_tuning.hot_weight_permille (0 = library default)")
+    ap.add_argument("--window-refresh", type=int, default=-1, help="w2b_tuning.window_refresh (-1 = library default)")
     ap.add_argument("--eval-questions", type=int, default=19544, help="--form eval: questions (questions-words.txt)")
     ap.add_argument("--eval-kind", choices=["1bit", "fp"], default="1bit")
     ap.add_argument("--eval-cpu-questions", type=int, default=24)
@@ -304,6 +311,33 @@ def run_eval_form(args):
     print(json.dumps(result), flush=True)
 
 
+def other_shapes():
+    """the other shapes DESIGN.md section 6 quotes, each as a short sub-run of this script (fresh process, same code path),
+    so that the driver's line carries them: value, roofline fraction (algorithmic bytes of THAT shape), kernel, workload"""
+    legs = {
+        "tuples": ["--form", "tuples"],
+        "cfg5_b1": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "1"],
+        "cfg5_b0": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "0"],
+        "d200": ["--vocab", "60238", "--dim", "200"],
+        "d400_b2": ["--vocab", "60238", "--dim", "400", "--bitlevel", "2"],
+    }
+    out = {}
+    for name, extra in legs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--tokens", "30000000", "--steps", "10", "--warmup", "3",
+               "--cpu-baseline", "none", "--also-relaxed", "0", "--also-legs", "0", "--also-shapes", "0"] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(line[-1])
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                         "roofline_frac": d["roofline"]["frac"], "achieved_GBps": d["roofline"]["achieved"],
+                         "kernel": d["roofline"]["kernel"], "avg_launch_ms": d["roofline"]["avg_launch_ms"],
+                         "workload": d["config"]["workload"], "worker_kernel": d["config"].get("worker_kernel")}
+        except Exception as e:                  # a leg must never take the headline down
+            out[name] = {"value": None, "error": repr(e)[:200]}
+    return out
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
@@ -373,6 +407,10 @@ def main():
         tune["atomic_rank"] = args.atomic_rank
     if args.atomic_cap >= 0:
         tune["atomic_cap"] = args.atomic_cap
+    if args.hot_weight > 0:
+        tune["hot_weight_permille"] = args.hot_weight
+    if args.window_refresh >= 0:
+        tune["window_refresh"] = args.window_refresh
 
     def make_trainer(relaxed, loss=bool(args.loss), bitlevel=args.bitlevel):
         tr = w2b.Trainer(V, D, W, K, bitlevel, num_threads=nw_local,
@@ -545,7 +583,7 @@ def main():
                    "bitlevel": args.bitlevel, "words_per_step_per_gpu": words_per_step, "ids": args.ids,
                    "row_coherence": "relaxed (plain cached accesses)" if args.relaxed else
                                     "agent scope (sc1): Hogwild coherent across the 8 XCD L2s",
-                   "replica_sync": ("%s every %d steps, mode %d (0 = delta-sum)" %
+                   "replica_sync": ("%s every %d steps, mode %d (0 delta-sum, 1 average, 2 contributor average)" %
                                     (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl,
                    "exchanges_in_timed_region": n_syncs[0],
                    "worker_kernel": (dict(zip(("sentence_resident", "radius", "column_bytes", "workers_per_cu",
@@ -579,7 +617,7 @@ def main():
             pass
     if world > 1:
         result["replica_exchange"] = {
-            "every_steps": args.sync_every, "mode": "delta-sum" if args.sync_mode == 0 else "average",
+            "every_steps": args.sync_every, "mode": ["delta-sum", "average", "contributor average"][args.sync_mode],
             "implementation": sync_impl, "exchanges": n_syncs[0],
             "bytes": 8 * V * D, "bytes_all_reduced_per_exchange": 8 * V * D,
             "device_ms": (sync_ms / sync_n) if sync_n else None,
@@ -643,6 +681,9 @@ def main():
             "roofline_frac": words_per_step * bpw / ((rms / 1e3) / max(1, rl)) / HBM_PEAK,
             "note": "plain cached row accesses: hot rows are private per XCD L2 within a launch (not the default)"}
         t2.close()
+    if (world == 1 and args.also_shapes and workload_name(args) == "BASELINE configs[1]" and args.form == "worker"
+            and not args.relaxed and not args.loss and not tune):
+        result["other_shapes"] = other_shapes()
     if rank == 0:
         cb = None
         if world == 1 and args.cpu_baseline != "none":

@@ -28,7 +28,7 @@ extern "C" {
 #define W2B_ENOGPU       -2   /* no usable HIP device */
 #define W2B_EHIP         -3   /* HIP runtime error (see w2b_last_error) */
 #define W2B_ENOMEM       -4
-#define W2B_EUNSUPPORTED -5   /* e.g. -size not a multiple of 4 and > 1024 */
+#define W2B_EUNSUPPORTED -5
 #define W2B_ERCCL        -6
 #define W2B_ESTATE       -7   /* call order (e.g. train before the corpus was set) */
 #define W2B_EIO          -8
@@ -111,8 +111,8 @@ void w2b_trainer_destroy(w2b_trainer *t);
  *
  * Hot rows: with coherent rows the few most frequent rows of u (context words) and v (targets) queue at their memory
  * lines.  Rows 1..hot_rows_u / 1..hot_rows_v (the vocabulary is sorted by count) therefore get one copy per XCD, shared
- * by all workers of the XCD through its L2, and every hot_period centre words a worker brings a few copies up to date
- * with their master rows.  -1 = automatic: as many rows as reach a load threshold computed from
+ * by all workers of the XCD through its L2, and every hot_period centre words a worker brings a few copies and their
+ * master rows together (a running average over the eight XCDs).  -1 = automatic: as many rows as reach a load threshold computed from
  * the word counts of w2b_set_vocab_counts and the number of workers (0 on flat distributions and for few workers), at
  * most hot_cap.  0 = every access goes to the master rows.  A single worker is bit-identical with and without copies. */
 typedef struct w2b_tuning {
@@ -126,11 +126,16 @@ typedef struct w2b_tuning {
   int32_t mem_mode;        /* -1 = from w2b_config.relaxed_coherence (default); 0 / 1 override it */
   /* Rows 1..atomic_rank (by count; beyond the hot rows) are updated with fp32 atomic adds at their own address instead of
    * load / modify / store: nothing another worker adds during the ~10 us a chunk of rows is in flight is lost, at the
-   * price of more memory time per update.  -1 = automatic: the rows whose expected number of concurrent updates reaches
-   * a threshold (computed from the word counts and the number of workers), at most atomic_cap of them. */
+   * price of more memory time per update.  -1 = automatic: every row when the vocabulary is so small and flat that even
+   * its least frequent row is hit by several workers at once (computed from the word counts and the number of
+   * workers), none otherwise; atomic_cap > 0 limits the number of rows. */
   int32_t atomic_rank;
   int32_t atomic_cap;
-  int32_t reserved[6];
+  int32_t hot_weight_permille;   /* weight of one XCD's copy of a hot row when it meets the master row; default 125 (1/8) */
+  /* sentence-resident kernel: the most frequent context words (the rows that would be hot rows of u) are merged with
+   * memory at the latest after this many steps in a worker's window, and stay resident; 0 = only when they leave */
+  int32_t window_refresh;
+  int32_t reserved[4];
 } w2b_tuning;
 int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out);
 int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in);
@@ -228,7 +233,11 @@ int w2b_comm_unique_id(void *out128);                      /* rank 0 creates, ot
  * creates no communicator (w2b_sync_replicas is then a no-op); with an id a communicator of size 1 is created and the
  * whole exchange path runs (a way to exercise it on a one-GPU machine; the model stays bit-identical). */
 int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id128);
-/* mode 0: delta-sum;  mode 1: average of the deltas.  Asynchronous (see above). */
+/* mode 0: delta-sum (a = 1);  mode 1: average of the deltas (a = 1/R);  mode 2: contributor average -- a row's summed
+ * delta is divided by the number of replicas that changed the row since the last exchange, so a row only one replica
+ * trained keeps its full update and a row all of them trained moves by their mean (what ./word2bits -gpus N uses: with
+ * mode 0 the R stale updates every replica makes to the frequent rows add up, with mode 1 rare rows learn R times too
+ * slowly; measured in tests/test_gpu_exchange.py).  Asynchronous (see above). */
 int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
 /* exchanges since the last call and their summed device time (begin of the first chunk -> end of the last; waits for
  * the exchanges in flight); resets both */
@@ -237,6 +246,8 @@ int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
 /* The same exchange for hosts that bring their own collective (MPI, torch.distributed over gloo or RCCL, ...):
  *   w2b_exchange_init once, while all replicas hold the same model; then per exchange
  *   w2b_exchange_begin(&n_chunks, &my_words)
+ *   (contributor average only) w2b_exchange_counts(&cnt, &m): cnt[0..m) = 1 for every row of [u||v] this replica changed;
+ *                            the host sums cnt over the replicas in place; w2b_exchange_apply then divides by it
  *   for c in [0, n_chunks): w2b_exchange_delta(c, &buf, &n)   -- buf[0..n) = this replica's delta (device memory, complete
  *                            on return);  the host sums buf over all replicas IN PLACE with its collective;
  *                           w2b_exchange_apply(c, a)          -- expects the sum to be complete
@@ -244,6 +255,7 @@ int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
  * Chunks c and c + 1 use different staging buffers and streams, so a host may pipeline them. */
 int w2b_exchange_init(w2b_trainer *t);
 int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count /* or NULL */);
+int w2b_exchange_counts(w2b_trainer *t, void **buf_dev, int64_t *elems);
 int w2b_exchange_delta(w2b_trainer *t, int64_t chunk, void **buf_dev, int64_t *elems);
 int w2b_exchange_apply(w2b_trainer *t, int64_t chunk, float scale);
 int w2b_exchange_end(w2b_trainer *t, int64_t word_count_all_replicas);

@@ -27,6 +27,8 @@ def same_bits(a, b):
     (800, 8, 24, 1, 0.0), (200, 8, 24, 1, 0.0), (400, 8, 24, 2, 0.0), (1000, 5, 12, 0, 0.0), (100, 5, 5, 4, 0.001),
     (64, 3, 7, 8, 0.0), (50, 4, 3, 1, 0.0), (1200, 2, 3, 2, 0.0), (36, 40, 70, 1, 0.0), (8, 1, 0, 0, 0.0),
     (257, 3, 5, 0, 0.0), (1, 3, 2, 2, 0.0),
+    # rows longer than a workgroup has columns (process_word_wide; the reference has no limit on -size, ref :598)
+    (5000, 3, 5, 1, 0.0), (1030, 4, 6, 2, 0.001), (4100, 2, 3, 0, 0.0),
 ])
 def test_tuple_updates_bit_exact(gpu, D, window, negative, bitlevel, reg):
     n = 24
@@ -51,12 +53,13 @@ def test_tuple_updates_bit_exact(gpu, D, window, negative, bitlevel, reg):
 @pytest.mark.parametrize("bitlevel,sample,D,window,negative,iters", [
     (1, 1e-3, 200, 8, 24, 2), (0, 1e-3, 200, 8, 24, 1), (2, 0.0, 100, 3, 7, 2), (1, 1e-3, 32, 1, 0, 3),
     (4, 1e-3, 50, 5, 5, 2), (1, 0.0, 800, 8, 24, 1),
+    (1, 1e-3, 5000, 3, 4, 1), (2, 0.0, 1030, 2, 3, 1),           # wide rows (process_word_wide)
 ])
 def test_single_worker_epochs_bit_exact(gpu, bitlevel, sample, D, window, negative, iters):
     """60 000 tokens over 150 words: every row is revisited hundreds of times, quantized training is chaotic (two
     builds of the reference drift apart by percents here), so bit equality after whole epochs means every single
     update was bit-exact."""
-    V, n = 150, 60000
+    V, n = 150, (60000 if D <= 1024 else 6000)
     rng = np.random.default_rng(9)
     ids = token_stream(rng, V, n)
     cn, tw, o = setup(V, ids, D, window, negative, bitlevel, sample, iters)

@@ -59,7 +59,7 @@ def test_size_one_communicator_runs_the_whole_exchange_and_changes_nothing(gpu):
                 if k == 5:
                     t.synchronize()
                     before = flat(t)
-                t.sync_replicas(k % 2)                       # both modes
+                t.sync_replicas((k // 3) % 3)                # all three modes
                 if before is not None:
                     assert np.array_equal(before.view(np.uint32), flat(t).view(np.uint32))
         fin, wca, alpha, loss = t.epoch_status()
@@ -77,7 +77,13 @@ def local_exchange(ts, mode=0):
     import torch
     begun = [t.exchange_begin() for t in ts]
     n_chunks = begun[0][0]
-    scale = 1.0 if mode == 0 else 1.0 / len(ts)
+    scale = 1.0 / len(ts) if mode == 1 else 1.0
+    if mode == 2:                                     # contributor average: how many replicas changed each row
+        cnts = [t.device_tensor(*t.exchange_counts()) for t in ts]
+        total = torch.stack(cnts).sum(0)
+        for b in cnts:
+            b.copy_(total)
+        torch.cuda.synchronize()
     for c in range(n_chunks):
         bufs = [t.device_tensor(*t.exchange_delta(c)) for t in ts]
         total = torch.stack(bufs).sum(0)
@@ -92,10 +98,10 @@ def local_exchange(ts, mode=0):
     return words
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_phase_api_arithmetic_two_replicas(gpu, mode):
-    """W_r += a * sum - d_r on top of the CURRENT rows, base += a * sum: against host arithmetic on copies of both
-    replicas, with training launches issued between the delta and the read-back (they must survive the exchange)."""
+    """W_r += a * sum - d_r on top of the CURRENT rows, base += a * sum (a = 1, 1/R, or per row 1 / number of replicas
+    that changed the row): against host arithmetic on copies of both replicas."""
     R, nw = 2, 4
     ts = [small_setup(nw, R * nw, r * nw, seed=3) for r in range(R)]
     for t in ts:
@@ -103,14 +109,19 @@ def test_phase_api_arithmetic_two_replicas(gpu, mode):
         t.epoch_begin()
     base = flat(ts[0])
     assert np.array_equal(base, flat(ts[1]))
-    a = 1.0 if mode == 0 else 1.0 / R
+    V2, D = 2 * 3000, 64
     for rnd in range(3):
         for t in ts:
             for _ in range(3):
                 t.train_step(150)
         mine = [flat(t) for t in ts]
         d = [m - base for m in mine]
-        total = np.float32(a) * (d[0] + d[1])
+        if mode == 2:
+            c = sum((x.reshape(V2, D) != 0).any(1).astype(np.float32) for x in d)
+            a = (np.float32(1) / np.maximum(c, 1))[:, None].repeat(D, 1).ravel()
+        else:
+            a = np.float32(1.0 if mode == 0 else 1.0 / R)
+        total = a * (d[0] + d[1])
         words = local_exchange(ts, mode)
         got = [flat(t) for t in ts]
         for r in range(R):
@@ -119,8 +130,7 @@ def test_phase_api_arithmetic_two_replicas(gpu, mode):
             assert np.abs(got[r] - mine[r]).max() > 0            # the other replica's work arrived
         base = base + total
         assert words == sum(t.epoch_status(want_loss=False)[1] for t in ts)
-    if mode == 0:
-        assert np.abs(got[0] - got[1]).max() <= 4e-6             # delta-sum: the replicas agree after every exchange
+    assert np.abs(got[0] - got[1]).max() <= 4e-6                 # the replicas agree after every exchange
     for t in ts:
         t.close()
 
@@ -134,7 +144,7 @@ def test_exchange_needs_init(gpu):
 
 
 # ---------------------------------------------------------------------------------------------- training effect
-def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=True):
+def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=True, mode=2):
     """one epoch over `corpus` with R replicas of workers_total / R workers each, exchanged every sync_every launches
     and at the end; returns the summed epoch loss"""
     per = workers_total // R
@@ -167,7 +177,7 @@ def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=
         launches += 1
         done = all(t.epoch_poll(0)[0] for t in ts)
         if R > 1 and (done or launches % sync_every == 0):
-            local_exchange(ts, 0)
+            local_exchange(ts, mode)
         if done:
             break
     loss = sum(t.epoch_status()[3] for t in ts)
@@ -183,10 +193,11 @@ def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=
 def test_training_effect_of_the_exchange_text8_size(gpu, tmp_path_factory):
     """17 M tokens, 70 K words, bitlevel 1, size 200, window 8, negative 24, one epoch.  The number of workers is what
     `./word2bits -threads 0` picks for the file; it is split over 1, 2 and 4 replicas, which exchange every 1 / 8 / 32
-    launches (and at the end).  A replica sees the other replicas' updates of a row only at an exchange, and delta-sum
-    adds all replicas' updates of a hot row up, so a lazy exchange trains the hot rows with an R times larger effective
-    step between two exchanges: asserted is that the epoch loss stays within EXCHANGE_RTOL of the single replica's, and
-    within the band of the reference's own runs (tests/golden/fidelity_bands.json) widened by the same amount."""
+    launches (and at the end) with the contributor-average rule (mode 2: what ./word2bits -gpus N uses).  Asserted: the
+    epoch loss stays within EXCHANGE_RTOL of the single replica's.  Printed next to it for the most frequent exchange:
+    plain delta-sum (mode 0), which adds the R stale updates that every replica makes to a frequent row (measured in
+    round 3: -5 % with 2 replicas, divergence with 4), and the plain average (mode 1), under which rows that only one
+    replica saw learn R times too slowly."""
     from w2b_testlib import write_zipf_text_corpus
     d = tmp_path_factory.mktemp("xchg")
     path = write_zipf_text_corpus(str(d / "c.txt"))
@@ -202,12 +213,14 @@ def test_training_effect_of_the_exchange_text8_size(gpu, tmp_path_factory):
     res = {}
     for R in (2, 4):
         for every in (1, 8, 32):
-            loss, _ = run_replicas(corpus, R, workers, every, positions, flags)
-            res[(R, every)] = loss
-            print("EXCHANGE text8size replicas=%d sync-every=%d: loss %.0f (%+.2f %% vs 1 replica)" %
-                  (R, every, loss, 100 * (loss - one) / abs(one)))
-    for (R, every), loss in res.items():
-        assert abs(loss - one) <= EXCHANGE_RTOL[every] * abs(one), (R, every, loss, one)
+            for mode in ((2, 0, 1) if every == 1 else (2,)):
+                loss, _ = run_replicas(corpus, R, workers, every, positions, flags, mode=mode)
+                res[(R, every, mode)] = loss
+                print("EXCHANGE text8size replicas=%d sync-every=%d mode=%d: loss %.0f (%+.2f %% vs 1 replica)" %
+                      (R, every, mode, loss, 100 * (loss - one) / abs(one)))
+    for (R, every, mode), loss in res.items():
+        if mode == 2:           # (modes 0 and 1 are printed for the record: DESIGN.md section 3.5 quotes them)
+            assert abs(loss - one) <= EXCHANGE_RTOL[every] * abs(one), (R, every, loss, one)
     corpus.close()
 
 

@@ -39,7 +39,7 @@ class Tuning(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("hot_rows_v", C.c_int32), ("hot_rows_u", C.c_int32), ("hot_period", C.c_int32),
         ("hot_cap", C.c_int32), ("force_row_desc", C.c_int32), ("grid_per_cu", C.c_int32), ("mem_mode", C.c_int32),
-        ("atomic_rank", C.c_int32), ("atomic_cap", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("atomic_rank", C.c_int32), ("atomic_cap", C.c_int32), ("hot_weight_permille", C.c_int32), ("window_refresh", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -88,6 +88,7 @@ SIGNATURES = {
     "w2b_sync_stats": (C.c_int, [vp, i64p, f64p]),
     "w2b_exchange_init": (C.c_int, [vp]),
     "w2b_exchange_begin": (C.c_int, [vp, i64p, i64p]),
+    "w2b_exchange_counts": (C.c_int, [vp, C.POINTER(vp), i64p]),
     "w2b_exchange_delta": (C.c_int, [vp, C.c_int64, C.POINTER(vp), i64p]),
     "w2b_exchange_apply": (C.c_int, [vp, C.c_int64, C.c_float]),
     "w2b_exchange_end": (C.c_int, [vp, C.c_int64]),

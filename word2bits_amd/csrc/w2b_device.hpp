@@ -309,26 +309,26 @@ __device__ __forceinline__ void add_col(float *tab, long long row, int dim, int 
 // u (context words) and v (targets) queue there: a 3200-byte row sustains ~7 M read-modify-writes per second, against
 // e.g. 0.32 target uses of row 1 per centre word on Zipf(1) ids at 25 M words/s.  Every XCD therefore works on ITS OWN
 // COPY of rows 1..nu of u and 1..nv of v (the vocabulary is sorted by count; the numbers come from the word counts and
-// the number of workers): an eighth of the traffic per address.  What makes shared copies safe at this concurrency --
-// dozens of workers have the same hot row in flight at any moment, so a load / modify / store would overwrite most of
-// what the others add (and an adopted value with it: the first version of this scheme, plain stores, turned lost
-// adoptions into negative deltas and un-trained the hot rows) -- is that NOTHING is ever stored into a copy:
-//   * a worker's update of a hot row is an atomic add of its delta to the XCD's copy (add_col);
-//   * a MERGE brings one copy and the master row together.  One wavefront at a time per 1 KiB segment of a copy
-//     (try-lock; a wavefront that finds it taken skips its turn).  With c = copy, e = the copy's value at its last
-//     merge ("entry"), per element:
-//        publish   m = CAS(master, e, c): where the master still holds e nobody else has published, and the exact
-//                  value c goes in -- a single worker stays bit-identical to a run without copies; where it does not,
-//                  the master gets an atomic add of c - e instead;
-//        adopt     what the others have published since the last merge, o = m - e, is atomically added to the copy;
-//        entry  <- c + o (so copy - entry is exactly what this XCD has added since).
-//     No update is lost or counted twice, whatever the interleaving.  Workers take turns: every hot_period centre words a
-//     worker merges xhot_m rows, rotating through the set.
-//   * k_xhot_fold (w2b_kernels_misc.hip) does the same for all eight copies before and after every launch (alone on
-//     the device, so with plain loads and stores): between launches the master rows are complete and copy == entry ==
-//     master.
-// Copies are read with `nt` loads (past the CU's L1; served by the XCD's L2 when the line is there -- an atomic drops
-// it).  16-byte columns only (VEC == 4).
+// the number of workers), accessed with `nt` loads and stores: past the CU's L1, served by and kept in the XCD's L2
+// (MI355X_MICROARCH.md, inter-workgroup visibility; tools/coherence_probe2.hip: all workgroups of an XCD see each
+// other's read-modify-writes).  Inside an XCD a hot row is the reference's racy shared row (ref :490,501), at L2 speed.
+// Across XCDs the copies are kept together by CONSENSUS merges.  One wavefront at a time per 1 KiB segment of a copy
+// (try-lock; a wavefront that finds it taken skips its turn) loads the copy c, the value e it left there at its last
+// merge and the master row m, and stores
+//      n = c                  if m == e  (nobody else has published since: this XCD's copy IS the consensus -- a single
+//                                         worker stays bit-identical to a run without copies)
+//          m                  if c == e  (nothing of ours: adopt)
+//          m + w * (c - m)    otherwise  (w = 1/8 by default: eight XCDs pulling with weight 1/8 each make the master
+//                                         the running average of the copies)
+// to master, copy and entry.  Deliberately NOT a sum of deltas: dozens of workers have a hot row in flight at any
+// moment, all with gradients of the same stale value; adding all of them up over-shoots (measured: lossless atomic
+// adds and delta sums moved the first-epoch loss of the text8-sized run by 7 % and made a 4-replica exchange diverge),
+// whereas the reference applies its updates one after the other.  And deliberately free of delta bookkeeping: a worker's
+// store that lands after an adoption undoes the adoption for that copy; with "copy - entry = our contribution" that
+// became a negative contribution (first version of this scheme); with averaging it only delays the consensus.
+// Workers take turns: every hot_period centre words a worker merges xhot_m rows, rotating through the set.
+// k_xhot_fold (w2b_kernels_misc.hip) applies the same rule for all eight copies before and after every launch, so
+// between launches the master rows are complete and copy == entry == master.  16-byte columns only (VEC == 4).
 #define W2B_MM_XCD 5          // Aux<>: nt loads + nt stores (XCD scope)
 struct XHot {
   float *cu, *cv, *eu, *ev;    // this XCD's copies of the hot rows of u / v, and their entry values
@@ -354,45 +354,53 @@ __device__ __forceinline__ XHot xhot_here(const W2bParams &P) {
 __device__ __forceinline__ Col<4> xhot_ld(const float *rows, int k, int n, int dim, int col0) {
   return load_col<4, W2B_MM_XCD, 0>(rows, k, dim, col0, (unsigned)(n * dim * 4));
 }
-__device__ __forceinline__ void xhot_add(float *rows, int k, int n, int dim, int col0, const Col<4> &d) {
-  add_col<4, 0>(rows, k, dim, col0, d, (unsigned)(n * dim * 4));
+__device__ __forceinline__ void xhot_st(float *rows, int k, int n, int dim, int col0, const Col<4> &c) {
+  store_col<4, W2B_MM_XCD, 0>(rows, k, dim, col0, c, (unsigned)(n * dim * 4));
 }
 // hot row k (master row k + 1 of `tab`) of this XCD meets memory: this wavefront's segment of the row.
+// MM / TB: how the master rows are accessed; w: weight of this XCD's copy in the consensus.
+template <int MM, int TB>
 __device__ __forceinline__ void xhot_merge_row(float *tab, float *copy, float *entry, unsigned *locks, int k, int n, int dim,
-                                               int col0, bool active, int wave, int lane) {
+                                               int col0, bool active, int wave, int lane, unsigned tab_bytes, float w) {
   unsigned *lock = locks + k * W2B_MAXW + wave;
   unsigned got = 1u;
   if (lane == 0) got = __hip_atomic_exchange(lock, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (__builtin_amdgcn_readfirstlane((int)got) != 0) return;       // somebody is merging this segment right now
-  if (active) {
-    const Col<4> c = xhot_ld(copy, k, n, dim, col0);
-    const Col<4> e = load_col<4, 0, 0>(entry, k, dim, col0, (unsigned)(n * dim * 4));
-    float *mrow = tab + (long long)(k + 1) * dim + col0;
-    Col<4> en;
+  Col<4> c, e, m, o;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const unsigned eb = __float_as_uint(e.e[i]), cb = __float_as_uint(c.e[i]);
-      unsigned mb = eb;          // (value of the master; when nothing of ours is to be published a load would do as well)
-      __hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned *>(mrow + i), &mb, cb, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-      const float m = __uint_as_float(mb);
-      if (mb != eb && cb != eb) (void)__hip_atomic_fetch_add(mrow + i, c.e[i] - e.e[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float o = m - e.e[i];
-      en.e[i] = (mb == eb) ? c.e[i] : c.e[i] + o;
-      if (mb != eb) (void)__hip_atomic_fetch_add(copy + (long long)k * dim + col0 + i, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    store_col<4, 0, 0>(entry, k, dim, col0, en, (unsigned)(n * dim * 4));
+  for (int i = 0; i < 4; i++) { c.e[i] = 0.f; e.e[i] = 0.f; m.e[i] = 0.f; }
+  if (active) {
+    c = xhot_ld(copy, k, n, dim, col0);
+    e = xhot_ld(entry, k, n, dim, col0);
+    m = load_col<4, MM, TB>(tab, k + 1, dim, col0, tab_bytes);
+  }
+  bool own = false, oth = false;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    own = own || __float_as_uint(c.e[i]) != __float_as_uint(e.e[i]);
+    oth = oth || __float_as_uint(m.e[i]) != __float_as_uint(e.e[i]);
+  }
+  const bool any_own = __ballot(own) != 0ull, any_oth = __ballot(oth) != 0ull;      // per 1 KiB segment
+#pragma unroll
+  for (int i = 0; i < 4; i++) o.e[i] = !any_oth ? c.e[i] : (!any_own ? m.e[i] : m.e[i] + w * (c.e[i] - m.e[i]));
+  if (active) {
+    if (any_own) store_col<4, MM, TB>(tab, k + 1, dim, col0, o, tab_bytes);
+    if (any_oth) xhot_st(copy, k, n, dim, col0, o);
+    if (any_own || any_oth) xhot_st(entry, k, n, dim, col0, o);
   }
   __builtin_amdgcn_s_waitcnt(0);                                    // everything above has reached the memory system
   if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one merge event of a workgroup of the plain kernels: P.xhot_m rows of each table, rotating through the sets
+template <int MM>
 __device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot &X, int &cursor, int col0, bool active) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int j = 0; j < P.xhot_m; j++) {
     const int i = cursor + j;
-    if (X.nu > 0 && j < X.nu) xhot_merge_row(P.u, X.cu, X.eu, X.lu, i % X.nu, X.nu, P.dim, col0, active, wave, lane);
-    if (X.nv > 0 && j < X.nv) xhot_merge_row(P.v, X.cv, X.ev, X.lv, i % X.nv, X.nv, P.dim, col0, active, wave, lane);
+    if (X.nu > 0 && j < X.nu)
+      xhot_merge_row<MM, -1>(P.u, X.cu, X.eu, X.lu, i % X.nu, X.nu, P.dim, col0, active, wave, lane, P.tab_bytes, P.xhot_w);
+    if (X.nv > 0 && j < X.nv)
+      xhot_merge_row<MM, -1>(P.v, X.cv, X.ev, X.lv, i % X.nv, X.nv, P.dim, col0, active, wave, lane, P.tab_bytes, P.xhot_w);
   }
   cursor += P.xhot_m;
 }
@@ -402,8 +410,8 @@ __device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot 
 // cw >= 1, nt >= 1.
 // Ends with a __syncthreads() (lists may be overwritten afterwards).
 // X: this XCD's copies of the hottest rows (nu = nv = 0: none; VEC == 4 only): a row k <= nu of u / k <= nv of v is read
-// at its copy instead of its master address and updated there with atomic adds.  Passed by reference, so that its
-// fields stay in registers.  P.atomic_rank: rows 1..atomic_rank are updated with atomic adds at their master address.
+// and written at its copy instead of its master address.  Passed by reference, so that its fields stay in registers.
+// P.atomic_rank: the other rows among 1..atomic_rank are updated with atomic adds at their master address.
 template <int QM, int VEC, bool LOSS, int MM>
 __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &L, const QParam &qp,
                                              const int cw, const int nt, const float alpha,
@@ -429,10 +437,10 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) return xhot_ld(X.cu, row - 1, nhu, dim, col0); }
     return load_col<VEC, MM>(P.u, row, dim, col0, P.tab_bytes);
   };
-  // row <- val (= old + d): a store for ordinary rows, an atomic add of d for hot rows and in the atomic-rows mode
+  // row <- val (= old + d): a store (hot rows: to this XCD's copy), or an atomic add of d for rows 1..atomic_rank
   const int atomic_rank = P.atomic_rank;
   auto up_u = [&](int row, const Col<VEC> &val, const Col<VEC> &d) {
-    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) { xhot_add(X.cu, row - 1, nhu, dim, col0, d); return; } }
+    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) { xhot_st(X.cu, row - 1, nhu, dim, col0, val); return; } }
     if (row <= atomic_rank) add_col<VEC>(P.u, row, dim, col0, d, P.tab_bytes);
     else store_col<VEC, MM>(P.u, row, dim, col0, val, P.tab_bytes);
   };
@@ -441,7 +449,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     return load_col<VEC, MM>(P.v, row, dim, col0, P.tab_bytes);
   };
   auto up_v = [&](int row, const Col<VEC> &val, const Col<VEC> &d) {
-    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) { xhot_add(X.cv, row - 1, nhv, dim, col0, d); return; } }
+    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) { xhot_st(X.cv, row - 1, nhv, dim, col0, val); return; } }
     if (row <= atomic_rank) add_col<VEC>(P.v, row, dim, col0, d, P.tab_bytes);
     else store_col<VEC, MM>(P.v, row, dim, col0, val, P.tab_bytes);
   };
@@ -627,7 +635,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
         const int m = L.umult[j0 + jj];
         if (m > 0) {
           const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
-          const bool by_add = crow <= atomic_rank || (VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu);
+          const bool by_add = crow <= atomic_rank && !(VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu);
           Col<VEC> dl;
           for (int k = 0; k < m; k++) {      // a row that occurs m times in the window is updated m times
 #pragma unroll
@@ -648,6 +656,106 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
   __syncthreads();
 }
 
+
+// ------------------------------------------------------------------------------------ one centre word, wide rows
+// Rows too long for one thread per column (more than 1024 columns of 16 / 4 bytes: -size > 4096, or > 1024 when not a
+// multiple of 4; the reference has no limit, ref :598).  Same preconditions and semantics as process_word, organised for
+// generality, not speed: 1024 threads, thread t owns the columns t, t + 1024, ...; the window average and the
+// accumulated error live in a per-workgroup scratch row in global memory (P.wide_scratch), the targets are taken one
+// at a time (so duplicates are ordered by construction), every element is accessed on its own (4 bytes per lane).
+// The dot product is a tree over threads / wavefronts in the fast mode and the reference's serial chain (blocks of
+// W2B_EXACT_COLS products through LDS, continued by thread 0) in the parity mode.
+template <int QM, bool LOSS, int MM>
+__device__ __forceinline__ void process_word_wide(const W2bParams &P, const WordLds &L, const QParam &qp, const int cw,
+                                                  const int nt, const float alpha, double &loss_acc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6, nthr = blockDim.x;
+  const int dim = P.dim;
+  const float ar2 = (2.f * alpha) * P.reg;
+  float *avg = P.wide_scratch + (long long)blockIdx.x * 2 * dim, *errv = avg + dim;
+  auto ld = [&](float *tab, int row, int c) -> float { return load_col<1, MM>(tab, row, dim, c, P.tab_bytes).e[0]; };
+  auto st = [&](float *tab, int row, int c, float x) { Col<1> v; v.e[0] = x; store_col<1, MM>(tab, row, dim, c, v, P.tab_bytes); };
+  // ---- phase A (ref :431-449)
+  float regsq = 0.f;
+  for (int c = tid; c < dim; c += nthr) {
+    float s = 0.f;
+    for (int j = 0; j < cw; j++) {
+      const float q = quant<QM>(ld(P.u, L.ctx[j], c), qp);
+      s += q;
+      if (LOSS) regsq += q * q;
+    }
+    avg[c] = s / (float)cw;
+    errv[c] = 0.f;
+  }
+  if (LOSS && P.reg != 0.f) {
+    const float s = wave_sum(regsq);
+    if (lane == 0) loss_acc -= (double)(P.reg * s);
+  }
+  __syncthreads();
+  // ---- phase B (ref :450-492), one target at a time
+  for (int t = 0; t < nt; t++) {
+    const int row = L.tgt[t];
+    float f = 0.f;
+    if (MM == W2B_MM_EXACT) {
+      for (int b0 = 0; b0 < dim; b0 += W2B_EXACT_COLS) {
+        if (tid < W2B_EXACT_COLS && b0 + tid < dim) L.xprod[tid] = avg[b0 + tid] * quant<QM>(ld(P.v, row, b0 + tid), qp);
+        __syncthreads();
+        if (tid == 0) {
+          const int cnt = min(W2B_EXACT_COLS, dim - b0);
+          for (int c = 0; c < cnt; c++) f += L.xprod[c];
+        }
+        __syncthreads();
+      }
+      if (tid == 0) L.red[0] = f;
+    } else {
+      float p = 0.f;
+      for (int c = tid; c < dim; c += nthr) p += avg[c] * quant<QM>(ld(P.v, row, c), qp);
+      p = wave_sum(p);
+      if (lane == 0) L.red[wave] = p;
+      __syncthreads();
+      if (tid == 0) {
+        for (int w = 0; w < nwaves; w++) f += L.red[w];
+        L.red[0] = f;
+      }
+    }
+    __syncthreads();
+    f = L.red[0];
+    const float label = (t == 0) ? 1.f : 0.f;
+    float g;
+    if (f > 6.f) g = (label - 1.f) * alpha;
+    else if (f < -6.f) g = label * alpha;
+    else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
+    if (LOSS && tid == 0) {                                       // ref :480-483
+      const float dp = (label != 0.f) ? f : -f;
+      float sg;
+      if (dp > 6.f) sg = 1.f;
+      else if (dp < -6.f) sg = 1e-9f;
+      else sg = 1.f / (1.f + expf(-dp));
+      loss_acc += (double)logf(sg);
+    }
+    float s2 = 0.f;
+    for (int c = tid; c < dim; c += nthr) {
+      const float xv = ld(P.v, row, c), q = quant<QM>(xv, qp);
+      if (LOSS) s2 += q * q;
+      errv[c] += g * q;
+      st(P.v, row, c, xv + (g * avg[c] - ar2 * xv));
+    }
+    if (LOSS && P.reg != 0.f) {
+      s2 = wave_sum(s2);
+      if (lane == 0) loss_acc -= (double)(P.reg * s2);
+    }
+    __syncthreads();            // the next target may be the same row: its stores are complete (one workgroup, in order)
+  }
+  // ---- phase C (ref :494-503), window order; a row that occurs twice is updated twice
+  for (int c = tid; c < dim; c += nthr) {
+    const float e = errv[c];
+    for (int j = 0; j < cw; j++) {
+      const int row = L.ctx[j];
+      const float r = ld(P.u, row, c);
+      st(P.u, row, c, r + (e - ar2 * r));
+    }
+  }
+  __syncthreads();
+}
 
 // ------------------------------------------------------------------------------------ worker helpers
 // exact n % d for a run-time divisor: magic = floor(2^64 / d) precomputed on the host; the quotient
@@ -742,13 +850,14 @@ template <typename F>
 hipError_t dispatch_q(int bitlevel, F &&f) {
 #ifdef W2B_QUICK_BUILD      // developer builds: only the 1-bit instantiations (register / ISA studies)
   return f(std::integral_constant<int, 1>());
-#endif
+#else
   switch (bitlevel) {
     case 0: return f(std::integral_constant<int, 0>());
     case 1: return f(std::integral_constant<int, 1>());
     case 2: return f(std::integral_constant<int, 2>());
     default: return f(std::integral_constant<int, 3>());
   }
+#endif
 }
 
 

@@ -68,6 +68,11 @@ struct W2bParams {
   int xhot_u, xhot_v;
   int hot_period;                 // centre words between two merge events of a worker / workgroup (power of two)
   int xhot_m;                     // hot rows of each table that one merge event brings up to date
+  int uavg_rank;                  // sentence-resident kernel: context rows 1..uavg_rank are merged by consensus and refreshed
+  int win_refresh;                // ... at the latest after this many steps in a worker's window (0 = never)
+  float xhot_w;                   // weight of one XCD's copy in the consensus of a merge (1 / W2B_NXCD by default)
+  float *wide_scratch;            // rows too long for one thread per column: [workgroups][2][dim] (process_word_wide)
+  int wide;                       // 1: such rows (1024 threads, every thread owns several columns)
   int atomic_rank;                // rows 1..atomic_rank (by count) are updated with fp32 atomic adds: no lost updates (see w2b_tuning)
   int exact;                      // serial dot product in the reference's order (plain worker / tuple kernels)
   float starting_alpha, sample, reg;
@@ -75,7 +80,7 @@ struct W2bParams {
 
 // launchers implemented in w2b_kernels.hip --------------------------------------------------------
 // block size chosen from dim: one thread per 16-byte (or 4-byte) column of a row
-int w2b_block_threads(int dim, int *vec_out);
+int w2b_block_threads(int dim, int *vec_out, int *wide_out = nullptr);
 size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact = false);
 int w2b_tuple_max_grid(int num_cus);                                   // most workgroups w2b_launch_tuples starts
 hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *center,
@@ -85,6 +90,7 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
 hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s);
 // sentence-resident variant (w2b_kernels_resident.hip): radius >= 0 when it can run for this shape
 int w2b_resident_plan(int dim, int window, int negative);
+bool w2b_resident_atomic_ok(const W2bParams &p, int radius);           // atomic_rank > 0: can the sentence-resident kernel do it?
 long long w2b_resident_scratch_rows(int radius);                       // scratch rows per worker
 hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int radius, bool loss, hipStream_t s);
 int w2b_workers_per_cu(const W2bParams &p, bool loss);                  // resident workgroups per CU, plain kernel
@@ -112,4 +118,7 @@ hipError_t w2b_launch_wca_pack(const W2bShared *sh, unsigned long long *buf, hip
 hipError_t w2b_launch_wca_unpack(W2bShared *sh, const unsigned long long *buf, hipStream_t s); // from buf[1] = global sum
 // replica exchange, one chunk (w2b_kernels_misc.hip): d = s = w - base;  w += a * s - d, base += a * s
 hipError_t w2b_launch_xchg_delta(float *w, const float *base, float *d, float *s_, long long n, hipStream_t s);
-hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n, hipStream_t s);
+hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n,
+                                 const float *cnt /* per-row contributor counts or nullptr */, long long first, int dim,
+                                 hipStream_t s);
+hipError_t w2b_launch_xchg_touched(const float *w, const float *base, float *cnt, long long rows, int dim, hipStream_t s);

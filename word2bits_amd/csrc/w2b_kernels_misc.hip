@@ -68,19 +68,30 @@ __global__ void k_xchg_delta(float *w, const float *__restrict__ base, float *__
 // s now holds the sum over all replicas.  What the OTHER replicas added, a * s - d (a = 1: delta-sum, a = 1 / replicas:
 // average of the deltas), goes on top of the rows as they are NOW -- whatever this replica has trained since the delta
 // was taken stays -- and base becomes the common state base + a * s.  Elements nobody else touched are not written.
+// cnt (optional): per ROW of [u || v], how many replicas have changed the row since the last exchange; then a is divided
+// by it -- the sum of a row's deltas is shared among the replicas that contributed to it (a row only one replica touched
+// keeps that replica's full delta, a row all of them trained moves by their average).  first = index of w[0] in [u || v].
 __global__ void k_xchg_apply(float *w, float *__restrict__ base, const float *__restrict__ d, const float *__restrict__ s,
-                             float a, long long n) {
+                             float a, long long n, const float *__restrict__ cnt, long long first, int dim) {
   const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (int)(n * 4), 0x27000);
   w2b_f4 *b4 = reinterpret_cast<w2b_f4 *>(base);
   const w2b_f4 *d4 = reinterpret_cast<const w2b_f4 *>(d), *s4 = reinterpret_cast<const w2b_f4 *>(s);
+  auto scale = [&](long long i) -> float {          // i: float index inside this chunk
+    if (!cnt) return a;
+    const float c = cnt[(first + i) / dim];
+    return c > 1.f ? a / c : a;
+  };
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const w2b_f4 sum = s4[i] * a, others = sum - d4[i];
+    w2b_f4 sum = s4[i];
+    if (!cnt) sum = sum * a;
+    else { sum.x *= scale(4 * i); sum.y *= scale(4 * i + 1); sum.z *= scale(4 * i + 2); sum.w *= scale(4 * i + 3); }
+    const w2b_f4 others = sum - d4[i];
     b4[i] = b4[i] + sum;
     if (others.x != 0.f || others.y != 0.f || others.z != 0.f || others.w != 0.f) xchg_st_sc1(rw, i, xchg_ld_sc1(rw, i) + others);
   }
   for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float sum = s[i] * a, others = sum - d[i];
+    const float sum = s[i] * scale(i), others = sum - d[i];
     base[i] += sum;
     if (others != 0.f) {
       const float x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (int)(i * 4), 0, 16)) + others;
@@ -88,9 +99,23 @@ __global__ void k_xchg_apply(float *w, float *__restrict__ base, const float *__
     }
   }
 }
+// cnt[r] = 1 if row r of [u || v] differs from base (this replica has trained it since the last exchange), else 0.
+// One wavefront per row at a time.
+__global__ void k_xchg_touched(const float *w, const float *__restrict__ base, float *__restrict__ cnt, long long rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < rows; r += nw) {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(w + r * dim), 0, dim * 4, 0x27000);
+    bool diff = false;
+    for (int c = lane; c < dim; c += 64)
+      diff = diff || __builtin_amdgcn_raw_buffer_load_b32(rw, c * 4, 0, 16) != __float_as_uint(base[r * dim + c]);
+    const bool any = __ballot(diff) != 0ull;
+    if (lane == 0) cnt[r] = any ? 1.f : 0.f;
+  }
+}
 // ---- XCD-local copies of the hot rows (XHot in w2b_device.hpp): all eight copies of hot row k meet the master row k + 1,
-// with the merge rule of xhot_merge_row (exact value where the master still holds the copy's entry, else the copy's
-// delta on top), XCD after XCD; afterwards master == every copy == every entry.  One workgroup per hot
+// with the merge rule of xhot_merge_row (the copy itself where the master still holds the copy's entry, else a step of
+// weight xhot_w towards the copy), XCD after XCD; afterwards master == every copy == every entry.  One workgroup per hot
 // row (u rows first), 16 bytes per thread.  Runs before and after every training launch: idempotent, and a master that
 // was changed in between (w2b_set_model, a replica exchange) is simply adopted.
 __global__ void k_xhot_fold(const W2bParams P) {
@@ -113,7 +138,7 @@ __global__ void k_xhot_fold(const W2bParams P) {
       for (int i = 0; i < 4; i++) {
         const bool ce = __float_as_uint(cv[i]) == __float_as_uint(ev[i]);
         const bool me = __float_as_uint(m[i]) == __float_as_uint(ev[i]);
-        m[i] = me ? cv[i] : (ce ? m[i] : m[i] + (cv[i] - ev[i]));
+        m[i] = me ? cv[i] : (ce ? m[i] : m[i] + P.xhot_w * (cv[i] - m[i]));
       }
     }
     master[c] = m;
@@ -133,12 +158,19 @@ __global__ void k_wca_unpack(W2bShared *sh, const unsigned long long *buf) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------ launchers
-int w2b_block_threads(int dim, int *vec_out) {
-  const int vec = (dim % 4 == 0) ? 4 : 1;
+int w2b_block_threads(int dim, int *vec_out, int *wide_out) {
+  int vec = (dim % 4 == 0) ? 4 : 1;
   const int cols = dim / vec;
-  const int threads = ((cols + 63) / 64) * 64;
+  int threads = ((cols + 63) / 64) * 64;
+  int wide = 0;
+  if (threads > 1024) {       // more columns than a workgroup has threads: every thread owns several 4-byte columns
+    threads = 1024;
+    vec = 1;
+    wide = 1;
+  }
   if (vec_out) *vec_out = vec;
-  return threads;   // caller rejects > 1024
+  if (wide_out) *wide_out = wide;
+  return threads;
 }
 
 size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool exact) {
@@ -187,7 +219,12 @@ hipError_t w2b_launch_xchg_delta(float *w, const float *base, float *d, float *s
   hipLaunchKernelGGL(k_xchg_delta, dim3(1024), dim3(256), 0, s, w, base, d, s_, n);
   return hipGetLastError();
 }
-hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n, hipStream_t s) {
-  hipLaunchKernelGGL(k_xchg_apply, dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n);
+hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n,
+                                 const float *cnt, long long first, int dim, hipStream_t s) {
+  hipLaunchKernelGGL(k_xchg_apply, dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n, cnt, first, dim);
+  return hipGetLastError();
+}
+hipError_t w2b_launch_xchg_touched(const float *w, const float *base, float *cnt, long long rows, int dim, hipStream_t s) {
+  hipLaunchKernelGGL(k_xchg_touched, dim3(2048), dim3(256), 0, s, w, base, cnt, rows, dim);
   return hipGetLastError();
 }

@@ -114,7 +114,8 @@ struct Step2 {
   int nck;                // number of target chunks = number of workgroup barriers inside the data phase
   float alpha;
   int cdup;               // 1: a window slot occurs more than once in this step's context list (phase C must run in order)
-  int pad[2];
+  int refresh;            // 1: the (single) row of the retire list does not leave: it is merged with memory and stays resident
+  int pad[1];
 };
 
 
@@ -138,6 +139,7 @@ struct StepRec {          // what the producer wavefront hands to the data wavef
 struct WorkRec {
   Win2Lds S;
   int slot_row[W2B_SMAX], slot_ref[W2B_SMAX], pos_slot[W2B_SMAX], slot_gen[W2B_SMAX];
+  int slot_born[W2B_SMAX];       // step at which the slot's row was last read from / merged with memory
   int prev[W2B_TMAX];
   float red[2][W2B_RT][W2B_NDWMAX];
   unsigned csum[W2B_SMAX][W2B_NDWMAX];   // per-wavefront xor checksum of the row bits at entry
@@ -199,6 +201,7 @@ __device__ __forceinline__ void lds_st(W2B_LDS float *p, const Col4 &c) {
 template <int MM>
 struct Rows {
   static constexpr int M = MM & 7, TB = (MM >> 3) & 1;     // memory mode, table form (1 = per-row descriptors)
+  static constexpr bool ATOMIC = ((MM >> 4) & 1) != 0;     // rows 1..atomic_rank of v are updated with atomic adds
   const W2bParams &P;
   long long scratch0;      // first scratch row of this worker
   int nsh;                 // scratch rows per generation = window slots
@@ -212,8 +215,12 @@ struct Rows {
   __device__ __forceinline__ void st_u(int row, const Col4 &c) const { store_col<4, M, TB>(P.u, row, dim, col0, c, P.tab_bytes); }
   __device__ __forceinline__ void st_v(int row, const Col4 &c) const { store_col<4, M, TB>(P.v, row, dim, col0, c, P.tab_bytes); }
   __device__ __forceinline__ Col4 ld_hot(int k) const { return xhot_ld(hot_c, k, nh, dim, col0); }
-  __device__ __forceinline__ void add_hot(int k, const Col4 &d) const { xhot_add(hot_c, k, nh, dim, col0, d); }
-  __device__ __forceinline__ void add_v(int row, const Col4 &d) const { add_col<4, TB>(P.v, row, dim, col0, d, P.tab_bytes); }
+  __device__ __forceinline__ void st_hot(int k, const Col4 &c) const { xhot_st(hot_c, k, nh, dim, col0, c); }
+  __device__ __forceinline__ void add_v1(int row, int e, float d) const {         // v[row][col0 + e] += d, atomically
+    Col<1> c;
+    c.e[0] = d;
+    add_col<1, TB>(P.v, row, dim, col0 + e, c, P.tab_bytes);
+  }
   // scratch ("entry") rows: written with plain stores, read back (rarely) past the L1
   __device__ __forceinline__ Col4 ld_entry(int gen, int slot) const {
     return load_col<4, 0, 1>(P.entry, scratch0 + (long long)gen * nsh + slot, dim, col0, 0u);
@@ -223,21 +230,37 @@ struct Rows {
   }
 };
 
-// ---- write-back of one leaving row: exact value if nobody else changed the row, else merge our contribution
+// ---- write-back of one leaving row: exact value if nobody else changed the row, else merge our contribution.
+// A row is "ours alone" for the ordinary word: delta-sum, g + (value - entry), is then exactly what the reference's
+// shared row would hold.  The most frequent context words (rows 1..P.uavg_rank; chosen like the hot target rows) are
+// resident in EVERY worker's window most of the time; hundreds of workers adding their whole private progress to such
+// a row over-shoots (every one of those deltas was trained against the same stale row), so for them the row moves a
+// step of weight P.xhot_w from its current value towards ours -- the rule of the hot target rows (XHot).
+// `keep`: the row stays resident (age-limited residency of those rows, Step2::refresh): the merged value also becomes
+// the slot's value, its new entry and checksum.
 template <int MM>
-__device__ __forceinline__ void retire_finish(const Rows<MM> &A, int row, int gen, int slot, unsigned csum_at_entry,
-                                              const Col4 &g, const Col4 &rw) {
+__device__ __forceinline__ void retire_finish(const Rows<MM> &A, const Win2 &L, int row, int gen, int slot, unsigned csum_at_entry,
+                                              const Col4 &g, const Col4 &rw, bool keep, int lane, int wave) {
   const unsigned now = wave_xor(A.active ? col_bits(g) : 0u);
   const bool untouched = (now == csum_at_entry);                          // wave-uniform
-  if (untouched) {
-    if (A.active) A.st_u(row, rw);
-  } else {
-    if (A.active) {
+  Col4 o = rw;
+  if (!untouched && A.active) {
+    if (row <= A.P.uavg_rank) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) o.e[e] = g.e[e] + A.P.xhot_w * (rw.e[e] - g.e[e]);
+    } else {
       const Col4 en = A.ld_entry(gen, slot);
-      Col4 o;
 #pragma unroll
       for (int e = 0; e < 4; e++) o.e[e] = g.e[e] + (rw.e[e] - en.e[e]);
-      A.st_u(row, o);
+    }
+  }
+  if (A.active) A.st_u(row, o);
+  if (keep) {
+    const unsigned cs = wave_xor(A.active ? col_bits(o) : 0u);
+    if (lane == 0) L.w->csum[slot][wave] = cs;
+    if (A.active) {
+      if (!untouched) lds_st(L.win + slot * A.dim + A.col0, o);
+      A.st_entry(gen, slot, o);
     }
   }
 }
@@ -259,7 +282,7 @@ __device__ __forceinline__ void window_retire(const Rows<MM> &A, const Win2 &L, 
     for (int i = 0; i < W2B_RCH; i++)
       if (i0 + i < n_ret) {
         const int s = L.s->ret_slot[i0 + i];
-        retire_finish<MM>(A, L.s->ret_row[i0 + i], L.s->ret_gen[i0 + i], s, L.w->csum[s][wave], g[i], rw[i]);
+        retire_finish<MM>(A, L, L.s->ret_row[i0 + i], L.s->ret_gen[i0 + i], s, L.w->csum[s][wave], g[i], rw[i], false, 0, wave);
       }
   }
 }
@@ -352,6 +375,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
   // producer registers: the unigram-table gather and the alpha load of the NEXT step are issued at the end
   // of a preparation, so that their latency is not on the producer's critical path either
   int t_pref = 0;
+  int pstep = 0;                 // steps prepared so far in this launch (ages of the window slots)
   bool pref_ok = false;
   float alpha_pref = P.starting_alpha;
   bool alpha_pref_ok = false;
@@ -448,6 +472,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
               const int gen = L.w->slot_gen[s] ^ 1;          // the scratch row of the previous tenant stays readable
               L.w->slot_gen[s] = gen;
               L.w->slot_row[s] = w; L.w->slot_ref[s] = 1;
+              L.w->slot_born[s] = pstep;
               O.s->adm_slot[n_adm] = s; O.s->adm_row[n_adm] = w; O.s->adm_gen[n_adm] = gen;
             }
             n_adm++;
@@ -467,6 +492,26 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
         n_ret += __popcll(ml);
         W2B_WAVE_SYNC();
       }
+      // Age-limited residency of the most frequent context words (rows 1..uavg_rank): such a word is in the window most
+      // of the time and would otherwise stay private to this worker for hundreds of steps.  When nothing else leaves in
+      // this step, the oldest one past win_refresh steps is merged with memory in place (retire_finish with `keep`).
+      int refresh = 0;
+      if (train && n_ret == 0 && P.win_refresh > 0 && P.uavg_rank > 0) {
+        const bool cand = (lane < NS) && (L.w->slot_row[lane] > 0) && (L.w->slot_row[lane] <= P.uavg_rank) &&
+                          (L.w->slot_ref[lane] > 0) && (pstep - L.w->slot_born[lane] >= P.win_refresh);
+        const unsigned long long mc = __ballot(cand);
+        if (mc) {
+          const int sr = __ffsll((long long)mc) - 1;
+          if (lane == 0) {
+            O.s->ret_slot[0] = sr; O.s->ret_row[0] = L.w->slot_row[sr]; O.s->ret_gen[0] = L.w->slot_gen[sr];
+            L.w->slot_born[sr] = pstep;
+          }
+          n_ret = 1;
+          refresh = 1;
+          W2B_WAVE_SYNC();
+        }
+      }
+      pstep++;
       if (train) {
         const int hiA = 2 * W + 1 - b;
         for (int a0 = b; a0 < hiA; a0 += 64) {                          // ref :431-436
@@ -568,6 +613,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
         O.s->st.n_ret = n_ret; O.s->st.n_adm = n_adm; O.s->st.next_row = next_row; O.s->st.nck = (cw > 0) ? nck : 0;
         O.s->st.alpha = alpha;
         O.s->st.cdup = cdup;
+        O.s->st.refresh = refresh;
         if (done) S->done = 1;
       }
   };
@@ -695,7 +741,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
             }
             // a register-held outer row of this step that is the row leaving right now must see the merge
             if (UC && deferred && ((uc_n > 0 && I.s->uc_row[0] == d_row) || (uc_n > 1 && I.s->uc_row[1] == d_row))) {
-              retire_finish<MM>(A, d_row, d_gen, d_slot, d_csum, d_g, d_rw);
+              retire_finish<MM>(A, L, d_row, d_gen, d_slot, d_csum, d_g, d_rw, I.s->st.refresh != 0, lane, wave);
               deferred = false;
             }
             // prefetch the row that enters at the next step (never one whose store is still ahead of us)
@@ -745,7 +791,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
           // The row that left the window is merged back here: its current value was requested before the admit
           // above and has had phase A to arrive (memory returns in order, the target rows are needed next anyway),
           // and its registers are free before the dot products need room.
-          if (deferred) retire_finish<MM>(A, d_row, d_gen, d_slot, d_csum, d_g, d_rw);
+          if (deferred) retire_finish<MM>(A, L, d_row, d_gen, d_slot, d_csum, d_g, d_rw, I.s->st.refresh != 0, lane, wave);
           deferred = false;
         }
         if (!word_step) break;
@@ -822,19 +868,15 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
             const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
             const unsigned hk = (unsigned)(rows[i] - 1);
             if (active) {
-              if (hk < (unsigned)NH || rows[i] <= P.atomic_rank) {
-                // a hot row: its delta is atomically added to this XCD's copy (dozens of workers have the row in
-                // flight); a frequent row below that (w2b_tuning.atomic_rank): atomically added to the row itself
-                Col4 dl;
+              if (Rows<MM>::ATOMIC && !(hk < (unsigned)NH) && rows[i] <= P.atomic_rank) {
+                // a frequent row below the hot ones (w2b_tuning.atomic_rank): its delta is added atomically to the row
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                   float xv = x[i].e[e];
                   if (QM != 0) asm volatile("" : "+v"(xv));
                   err.e[e] += g * quant<QM>(xv, qp);
-                  dl.e[e] = g * avg.e[e] - ar2 * xv;
+                  A.add_v1(rows[i], e, g * avg.e[e] - ar2 * xv);
                 }
-                if (hk < (unsigned)NH) A.add_hot((int)hk, dl);
-                else A.add_v(rows[i], dl);
               } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -844,7 +886,8 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
                   err.e[e] += g * quant<QM>(xv, qp);
                   x[i].e[e] = xv + (g * avg.e[e] - ar2 * xv);
                 }
-                A.st_v(rows[i], x[i]);
+                if (hk < (unsigned)NH) A.st_hot((int)hk, x[i]);       // a hot row: this XCD's copy
+                else A.st_v(rows[i], x[i]);
               }
             }
           }
@@ -901,7 +944,8 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
         // this worker's turn: xhot_m of the XCD's hot rows meet their master rows (the copies of a launch are folded
         // into the masters by k_xhot_fold afterwards, so a stop pass has nothing to do)
         for (int j = 0; j < P.xhot_m && j < NH; j++)
-          xhot_merge_row(P.v, A.hot_c, A.hot_e, A.hot_l, (merge_cursor + j) % NH, NH, dim, col0, active, wave, lane);
+          xhot_merge_row<Rows<MM>::M, Rows<MM>::TB>(P.v, A.hot_c, A.hot_e, A.hot_l, (merge_cursor + j) % NH, NH, dim, col0, active,
+                                                    wave, lane, P.tab_bytes, P.xhot_w);
         merge_cursor += P.xhot_m;
       }
       W2B_TICK(8);
@@ -939,6 +983,10 @@ int w2b_resident_plan(int dim, int window, int negative) {
   if (window >= 2 && win2_lds_bytes(dim, window, negative, window - 1) <= budget) return window - 1;
   return -1;
 }
+
+// can the sentence-resident kernel update rows 1..atomic_rank atomically for this launch?  (instantiated for the
+// small-table form with radius == window only; otherwise the plain kernel, which does it at run time, takes over)
+bool w2b_resident_atomic_ok(const W2bParams &p, int R) { return p.tab_bytes != 0 && R == p.window; }
 
 // rows of scratch ("entry") memory per worker
 long long w2b_resident_scratch_rows(int R) { return 2ll * (2 * R + 1); }
@@ -981,10 +1029,12 @@ hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int 
   }
   return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
     constexpr int QM = decltype(qm)::value;
-    // template MM carries the memory mode in bits 0-2 (0: agent-scope rows) and "tables >= 2 GiB" (per-row descriptors) in bit 3
+    // template MM carries the memory mode in bits 0-2 (0: agent-scope rows), "tables >= 2 GiB" (per-row descriptors) in bit 3
+    // and "atomic adds for rows 1..atomic_rank" in bit 4 (small-table form and radius == window only: w2b_resident_atomic_ok)
 #define W2B_LAUNCH_R(LOSS, MMV, UCV) hipLaunchKernelGGL((k_train_resident<QM, LOSS, MMV, UCV>), dim3(grid), dim3(threads), lds, s, p, max_positions, R, NDW, lds_ints)
 #define W2B_LAUNCH_R2(MMV, UCV) do { if (loss) W2B_LAUNCH_R(true, MMV, UCV); else W2B_LAUNCH_R(false, MMV, UCV); } while (0)
     if (R < p.window) { if (p.tab_bytes) W2B_LAUNCH_R2(0, true); else W2B_LAUNCH_R2(8, true); }
+    else if (p.atomic_rank > 0 && p.tab_bytes) W2B_LAUNCH_R2(16, false);
     else { if (p.tab_bytes) W2B_LAUNCH_R2(0, false); else W2B_LAUNCH_R2(8, false); }
 #undef W2B_LAUNCH_R2
 #undef W2B_LAUNCH_R

@@ -112,11 +112,15 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     if (S->done) break;
     const int cw = S->cw, nt = S->nt;
     const float alpha = S->alpha;
-    if (cw > 0) process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, XH);
-    else __syncthreads();
+    bool wide = false;
+    if constexpr (VEC == 1 && MAXTHREADS == 1024) wide = P.wide != 0;
+    if (cw > 0) {
+      if (wide) { if constexpr (VEC == 1 && MAXTHREADS == 1024) process_word_wide<QM, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc); }
+      else process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, XH);
+    } else __syncthreads();
     if (VEC == 4 && hot && ++since_merge >= P.hot_period) {
       since_merge = 0;
-      xhot_merge_event(P, XH, merge_cursor, tid * VEC, tid * VEC < P.dim);
+      xhot_merge_event<MM>(P, XH, merge_cursor, tid * VEC, tid * VEC < P.dim);
     }
   }
   // save the worker

@@ -52,6 +52,8 @@ struct w2b_trainer {
   std::vector<double> rate_v, rate_u;   // [k]: uses of row k + 1 of v (as a target) / of u (as a context row) per centre word
   std::vector<int64_t> counts;          // vocab[].cn as given to w2b_set_vocab_counts (sorted by count behind row 0)
   double counts_pw = 0, counts_tot = 0; // sum cn^0.75, sum cn
+  float *wide_scratch = nullptr;        // process_word_wide: [workgroups][2][dim]
+  size_t wide_floats = 0;
   float *xhot = nullptr;        // [W2B_NXCD]{copies [nu + nv][dim], entries [nu + nv][dim], merge locks [nu + nv][W2B_MAXW]}
   size_t xhot_floats = 0;
   int xhot_nu = -1, xhot_nv = -1;       // layout the buffer currently has (-1: none)
@@ -86,6 +88,8 @@ struct w2b_trainer {
   // replica exchange (see "multi-GPU" below): two exchange streams, chunk staging buffers, events
   hipStream_t xs[2] = {nullptr, nullptr};
   float *xd[2] = {nullptr, nullptr}, *xsum[2] = {nullptr, nullptr};   // per slot: own delta / sum over the replicas
+  float *xcnt = nullptr;                    // [2 * vocab_size]: replicas that changed each row (contributor-average mode)
+  bool x_use_cnt = false;                   // the exchange in progress divides by xcnt
   long long xchunk = 0;                     // floats per chunk
   hipEvent_t x_train = nullptr;             // "the launches issued so far": the exchange streams wait for it
   hipEvent_t x_done[2] = {nullptr, nullptr};     // last operation of the latest exchange on each exchange stream
@@ -203,7 +207,12 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.xhot = nullptr;                    // set by xhot_prepare() for the launch that uses the copies
   p.xhot_u = p.xhot_v = 0;
   p.xhot_m = 1;
+  p.xhot_w = (float)t->tune.hot_weight_permille / 1000.f;
+  p.uavg_rank = 0;
+  p.win_refresh = t->tune.window_refresh;
   p.atomic_rank = 0;
+  (void)w2b_block_threads(t->cfg.layer1_size, nullptr, &p.wide);   // rows longer than a workgroup has columns
+  p.wide_scratch = t->wide_scratch;
   p.starting_alpha = t->cfg.alpha;
   p.sample = t->cfg.sample;
   p.reg = t->cfg.reg;
@@ -218,11 +227,6 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
       cfg->worker_offset < 0 || cfg->total_threads < 0 ||
       (cfg->total_threads > 0 && cfg->worker_offset + cfg->num_threads > cfg->total_threads))
     return fail(W2B_EINVAL, "w2b_trainer_create: bad configuration value");
-  int vec = 0;
-  const int threads = w2b_block_threads(cfg->layer1_size, &vec);
-  if (threads > 1024)
-    return fail(W2B_EUNSUPPORTED, "layer1_size too large for one workgroup (max 4096 when a multiple "
-                                  "of 4, else 1024)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(W2B_ENOGPU, "no HIP device visible (this library has no CPU fallback)");
@@ -245,7 +249,9 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
   t->tune.grid_per_cu = 0;
   t->tune.mem_mode = -1;
   t->tune.atomic_rank = -1;
-  t->tune.atomic_cap = 0;         // (set from measurements: DESIGN.md section 6)
+  t->tune.atomic_cap = 0;         // 0 = no cap
+  t->tune.hot_weight_permille = 1000 / W2B_NXCD;
+  t->tune.window_refresh = 16;
   HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
   t->table_elems = (long long)cfg->vocab_size * cfg->layer1_size;
   HIPCHK(hipMalloc(&t->uv, sizeof(float) * 2 * t->table_elems));
@@ -307,7 +313,7 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   for (hipEvent_t e : t->x_done) if (e) (void)hipEventDestroy(e);
   if (t->x_train) (void)hipEventDestroy(t->x_train);
   for (hipStream_t q : t->xs) if (q) (void)hipStreamDestroy(q);
-  void *ptrs[] = {t->xd[0], t->xd[1], t->xsum[0], t->xsum[1], t->uv, t->base, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->xhot, t->corpus_owned, t->workers, t->shared,
+  void *ptrs[] = {t->xcnt, t->xd[0], t->xd[1], t->xsum[0], t->xsum[1], t->uv, t->base, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->xhot, t->wide_scratch, t->corpus_owned, t->workers, t->shared,
                   t->jump_a, t->jump_c, t->st_center, t->st_off, t->st_ctx, t->st_neg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -340,6 +346,9 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
   if (in->mem_mode < -1 || in->mem_mode > 1) return fail(W2B_EINVAL, "w2b_set_tuning: mem_mode must be -1, 0 or 1");
 #endif
   if (in->atomic_rank < -1 || in->atomic_cap < 0) return fail(W2B_EINVAL, "w2b_set_tuning: atomic_rank >= -1, atomic_cap >= 0");
+  if (in->window_refresh < 0) return fail(W2B_EINVAL, "w2b_set_tuning: window_refresh must be >= 0");
+  if (in->hot_weight_permille < 1 || in->hot_weight_permille > 1000)
+    return fail(W2B_EINVAL, "w2b_set_tuning: hot_weight_permille must be 1..1000");
   for (int r : in->reserved) if (r != 0) return fail(W2B_EINVAL, "w2b_set_tuning: reserved fields must be zero");
   t->tune = *in;
   return W2B_OK;
@@ -651,7 +660,9 @@ static const double W2B_HOT_LOAD = 6400.0;
 static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv) {
   *nu = *nv = 0;
   const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
-  if (t->cfg.layer1_size % 4 != 0 || mem_mode != 0 || t->cfg.exact_reduction) return;
+  int wide = 0;
+  (void)w2b_block_threads(t->cfg.layer1_size, nullptr, &wide);
+  if (t->cfg.layer1_size % 4 != 0 || wide || mem_mode != 0 || t->cfg.exact_reduction) return;
   const long long vmax = t->cfg.vocab_size - 1 < W2B_XHOT_MAX ? t->cfg.vocab_size - 1 : W2B_XHOT_MAX;
   auto pick = [&](int explicit_n, const std::vector<double> &rate) -> int {
     long long n = 0;
@@ -666,30 +677,49 @@ static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int 
   if (with_u) *nu = pick(t->tune.hot_rows_u, t->rate_u);
 }
 
-// Rows 1..n (by count) whose updates are atomic adds at their master address (w2b_tuning.atomic_rank).  Automatic: a
-// load / modify / store of a row is open for about 10 us on this machine (the rows of a chunk are loaded together and
-// written after their dot products), during which every other worker's update of the same row is lost; a row that is
-// a target of `rate` centre words is hit rate x words/s times a second, i.e. about 0.6 x workers x rate times per
-// window.  Rows for which that reaches W2B_ATOMIC_LOAD are updated atomically, at most atomic_cap of them (an atomic
-// update costs more memory time than a store).
+// Rows 1..n (by count) whose updates are atomic adds at their master address (w2b_tuning.atomic_rank).  A load / modify /
+// store of a row is open for about 10 us on this machine (the rows of a chunk are loaded together and written after
+// their dot products), during which every other worker's update of the same row is lost; a row that is a target of
+// `rate` centre words is hit about 0.6 x workers x rate times per window.  Measured: on small
+// flat vocabularies, where that number is between a fraction and a few for EVERY row, atomic adds bring the epoch
+// losses of 64 ... 512 workers back to the reference's (planted corpus, 512 workers, first epoch: -1.1 % instead of
+// -31 %); on Zipf vocabularies they change nothing that matters (the rows that collide are the hot rows, which have
+// their own scheme, and summing the hundreds of stale gradients a hot row collects per window over-shoots) and cost
+// 20-30 % of the throughput.  Automatic therefore means: all rows when even the least frequent row collides
+// (0.6 x workers x rate >= W2B_ATOMIC_LOAD), none otherwise; atomic_cap > 0 limits the number of rows.
 static const double W2B_ATOMIC_LOAD = 0.25;
 static int atomic_plan(const w2b_trainer *t, long long workers) {
-  if (t->cfg.exact_reduction) return 0;
+  int wide = 0;
+  (void)w2b_block_threads(t->cfg.layer1_size, nullptr, &wide);
+  if (t->cfg.exact_reduction || wide) return 0;
   const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
   if (mem_mode != 0) return 0;
   const long long V = t->cfg.vocab_size;
-  if (t->tune.atomic_rank >= 0) return (int)(t->tune.atomic_rank < V - 1 ? t->tune.atomic_rank : V - 1);
-  if (t->counts.empty() || t->counts_pw <= 0 || t->counts_tot <= 0) return 0;
-  auto rate = [&](long long r) {           // uses of row r of v as a target per centre word (monotone: counts are sorted)
-    const double c = (double)t->counts[(size_t)r];
-    return t->cfg.negative * pow(c, 0.75) / t->counts_pw + c / t->counts_tot;
-  };
-  long long lo = 0, hi = V - 1;            // largest r in [1, V-1] with 0.6 * workers * rate(r) >= W2B_ATOMIC_LOAD
-  while (lo < hi) {
-    const long long mid = (lo + hi + 1) / 2;
-    if (0.6 * (double)workers * rate(mid) >= W2B_ATOMIC_LOAD) lo = mid; else hi = mid - 1;
+  long long n = 0;
+  if (t->tune.atomic_rank >= 0) n = t->tune.atomic_rank;
+  else if (!t->counts.empty() && t->counts_pw > 0 && t->counts_tot > 0) {
+    const double c = (double)t->counts[(size_t)(V - 1)];           // the least frequent row (counts are sorted)
+    const double rate = t->cfg.negative * pow(c, 0.75) / t->counts_pw + c / t->counts_tot;
+    if (0.6 * (double)workers * rate >= W2B_ATOMIC_LOAD) n = V - 1;
+    if (t->tune.atomic_cap > 0 && n > t->tune.atomic_cap) n = t->tune.atomic_cap;
   }
-  return (int)(lo < t->tune.atomic_cap ? lo : t->tune.atomic_cap);
+  return (int)(n < V - 1 ? n : V - 1);
+}
+
+// scratch rows of process_word_wide for `workgroups` workgroups (grown on demand)
+static int wide_prepare(w2b_trainer *t, W2bParams &p, long long workgroups) {
+  if (!p.wide) return W2B_OK;
+  const size_t need = (size_t)workgroups * 2 * t->cfg.layer1_size;
+  if (need > t->wide_floats) {
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if (t->wide_scratch) HIPCHK(hipFree(t->wide_scratch));
+    t->wide_scratch = nullptr;
+    t->wide_floats = 0;
+    HIPCHK(hipMalloc(&t->wide_scratch, sizeof(float) * need));
+    t->wide_floats = need;
+  }
+  p.wide_scratch = t->wide_scratch;
+  return W2B_OK;
 }
 
 // Buffer + parameters of the XCD-shared hot rows for one launch; folds the copies into the masters first when the
@@ -701,6 +731,11 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   p.xhot_u = nu;
   p.xhot_v = nv;
   p.atomic_rank = atomic_plan(t, workers);
+  if (!with_u) {          // sentence-resident kernel: its context rows live in LDS; the most frequent ones (the rows that
+    int un = 0, vn = 0;   // would be hot rows of u) are merged by consensus and refreshed (w2b_kernels_resident.hip)
+    xhot_plan(t, workers, true, &un, &vn);
+    p.uavg_rank = un;
+  }
   if (nu + nv == 0) return W2B_OK;
   const size_t need = (size_t)W2B_NXCD * ((size_t)2 * (nu + nv) * t->cfg.layer1_size + (size_t)(nu + nv) * W2B_MAXW);
   bool fresh = (nu != t->xhot_nu || nv != t->xhot_nv);
@@ -772,7 +807,12 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   NEED(t);
   if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_train_step: corpus/shards not set");
   if (max_positions <= 0) return fail(W2B_EINVAL, "w2b_train_step: max_positions must be positive");
-  const int radius = worker_plan(t);
+  int radius = worker_plan(t);
+  if (radius >= 0) {       // atomic row updates (small flat vocabularies): only some forms of the sentence-resident kernel have them
+    W2bParams probe = make_params(t);
+    probe.atomic_rank = atomic_plan(t, t->cfg.num_threads);
+    if (probe.atomic_rank > 0 && !w2b_resident_atomic_ok(probe, radius)) radius = -1;
+  }
   if (radius >= 0) {                       // scratch rows of the sentence-resident kernel (grown on demand)
     const size_t need = (size_t)t->cfg.num_threads * (size_t)w2b_resident_scratch_rows(radius) * t->cfg.layer1_size;
     if (need > t->entry_floats) {
@@ -787,6 +827,7 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   W2bParams p = make_params(t);
   // per-XCD copies of the hottest rows: v only for the sentence-resident kernel (its context rows live in LDS)
   if (int rc = xhot_prepare(t, p, t->cfg.num_threads, radius < 0)) return rc;
+  if (int rc = wide_prepare(t, p, t->cfg.num_threads)) return rc;
   HIPCHK(timing_begin(t));
   if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream));
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
@@ -865,6 +906,10 @@ extern "C" int w2b_train_tuples_device(w2b_trainer *t, int64_t n, const void *ce
     long long wgs = grid > 0 ? grid : (long long)(t->tune.grid_per_cu > 0 ? t->tune.grid_per_cu : 4) * t->num_cus;
     if (wgs > n) wgs = n;
     if (int rc = xhot_prepare(t, p, wgs, true)) return rc;
+    if (p.wide) {                          // (an explicit grid: the scratch rows are per workgroup)
+      if (grid <= 0) grid = (int32_t)(n < 2ll * t->num_cus ? n : 2ll * t->num_cus);
+      if (int rc = wide_prepare(t, p, grid)) return rc;
+    }
   }
   HIPCHK(timing_begin(t));
   HIPCHK(w2b_launch_tuples(p, n, (const int32_t *)center, (const int32_t *)ctx_off, (const int32_t *)ctx,
@@ -957,6 +1002,7 @@ static int xchg_setup(w2b_trainer *t) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_done[k], hipEventDisableTiming);
   }
   if (e == hipSuccess && !t->wca_buf) e = hipMalloc(&t->wca_buf, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc(&t->xcnt, sizeof(float) * 2 * t->cfg.vocab_size);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_train, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemcpyAsync(t->base, t->uv, sizeof(float) * n, hipMemcpyDeviceToDevice, t->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -1043,7 +1089,8 @@ static int xchg_delta(w2b_trainer *t, long long c) {
 static int xchg_apply(w2b_trainer *t, long long c, float scale) {
   const long long n = 2 * t->table_elems, o = c * t->xchunk, m = (n - o < t->xchunk) ? n - o : t->xchunk;
   const int k = (int)(c & 1);
-  HIPCHK(w2b_launch_xchg_apply(t->uv + o, t->base + o, t->xd[k], t->xsum[k], scale, m, t->xs[k]));
+  HIPCHK(w2b_launch_xchg_apply(t->uv + o, t->base + o, t->xd[k], t->xsum[k], scale, m, t->x_use_cnt ? t->xcnt : nullptr, o,
+                               t->cfg.layer1_size, t->xs[k]));
   return W2B_OK;
 }
 static int xchg_end(w2b_trainer *t) {
@@ -1061,14 +1108,21 @@ static int xchg_end(w2b_trainer *t) {
 extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
   NEED(t);
   if (!t->comm) return W2B_OK;             // a single replica without a communicator: nothing to exchange
-  if (mode != 0 && mode != 1) return fail(W2B_EINVAL, "w2b_sync_replicas: unknown mode");
+  if (mode < 0 || mode > 2) return fail(W2B_EINVAL, "w2b_sync_replicas: unknown mode");
   if (int rc = xchg_begin(t)) return rc;
   // progress first (16 bytes): every replica learns the global word count -- the alpha schedule (ref :391) is exact
   // at every exchange and extrapolates in between (W2bShared::wca_others)
   HIPCHK(w2b_launch_wca_pack(t->shared, t->wca_buf, t->xs[0]));
   NCCLCHK(ncclAllReduce(t->wca_buf, t->wca_buf + 1, 1, ncclUint64, ncclSum, t->comm, t->xs[0]));
   HIPCHK(w2b_launch_wca_unpack(t->shared, t->wca_buf, t->xs[0]));
-  const float scale = mode == 0 ? 1.f : 1.f / (float)t->nranks;
+  const float scale = mode == 1 ? 1.f / (float)t->nranks : 1.f;
+  t->x_use_cnt = mode == 2;
+  if (mode == 2) {          // who has trained which row since the last exchange (2 V floats), before the first apply
+    HIPCHK(w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, 2 * t->cfg.vocab_size, t->cfg.layer1_size, t->xs[0]));
+    NCCLCHK(ncclAllReduce(t->xcnt, t->xcnt, (size_t)(2 * t->cfg.vocab_size), ncclFloat, ncclSum, t->comm, t->xs[0]));
+    HIPCHK(hipEventRecord(t->x_done[0], t->xs[0]));
+    HIPCHK(hipStreamWaitEvent(t->xs[1], t->x_done[0], 0));
+  }
   const long long nc = xchg_chunks(t), n = 2 * t->table_elems;
   for (long long c = 0; c < nc; c++) {
     const long long o = c * t->xchunk, m = (n - o < t->xchunk) ? n - o : t->xchunk;
@@ -1088,6 +1142,7 @@ extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
 extern "C" int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count) {
   NEED(t);
   if (int rc = xchg_begin(t)) return rc;
+  t->x_use_cnt = false;
   if (n_chunks) *n_chunks = xchg_chunks(t);
   if (local_word_count) {
     HIPCHK(w2b_launch_wca_pack(t->shared, t->wca_buf, t->xs[0]));
@@ -1098,6 +1153,18 @@ extern "C" int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *lo
   }
   return W2B_OK;
 }
+extern "C" int w2b_exchange_counts(w2b_trainer *t, void **buf_dev, int64_t *elems) {
+  NEED(t);
+  if (!t->base || t->x_ev.empty()) return fail(W2B_ESTATE, "w2b_exchange_counts: w2b_exchange_begin first");
+  if (!buf_dev || !elems) return fail(W2B_EINVAL, "w2b_exchange_counts: null argument");
+  HIPCHK(w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, 2 * t->cfg.vocab_size, t->cfg.layer1_size, t->xs[0]));
+  HIPCHK(hipStreamSynchronize(t->xs[0]));
+  t->x_use_cnt = true;
+  *buf_dev = t->xcnt;
+  *elems = 2 * t->cfg.vocab_size;
+  return W2B_OK;
+}
+
 extern "C" int w2b_exchange_delta(w2b_trainer *t, int64_t chunk, void **buf_dev, int64_t *elems) {
   NEED(t);
   if (!t->base || t->x_ev.empty()) return fail(W2B_ESTATE, "w2b_exchange_delta: w2b_exchange_begin first");

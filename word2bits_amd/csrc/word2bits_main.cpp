@@ -41,6 +41,8 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int hot_rows = -1;                   // -hot-rows N: leading rows of v (and u) with per-XCD copies; -1 = from the counts
   int hot_period = 0;                  // -hot-period N: centre words between two merge events of a worker (0 = default)
   int atomic_rank = -2;                // -atomic-rank N: rows 1..N are updated with atomic adds (-1 automatic; default: library's)
+  int window_refresh = -1;             // -window-refresh N: w2b_tuning.window_refresh (-1 = default)
+  int hot_weight = 0;                  // -hot-weight N: w2b_tuning.hot_weight_permille (0 = default)
   int atomic_cap = -1;                 // -atomic-cap N: most rows the automatic choice takes
   int row_desc = 0;                    // -row-desc 1: the row addressing of tables >= 2 GiB on any table (w2b_tuning.force_row_desc)
 };
@@ -126,6 +128,8 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-row-desc", argc, argv)) > 0) o.row_desc = atoi(argv[i + 1]);
   if ((i = arg_pos("-atomic-rank", argc, argv)) > 0) o.atomic_rank = atoi(argv[i + 1]);
   if ((i = arg_pos("-atomic-cap", argc, argv)) > 0) o.atomic_cap = atoi(argv[i + 1]);
+  if ((i = arg_pos("-hot-weight", argc, argv)) > 0) o.hot_weight = atoi(argv[i + 1]);
+  if ((i = arg_pos("-window-refresh", argc, argv)) > 0) o.window_refresh = atoi(argv[i + 1]);
 
   // ---- TrainModel, ref :518-577
   printf("Starting training using file %s\n", o.train_file.c_str());
@@ -217,7 +221,7 @@ int main(int argc, char **argv) {
     cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
-    if (o.hot_rows >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0) {
+    if (o.hot_rows >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0) {
       w2b_tuning tn;
       CK(w2b_get_tuning(a->r->t, &tn));
       if (o.hot_rows >= 0) tn.hot_rows_v = tn.hot_rows_u = o.hot_rows;
@@ -225,6 +229,8 @@ int main(int argc, char **argv) {
       tn.force_row_desc = o.row_desc ? 1 : 0;
       if (o.atomic_rank >= -1) tn.atomic_rank = o.atomic_rank;
       if (o.atomic_cap >= 0) tn.atomic_cap = o.atomic_cap;
+      if (o.hot_weight > 0) tn.hot_weight_permille = o.hot_weight;
+      if (o.window_refresh >= 0) tn.window_refresh = o.window_refresh;
       CK(w2b_set_tuning(a->r->t, &tn));
     }
     CK(w2b_init_net(a->r->t));                              // ref :528
@@ -306,10 +312,11 @@ int main(int argc, char **argv) {
       }
       launches++;
       if (o.gpus > 1 && (finished || launches % (o.sync_every > 0 ? o.sync_every : 1) == 0)) {
-        // replicas: periodic delta-sum all-reduce of [u||v] over RCCL (and always at the end of an epoch)
+        // replicas: periodic all-reduce of the deltas of [u||v] over RCCL, every row's sum shared among the replicas that
+        // trained it (w2b_sync_replicas mode 2), and always at the end of an epoch
         std::vector<pthread_t> th(o.gpus);
         // (one host thread per replica: the collectives of one process's communicators must be issued concurrently)
-        auto sync = [](void *p) -> void * { CK(w2b_sync_replicas((w2b_trainer *)p, 0)); return nullptr; };
+        auto sync = [](void *p) -> void * { CK(w2b_sync_replicas((w2b_trainer *)p, 2)); return nullptr; };
         for (int g = 0; g < o.gpus; g++) pthread_create(&th[g], nullptr, sync, reps[g].t);
         for (int g = 0; g < o.gpus; g++) pthread_join(th[g], nullptr);
       }

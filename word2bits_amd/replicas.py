@@ -101,19 +101,13 @@ class PhasedReplicaSync:
     def sync(self):
         import torch
         n_chunks, words = self.t.exchange_begin()
-        scale = 1.0 if self.mode == 0 else 1.0 / self.world
+        scale = 1.0 / self.world if self.mode == 1 else 1.0
+        if self.mode == 2:                                    # contributor average: who trained which row
+            self._reduce(self.t.device_tensor(*self.t.exchange_counts()))
         for c in range(n_chunks):
             ptr, n = self.t.exchange_delta(c)                 # complete on return
             buf = self.t.device_tensor(ptr, n)
-            if self.world > 1:
-                if self.on_device:
-                    self.dist.all_reduce(buf)
-                    torch.cuda.synchronize(buf.device)
-                else:                                         # gloo: through host memory
-                    host = buf.cpu()
-                    self.dist.all_reduce(host)
-                    buf.copy_(host)
-                    torch.cuda.synchronize(buf.device)
+            self._reduce(buf)
             self.t.exchange_apply(c, scale)
         total = torch.tensor([words], dtype=torch.int64)
         if self.world > 1:
@@ -121,6 +115,17 @@ class PhasedReplicaSync:
                 total = total.to(buf.device)
             self.dist.all_reduce(total)
         self.t.exchange_end(int(total.item()))
+
+    def _reduce(self, buf):
+        import torch
+        if self.world > 1:
+            if self.on_device:
+                self.dist.all_reduce(buf)
+            else:                                             # gloo: through host memory
+                host = buf.cpu()
+                self.dist.all_reduce(host)
+                buf.copy_(host)
+            torch.cuda.synchronize(buf.device)
 
 
 def global_progress_alpha(starting_alpha, words_done_all_ranks, iters, train_words):

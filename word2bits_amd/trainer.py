@@ -287,6 +287,13 @@ class Trainer:
         check(lib().w2b_exchange_begin(self._h, C.byref(n), C.byref(w)))
         return n.value, w.value
 
+    def exchange_counts(self):
+        """-> (device pointer, floats): 1 for every row of [u||v] this replica changed since the last exchange; sum it over
+        the replicas in place and exchange_apply divides every row's summed delta by it (contributor average)"""
+        p, n = _lib.vp(), C.c_int64(0)
+        check(lib().w2b_exchange_counts(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def exchange_delta(self, chunk):
         """-> (device pointer, floats) of this replica's delta of the chunk; sum it over the replicas in place"""
         p, n = _lib.vp(), C.c_int64(0)
