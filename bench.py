@@ -388,8 +388,10 @@ def main():
     wcache = None if args.window_cache < 0 else bool(args.window_cache)
     workers = args.workers
     if workers <= 0:          # ask the library how many workgroups of the worker kernel are resident at once
-        probe = w2b.Trainer(2, D, W, K, args.bitlevel, num_threads=1, device=local_rank,
+        probe = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=1, device=local_rank, sample=0.0,
+                            train_words=train_words * world,
                             relaxed_coherence=bool(args.relaxed), window_cache=wcache, compute_loss=False)
+        probe.set_vocab_counts(counts, 0)         # which kernel runs (and how many workers fill the device) depends on the counts
         workers = probe.suggested_threads()
         probe.close()
     from word2bits_amd import replicas

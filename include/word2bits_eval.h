@@ -64,6 +64,11 @@ int w2b_eval_top1(w2b_eval *e, int64_t nq, const int32_t *b1, const int32_t *b2,
 int w2b_eval_transcript(w2b_eval *e, const char *questions, int64_t len, char **out, int64_t *out_len);
 void w2b_eval_free_text(char *text);
 
+/* Which kernel scores the fused (FMA) mode: 1 (default) = the f32 MFMA kernel; 0 = the same fused chain on the vector ALU
+ * (v_pk_fma_f32; a cross-check of the MFMA path); n > 1 = MFMA with n question tiles per row tile in the launch order.
+ * The two-rounding mode always runs on the vector ALU.  (Round 2 read this from the environment.) */
+int w2b_eval_set_kernel(w2b_eval *e, int32_t variant);
+
 /* Device time (HIP events on the evaluator's stream) and launch count of the score kernel since load or since
  * the last call; `macs` = multiply-adds those launches performed (questions x padded rows x padded size). */
 int w2b_eval_timing_read(w2b_eval *e, double *kernel_ms, int64_t *launches, double *macs);

@@ -43,48 +43,28 @@ def matrix(job, corpus, flags, cases, refs):
               np.round(100 * (losses - m) / np.abs(m), 2).tolist(), info[0], info[1]), flush=True)
 
 
-jobs = sys.argv[1:] or ["text8size", "headline", "planted"]
-K = {"resident": ["-window-cache", "1"], "plain": ["-window-cache", "0"]}
+jobs = sys.argv[1:] or ["text8size", "headline"]
+K = {"resident": ["-window-cache", "1"], "plain": ["-window-cache", "0"], "auto": []}
 if "text8size" in jobs:
     c = write_zipf_text_corpus(os.path.join(TMP, "t8.txt"))
     fl = dict(bitlevel=1, size=200, window=8, negative=24, iter=3)
-    cases = []
-    for th, ref in ((0, 256), (256, 256), (64, 64)):
-        for kern in ("resident", "plain"):
-            cases.append(("text8size threads=%d %s (defaults)" % (th, kern), th, K[kern], ref))
-    for name, extra in (("hot-rows=0", ["-hot-rows", "0"]), ("window-refresh=0", ["-window-refresh", "0"]),
-                        ("hot-weight=500", ["-hot-weight", "500"]), ("hot-period=2", ["-hot-period", "2"]),
-                        ("hot-rows=0 window-refresh=0", ["-hot-rows", "0", "-window-refresh", "0"])):
-        cases.append(("text8size threads=0 resident %s" % name, 0, K["resident"] + extra, 256))
-    cases.append(("text8size threads=0 plain hot-rows=0", 0, K["plain"] + ["-hot-rows", "0"], 256))
-    matrix("text8size", c, fl, cases, (64, 256))
+    cases = [("text8size threads=0 auto", 0, [], 256),
+             ("text8size threads=0 plain hot-weight=500", 0, K["plain"] + ["-hot-weight", "500"], 256),
+             ("text8size threads=0 plain hot-weight=1000", 0, K["plain"] + ["-hot-weight", "1000"], 256)]
+    matrix("text8size", c, fl, cases, (256,))
     os.remove(c)
 if "headline" in jobs:
     c = write_headline_corpus(os.path.join(TMP, "hl.txt"))
     fl = dict(bitlevel=1, size=800, window=8, negative=24, iter=1, sample=0)
-    cases = []
-    for th, ref in ((0, 256), (256, 256), (64, 64)):
-        for kern in ("resident", "plain"):
-            cases.append(("headline threads=%d %s (defaults)" % (th, kern), th, K[kern], ref))
-    for name, extra in (("hot-rows=0", ["-hot-rows", "0"]), ("window-refresh=0", ["-window-refresh", "0"]),
-                        ("window-refresh=4", ["-window-refresh", "4"]),
-                        ("hot-weight=500", ["-hot-weight", "500"]), ("hot-weight=1000", ["-hot-weight", "1000"]),
-                        ("hot-period=2", ["-hot-period", "2"]),
-                        ("hot-rows=0 window-refresh=0", ["-hot-rows", "0", "-window-refresh", "0"])):
-        cases.append(("headline threads=0 resident %s" % name, 0, K["resident"] + extra, 256))
-    cases.append(("headline threads=0 plain hot-rows=0", 0, K["plain"] + ["-hot-rows", "0"], 256))
-    cases.append(("headline threads=64 resident hot-rows=0 window-refresh=0", 64, K["resident"] + ["-hot-rows", "0", "-window-refresh", "0"], 64))
-    cases.append(("headline threads=64 plain hot-rows=0", 64, K["plain"] + ["-hot-rows", "0"], 64))
+    cases = [("headline threads=0 auto", 0, [], 256)]
+    for th, ref in ((512, 256), (256, 256), (64, 64)):
+        cases.append(("headline threads=%d auto" % th, th, [], ref))
+    for name, extra in (("hot-weight=250", ["-hot-weight", "250"]), ("hot-weight=500", ["-hot-weight", "500"]),
+                        ("hot-weight=1000", ["-hot-weight", "1000"]), ("hot-period=2", ["-hot-period", "2"]),
+                        ("hot-period=32", ["-hot-period", "32"]), ("hot-cap=16", ["-hot-cap", "16"]), ("hot-cap=128", ["-hot-cap", "128"])):
+        cases.append(("headline threads=0 plain %s" % name, 0, K["plain"] + extra, 256))
+    for name, extra in (("hot-weight=500", ["-hot-weight", "500"]), ("hot-weight=1000", ["-hot-weight", "1000"])):
+        cases.append(("headline threads=256 plain %s" % name, 256, K["plain"] + extra, 256))
+        cases.append(("headline threads=64 plain %s" % name, 64, K["plain"] + extra, 64))
     matrix("headline", c, fl, cases, (64, 256))
     os.remove(c)
-if "planted" in jobs:
-    corpus, q = os.path.join(TMP, "pl.txt"), os.path.join(TMP, "q.txt")
-    make_planted(corpus, q, repeats=120)
-    for job, fl in (("planted_b1_d200", dict(bitlevel=1, size=200, window=8, negative=24, iter=5)),
-                    ("planted_cfg2_b2_d400", dict(bitlevel=2, size=400, window=8, negative=24, iter=5))):
-        cases = []
-        for th in (8, 64, 512):
-            for kern in ("resident", "plain"):
-                cases.append(("%s threads=%d %s (defaults)" % (job, th, kern), th, K[kern], th))
-        cases.append(("%s threads=64 resident atomic-rank=0" % job, 64, K["resident"] + ["-atomic-rank", "0"], 64))
-        matrix(job, corpus, fl, cases, (8, 64, 512))

@@ -117,6 +117,7 @@ SIGNATURES = {
     "w2b_eval_top1": (C.c_int, [vp, C.c_int64, i32p, i32p, i32p, i32p, f32p]),
     "w2b_eval_transcript": (C.c_int, [vp, C.c_char_p, C.c_int64, C.POINTER(vp), i64p]),
     "w2b_eval_free_text": (None, [vp]),
+    "w2b_eval_set_kernel": (C.c_int, [vp, C.c_int32]),
     "w2b_eval_timing_read": (C.c_int, [vp, f64p, i64p, f64p]),
 }
 

@@ -123,7 +123,6 @@ static w2b_eval *eval_new(long long words, long long size, int32_t fused, int32_
   e->words = words;
   e->size = size;
   e->fused = fused ? 1 : 0;
-  if (const char *env = getenv("W2B_EVAL_KERNEL")) e->variant = atoi(env);   // 0 vector ALU; 1 MFMA (default grouping); >1 MFMA with that many question tiles per row tile
   e->ld = (size + 15) / 16 * 16;
   e->rows_padded = (words + kTile - 1) / kTile * kTile;
   if (e->rows_padded == 0) e->rows_padded = kTile;
@@ -298,6 +297,13 @@ extern "C" int w2b_eval_top1(w2b_eval *e, int64_t nq, const int32_t *b1, const i
       }
     }
   }
+  return W2B_OK;
+}
+
+extern "C" int w2b_eval_set_kernel(w2b_eval *e, int32_t variant) {
+  if (!e) return efail(W2B_EINVAL, "w2b_eval_set_kernel: null evaluator");
+  if (variant < 0 || variant > 64) return efail(W2B_EINVAL, "w2b_eval_set_kernel: variant must be 0..64");
+  e->variant = variant;
   return W2B_OK;
 }
 

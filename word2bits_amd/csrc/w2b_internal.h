@@ -92,7 +92,8 @@ hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool 
 int w2b_resident_plan(int dim, int window, int negative);
 bool w2b_resident_atomic_ok(const W2bParams &p, int radius);           // atomic_rank > 0: can the sentence-resident kernel do it?
 long long w2b_resident_scratch_rows(int radius);                       // scratch rows per worker
-hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int radius, bool loss, hipStream_t s);
+hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int radius, bool loss, hipStream_t s,
+                               bool debug = false);
 int w2b_workers_per_cu(const W2bParams &p, bool loss);                  // resident workgroups per CU, plain kernel
 int w2b_resident_per_cu(const W2bParams &p, int radius, bool loss);     // ... sentence-resident kernel
 hipError_t w2b_launch_init_net(float *u, float *v, long long n_per_table, const float *lut,

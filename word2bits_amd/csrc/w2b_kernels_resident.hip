@@ -1013,7 +1013,7 @@ int w2b_resident_per_cu(const W2bParams &p, int R, bool loss) {
 }
 
 // Coherent rows only (memory mode 0): with relaxed rows the launcher of the trainer picks the plain kernel.
-hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int R, bool loss, hipStream_t s) {
+hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int R, bool loss, hipStream_t s, bool debug) {
   const int wthreads = win2_threads(p.dim);  // data wavefronts (one thread per 16-byte column) + 1 producer wavefront
   const int NDW = wthreads / 64 - 1;
   const size_t wlds = win2_lds_per_worker(p, R);
@@ -1021,7 +1021,7 @@ hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int 
   const size_t lds = W2B_WPG * wlds;
   const int lds_ints = (int)(wlds / 4);
   static bool reported = false;
-  if (!reported && getenv("W2B_DEBUG")) {
+  if (!reported && debug) {
     reported = true;
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_train_resident<1, false, 0, false>, threads, lds);

@@ -479,8 +479,15 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
     // table) + cn_i / train_words (as the centre word itself); and row i of u a context row: (window + 1 on average,
     // SURVEY A.3) * cn_i / train_words.  The vocabulary is sorted by count, so the rows worth per-XCD copies are a prefix;
     // how long a prefix is decided per launch from these rates and the number of workers (xhot_plan).
-    double pw = 0, tot = 0;
-    for (int64_t a = 0; a < V; a++) { pw += pow((double)cn[a], 0.75); tot += (double)cn[a]; }
+    // (a token is a centre / context word only if it survives sub-sampling, ref :403-406: the counts that matter for
+    // those two roles are the expected KEPT occurrences; the negative draws use the raw counts, ref :112-128)
+    double pw = 0, tot = 0, tot_kept = 0;
+    auto kept = [&](int64_t a) -> double {
+      if (a == 0) return 0.0;                                  // "</s>" is never a centre or context word (ref :400)
+      const double k = t->cfg.sample > 0 ? (double)keep[(size_t)a] : 1.0;
+      return (double)cn[a] * (k < 1.0 ? k : 1.0);
+    };
+    for (int64_t a = 0; a < V; a++) { pw += pow((double)cn[a], 0.75); tot += (double)cn[a]; tot_kept += kept(a); }
     t->counts.assign(cn, cn + V);
     t->counts_pw = pw;
     t->counts_tot = tot;
@@ -489,8 +496,8 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
     t->rate_u.assign((size_t)(n > 0 ? n : 0), 0.0);
     for (int k = 0; k < n; k++) {
       const double c = (double)cn[k + 1];
-      t->rate_v[k] = (pw > 0 ? t->cfg.negative * pow(c, 0.75) / pw : 0) + (tot > 0 ? c / tot : 0);
-      t->rate_u[k] = tot > 0 ? (t->cfg.window + 1) * c / tot : 0;
+      t->rate_v[k] = (pw > 0 ? t->cfg.negative * pow(c, 0.75) / pw : 0) + (tot_kept > 0 ? kept(k + 1) / tot_kept : 0);
+      t->rate_u[k] = tot_kept > 0 ? (t->cfg.window + 1) * kept(k + 1) / tot_kept : 0;
     }
   }
   if (table_size > 0) {
@@ -637,6 +644,9 @@ extern "C" int w2b_epoch_begin(w2b_trainer *t) {
   return W2B_OK;
 }
 
+static const double W2B_PLAIN_CTX_SHARE = 0.2;     // share of the context positions held by hot rows above which the plain kernel runs
+static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv);
+
 // Which worker kernel runs: plain_worker_kernel 0 = automatic (sentence-resident kernel for coherent rows when
 // the window fits in LDS; plain kernel for relaxed rows, where caching in L2 already absorbs the re-reads and
 // four workgroups per CU win), 1 = plain, 2 = sentence-resident whenever it fits -- coherent rows only: relaxed rows and
@@ -646,6 +656,20 @@ static int worker_plan(const w2b_trainer *t) {
   if (mode == 1 || t->cfg.exact_reduction) return -1;   // the serial reduction lives in the plain kernel
   if (t->cfg.relaxed_coherence) return -1;              // the sentence-resident kernel exists for coherent rows only
   if (t->tune.mem_mode > 0) return -1;
+  if (mode == 0) {
+    // Automatic: the sentence-resident kernel keeps every context row private to a worker while it is in the window.
+    // That is a gain when the window's words are mostly rare (a real corpus with sub-sampling: ref default -sample
+    // 1e-3); when a large part of all context positions are the few most frequent words (no sub-sampling: the
+    // synthetic benchmark stream), those rows would be resident in every worker nearly all the time.  Then the plain
+    // kernel, which reads and writes them at their XCD copies every step (XHot), is as fast and follows the
+    // reference's losses more closely.
+    int nu = 0, nv = 0;       // (judged for a full device, so that a probe trainer with one worker decides as the real one will)
+    const long long full = 2ll * t->num_cus;
+    xhot_plan(t, t->cfg.num_threads > full ? t->cfg.num_threads : full, true, &nu, &nv);
+    double share = 0;
+    for (int k = 0; k < nu && k < (int)t->rate_u.size(); k++) share += t->rate_u[(size_t)k];
+    if (share / (t->cfg.window + 1) > W2B_PLAIN_CTX_SHARE) return -1;
+  }
   return w2b_resident_plan(t->cfg.layer1_size, t->cfg.window, t->cfg.negative);
 }
 
@@ -829,7 +853,7 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   if (int rc = xhot_prepare(t, p, t->cfg.num_threads, radius < 0)) return rc;
   if (int rc = wide_prepare(t, p, t->cfg.num_threads)) return rc;
   HIPCHK(timing_begin(t));
-  if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream));
+  if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream, t->debug));
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));
   HIPCHK(w2b_launch_xhot_fold(p, t->stream));      // the master rows are complete again when the stream is idle

@@ -39,6 +39,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int exact = 0;                       // 1: serial dot product in the reference's order (bit parity at -threads 1)
   std::string eval_file;               // -eval FILE: questions to score on the GPU after the final save (-binary 1)
   int hot_rows = -1;                   // -hot-rows N: leading rows of v (and u) with per-XCD copies; -1 = from the counts
+  int hot_cap = -1;                    // -hot-cap N: most rows the automatic choice takes (-1 = default)
   int hot_period = 0;                  // -hot-period N: centre words between two merge events of a worker (0 = default)
   int atomic_rank = -2;                // -atomic-rank N: rows 1..N are updated with atomic adds (-1 automatic; default: library's)
   int window_refresh = -1;             // -window-refresh N: w2b_tuning.window_refresh (-1 = default)
@@ -125,6 +126,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-eval", argc, argv)) > 0) o.eval_file = argv[i + 1];
   if ((i = arg_pos("-hot-rows", argc, argv)) > 0) o.hot_rows = atoi(argv[i + 1]);
   if ((i = arg_pos("-hot-period", argc, argv)) > 0) o.hot_period = atoi(argv[i + 1]);
+  if ((i = arg_pos("-hot-cap", argc, argv)) > 0) o.hot_cap = atoi(argv[i + 1]);
   if ((i = arg_pos("-row-desc", argc, argv)) > 0) o.row_desc = atoi(argv[i + 1]);
   if ((i = arg_pos("-atomic-rank", argc, argv)) > 0) o.atomic_rank = atoi(argv[i + 1]);
   if ((i = arg_pos("-atomic-cap", argc, argv)) > 0) o.atomic_cap = atoi(argv[i + 1]);
@@ -159,8 +161,12 @@ int main(int argc, char **argv) {
   if (o.num_threads < 1) {                                   // GPU extension: -threads 0 = fill the device(s)
     w2b_config probe_cfg;
     memset(&probe_cfg, 0, sizeof probe_cfg);
-    probe_cfg.train_words = w2b_corpus_train_words(corpus) / o.gpus;   // per replica: caps workers on small corpora
-    probe_cfg.vocab_size = 2; probe_cfg.layer1_size = (int32_t)o.layer1_size; probe_cfg.window = o.window;
+    probe_cfg.train_words = w2b_corpus_train_words(corpus);   // (with total_threads = replicas below: caps workers on small corpora)
+    probe_cfg.total_threads = o.gpus;
+    // (the real vocabulary and its counts: which worker kernel runs -- and with it how many workers fill the device --
+    // depends on how much of the text the most frequent words are)
+    probe_cfg.vocab_size = V; probe_cfg.layer1_size = (int32_t)o.layer1_size; probe_cfg.window = o.window;
+    probe_cfg.sample = o.sample;
     probe_cfg.negative = o.negative; probe_cfg.bitlevel = o.bitlevel; probe_cfg.num_threads = 1;
     probe_cfg.alpha = o.alpha; probe_cfg.compute_loss = 1; probe_cfg.device = o.device;
     probe_cfg.relaxed_coherence = o.relaxed;
@@ -169,6 +175,7 @@ int main(int argc, char **argv) {
     w2b_trainer *probe = nullptr;
     int32_t per_gpu = 1024;
     CK(w2b_trainer_create(&probe_cfg, &probe));
+    CK(w2b_set_vocab_counts(probe, w2b_corpus_counts(corpus), 0));
     CK(w2b_suggested_threads(probe, &per_gpu));               // workgroups resident at once on one GPU
     w2b_trainer_destroy(probe);
     o.num_threads = per_gpu * o.gpus;
@@ -221,11 +228,12 @@ int main(int argc, char **argv) {
     cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
-    if (o.hot_rows >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0) {
+    if (o.hot_rows >= 0 || o.hot_cap >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0) {
       w2b_tuning tn;
       CK(w2b_get_tuning(a->r->t, &tn));
       if (o.hot_rows >= 0) tn.hot_rows_v = tn.hot_rows_u = o.hot_rows;
       if (o.hot_period > 0) tn.hot_period = o.hot_period;
+      if (o.hot_cap >= 0) tn.hot_cap = o.hot_cap;
       tn.force_row_desc = o.row_desc ? 1 : 0;
       if (o.atomic_rank >= -1) tn.atomic_rank = o.atomic_rank;
       if (o.atomic_cap >= 0) tn.atomic_cap = o.atomic_cap;

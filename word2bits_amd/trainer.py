@@ -340,8 +340,9 @@ def train_model(train_file, output_file, bitlevel=1, size=100, window=5, negativ
     Returns the list of epoch losses."""
     corpus = Corpus(train_file, min_count)
     if threads < 1:      # GPU extension (as ./word2bits -threads 0): as many workers as fill the device for this shape
-        probe = Trainer(2, size, window, negative, bitlevel, 1, iter, alpha, sample, reg, corpus.train_words, True,
-                        device, relaxed_coherence=relaxed_coherence, window_cache=window_cache, exact=exact)
+        probe = Trainer(corpus.vocab_size, size, window, negative, bitlevel, 1, iter, alpha, sample, reg, corpus.train_words,
+                        True, device, relaxed_coherence=relaxed_coherence, window_cache=window_cache, exact=exact)
+        probe.set_vocab_counts(corpus.counts(), 0)     # the kernel choice (and the fill) depends on the word counts
         threads = probe.suggested_threads()
         probe.close()
     t = Trainer(corpus.vocab_size, size, window, negative, bitlevel, threads, iter, alpha, sample, reg,
