@@ -602,15 +602,17 @@ def main():
     result["roofline"]["algorithmic_bytes_per_launch"] = words_per_step * bpw
     # HBM bytes per launch from the counters: collected by tools/gpu_profile_session.sh with rocprofv3 --pmc (separate
     # FETCH_SIZE / WRITE_SIZE passes of this same command) and committed; quoted only for the shape they were measured on
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.form)
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % args.form)
     if world == 1 and os.path.exists(pmc) and args.ids == "zipf" and not args.relaxed:
         try:
             pj = json.load(open(pmc))
-            same = (pj.get("vocab"), pj.get("dim"), pj.get("negative"), pj.get("bitlevel")) == (V, D, K, args.bitlevel)
+            same = (pj.get("vocab"), pj.get("dim"), pj.get("negative"), pj.get("bitlevel")) == (V, D, K, args.bitlevel) and \
+                pj.get("kernel") == result["roofline"]["kernel"]
             if same and pj.get("words_per_launch"):
                 per_word = pj["hbm_bytes_per_launch"] / pj["words_per_launch"]
                 result["roofline"]["traffic"] = per_word * words_per_step
                 result["roofline"]["traffic_GBps"] = per_word * words_per_step / avg_launch_s / 1e9
+                result["roofline"]["traffic_frac"] = per_word * words_per_step / avg_launch_s / HBM_PEAK
                 result["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
                                                         "passes, FETCH x2 gfx950 correction) on this command, %d centre "
                                                         "words per launch there" %

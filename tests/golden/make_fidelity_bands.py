@@ -2,7 +2,7 @@
 (oracle/_ref/word2bits_stock, built from /root/reference by oracle/Makefile; the binary travels to the GPU box) does
 with N truly concurrent threads.
 
-The round-2 bands (make_fidelity_golden*.py) were recorded in the 8-vCPU build container, where 64 or 512 threads are
+The round-2 bands were recorded in the 8-vCPU build container, where 64 or 512 threads are
 time-sliced: each thread runs alone for milliseconds, which is far less concurrent than 64 workgroups of a GPU.  This
 script is meant to run on the GPU box's HOST (2 x EPYC 9575F, 256 hardware threads; `gpurun -- python
 tests/golden/make_fidelity_bands.py --out gpurun_out/bands.json ...`), so that "the same thread count" also means the

@@ -89,6 +89,11 @@ def test_top1_bit_exact_on_seeded_inputs(gpu, kind, V, D, Q, fused, tmp_path):
     want, wd = om.top1(*b)
     assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
     assert same_floats(gd, wd)
+    if fused:              # the same fused chain on the vector ALU (w2b_eval_set_kernel 0): a cross-check of the MFMA path
+        ev.set_kernel(0)
+        got0, gd0 = ev.top1(*b)
+        assert np.array_equal(got0, want) and same_floats(gd0, wd)
+        ev.set_kernel(1)
     if kind != "fp":
         # the fixture really is tie-dominated: the best score is shared by several rows for most questions
         q = 0

@@ -1,20 +1,23 @@
 """-m gpu: Hogwild fidelity of the kernels users actually run (SURVEY 8c rung 6).
 
-With several workers nothing is bit-reproducible -- not in the reference either -- so these tests hold the HIP trainer
-to what the UNMODIFIED reference program does with the SAME number of Hogwild threads on the same corpus:
-`tests/golden/fidelity_golden.json` (planted-analogy corpus; generator make_fidelity_golden.py) and
-`tests/golden/fidelity_text8size.json` (17 M-token text8-sized corpus; make_fidelity_golden_text8size.py) record its
-per-epoch "Epoch Loss" values and, for the planted corpus, the total accuracy printed by the unmodified evaluator, over
-several runs per thread count.  Asserted here, per worker count:
-  * every epoch loss of `./word2bits` (default kernel = sentence-resident, coherent rows) within LOSS_RTOL[workers] of
-    the mean of the reference's runs with that many threads, and within RESIDENT_VS_PLAIN_RTOL of the plain worker kernel;
-  * total accuracy (scored by ./compute_accuracy, whose transcript must equal the unmodified evaluator's byte for byte
-    when oracle/_ref is present) inside the reference's own band widened by ACC_MARGIN points.
-The thread count matters as much as the implementation (the reference's own last-epoch loss moves from -401 K to -395 K to
--383 K between 8, 64 and 512 threads on the planted corpus, its accuracy from 44 % to 49 % to 77 %: each thread
-re-computes alpha only after 10 000 of its own words), so the comparison is always at equal counts.
-BASELINE configs[2] (text8, bitlevel 2, size 400, negative 24, iter 5 + compute-accuracy parity) is covered at its own
-shape on the planted corpus -- text8 and questions-words.txt are not available offline."""
+With several workers nothing is bit-reproducible -- not in the reference either -- so these tests hold `./word2bits`
+to what the UNMODIFIED reference program does with the SAME number of truly concurrent threads on the same corpus:
+`tests/golden/fidelity_bands.json`, recorded by tests/golden/make_fidelity_bands.py on the GPU box's HOST (2 x EPYC
+9575F, 256 hardware threads -- round 2's bands came from an 8-core container that time-slices 64 threads), 2-3 runs
+per thread count:
+  planted_*   planted-analogy corpus (564 K tokens), bitlevel 1 size 200 and BASELINE configs[2] shape (bitlevel 2, size
+              400, negative 24, iter 5), 8 / 64 / 512 threads, scored by the unmodified evaluator
+  text8size   17 M Zipf tokens over 70 K words, bitlevel 1 size 200 (BASELINE configs[0] shape), 3 epochs, 64 / 256 threads
+  headline    the BENCHMARKED regime, BASELINE configs[1]: V = 400 K, size 800, window 8, negative 24, bitlevel 1,
+              -sample 0, 22 M tokens (every word 5x + a 20 M-token Zipf(1) stream), 64 / 256 threads
+
+Every tolerance is  max(3 sigma of the reference's own runs at that thread count, FLOOR[regime])  per epoch -- the
+reference's run-to-run spread, not the product's measured value.  The reference is extremely repeatable (sigma 0.01-0.4 %
+of an epoch loss), so the floors decide; they are stated per regime below with what round 3 measured, and DESIGN.md
+section 6 has the full matrix (kernels x worker counts x hot-row / atomic / exchange knobs) they were read from.
+Accuracy is asserted inside the reference's band widened by max(2 points, 3 sigma).
+The product's `./compute_accuracy` transcript must equal the unmodified evaluator's byte for byte on every trained file.
+text8 and questions-words.txt are not available offline; the planted corpus stands in for them."""
 import json
 import os
 import re
@@ -29,28 +32,40 @@ from planted import make_planted, parse_accuracy
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(ROOT, "word2bits")
 EVAL = os.path.join(ROOT, "compute_accuracy")
-GOLD = json.load(open(os.path.join(GOLDEN, "fidelity_golden.json")))
+BANDS = json.load(open(os.path.join(GOLDEN, "fidelity_bands.json")))["jobs"]
 
-# Tolerances, calibrated on MI355X against the committed reference runs (values of round 2 in DESIGN.md section 6):
-#  * up to 8 workers both kernels track the reference's epoch losses within 1 %;
-#  * at 64 workers on this 3 310-word, 564 K-token corpus (8 800 words per worker and epoch) a GPU really runs 64 workers at
-#    once where the 8-core host that produced the bands time-slices 64 threads: the plain kernel's first epoch is 5 %
-#    off and the later ones < 2 %; the sentence-resident kernel (rows stay on chip for up to 17 positions) 8 % / < 4.5 %;
-#    at the cfg2 shape (bitlevel 2, size 400) both kernels end 3-6 % BETTER than the reference's 64-thread losses.
-#  * total accuracy on this corpus moves by several points from run to run on either side (reference: 42.0-47.0 % over
-#    1 / 8 / 64 threads; HIP at 8 workers: 41.3-50.3 % over the runs of this round), hence the wide margin.
-LOSS_RTOL = {8: (0.02, 0.02), 64: (0.09, 0.08)}        # workers -> (first epoch, later epochs), vs the reference mean
-RESIDENT_VS_PLAIN_RTOL = 0.045                         # sentence-resident vs plain worker kernel, same worker count
-ACC_MARGIN = 8.0                                       # points of total accuracy around the reference's [min, max] band
+# Floors of the per-epoch loss tolerance (fraction of the reference's mean), by regime.  What they cover: a GPU worker
+# has a chunk of 13 rows in flight for ~10 us between load and store, dozens to hundreds of workers at once; the
+# reference's thread has ONE row open for ~0.1 us.  Updates that the reference applies one after the other are here
+# computed from the same stale row and then either lost (plain stores), averaged (hot rows) or
+# summed (atomic rows) -- none of which is the reference's sequence.  Measured in round 3 (gpurun_out/r03*/):
+FLOOR = {
+    # planted corpus, bitlevel 1: 8 workers -1.0 ... +0.1 %; 64 workers (every row updated atomically: small flat
+    # vocabulary) -1.05 ... +0.3 %
+    "planted_b1_d200": 0.015,
+    # planted corpus, 2 bits, size 400: 8 workers -0.2 ... +1.9 %; 64 workers -1.0 ... -2.9 % (without the atomic
+    # updates: +4 ... +6 %)
+    "planted_cfg2_b2_d400": 0.035,
+    # text8-sized corpus (default -sample 1e-3): 64 workers <= 0.36 %, 256 workers <= 0.9 %, 850 workers (-threads 0) <= 1 %
+    "text8size": 0.015,
+    # benchmarked regime (-sample 0: the ten most frequent words are a third of all context positions): -threads 0
+    # (1024 workers) +1.0 %, 512 -1.3 %, 256 -2.7 %, 64 -2.1 %
+    "headline": 0.035,
+}
+ACC_POINTS = 2.0
 
 
-@pytest.fixture(scope="module")
-def planted(tmp_path_factory):
-    d = tmp_path_factory.mktemp("planted")
-    corpus, questions = str(d / "planted.txt"), str(d / "questions.txt")
-    ntok = make_planted(corpus, questions, repeats=120)
-    assert ntok == GOLD["corpus"]["tokens"]
-    return corpus, questions, d
+def band(job, threads):
+    runs = [r for r in BANDS[job]["runs"] if r["threads"] == threads]
+    assert len(runs) >= 2
+    L = np.array([r["epoch_losses"] for r in runs])
+    acc = np.array([r["accuracy"]["total"] for r in runs]) if "accuracy" in runs[0] else None
+    return L.mean(0), L.std(0, ddof=1), acc
+
+
+def loss_tolerance(job, threads):
+    mean, std, _ = band(job, threads)
+    return np.maximum(3 * std, FLOOR[job] * np.abs(mean))
 
 
 def train(corpus, out, threads, flags, extra=()):
@@ -59,7 +74,8 @@ def train(corpus, out, threads, flags, extra=()):
         args += ["-" + k, str(v)]
     r = subprocess.run(args + list(extra), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-300:] + r.stderr[-300:]
-    return [float(x) for x in re.findall(r"Epoch Loss: (-?[\d.]+)", r.stdout)]
+    w = re.search(r"Hogwild workers \(workgroups\): (\d+)", r.stdout)
+    return np.array([float(x) for x in re.findall(r"Epoch Loss: (-?[\d.]+)", r.stdout)]), (int(w.group(1)) if w else threads), r.stderr
 
 
 def score(vec, questions):
@@ -73,104 +89,111 @@ def score(vec, questions):
     return parse_accuracy(got.decode())
 
 
-def reference_band(config, threads):
-    runs = [r for r in GOLD["configs"][config]["runs"] if r["threads"] == threads]
-    assert runs
-    losses = np.array([r["epoch_losses"] for r in runs])
-    acc = [r["accuracy"]["total"] for r in runs]
-    return losses.mean(axis=0), min(acc), max(acc)
+def check_losses(tag, job, ref_threads, losses):
+    mean, std, _ = band(job, ref_threads)
+    tol = loss_tolerance(job, ref_threads)
+    dev = 100 * (losses - mean) / np.abs(mean)
+    print("FIDELITY %s: losses %s | reference @%d threads %s (3 sigma %s %%) | deviation %s %% (allowed %s %%)" %
+          (tag, np.round(losses).tolist(), ref_threads, np.round(mean).tolist(), np.round(300 * std / np.abs(mean), 2).tolist(),
+           np.round(dev, 2).tolist(), np.round(100 * tol / np.abs(mean), 2).tolist()))
+    assert len(losses) == len(mean)
+    assert np.all(np.abs(losses - mean) <= tol), (tag, dev.tolist())
 
 
-def check_against_reference(config, threads, planted, label=""):
+@pytest.fixture(scope="module")
+def planted(tmp_path_factory):
+    d = tmp_path_factory.mktemp("planted")
+    corpus, questions = str(d / "planted.txt"), str(d / "questions.txt")
+    ntok = make_planted(corpus, questions, repeats=120)
+    assert ("%d tokens" % ntok) in BANDS["planted_b1_d200"]["corpus"]
+    return corpus, questions, d
+
+
+@pytest.mark.parametrize("job,threads", [("planted_b1_d200", 8), ("planted_b1_d200", 64),
+                                         ("planted_cfg2_b2_d400", 8), ("planted_cfg2_b2_d400", 64)])
+def test_planted_matches_reference_at_equal_thread_count(gpu, planted, job, threads):
+    """epoch losses and total accuracy of both worker kernels against the reference at the same thread count;
+    planted_cfg2_b2_d400 is BASELINE configs[2]'s shape (bitlevel 2, size 400, negative 24, iter 5) with its
+    compute-accuracy parity"""
     corpus, questions, d = planted
-    flags = GOLD["configs"][config]["flags"]
-    want, acc_lo, acc_hi = reference_band(config, threads)
-    res = {}
-    for name, extra in (("resident", ["-window-cache", "1"]), ("plain", ["-window-cache", "0"])):
-        out = str(d / ("%s_%s_%d.bin" % (config, name, threads)))
-        losses = train(corpus, out, threads, flags, extra)
+    flags = BANDS[job]["flags"]
+    _, _, acc_ref = band(job, threads)
+    margin = max(ACC_POINTS, 3 * float(acc_ref.std(ddof=1)))
+    for kernel, extra in (("resident", ["-window-cache", "1"]), ("plain", ["-window-cache", "0"])):
+        out = str(d / ("%s_%s_%d.bin" % (job, kernel, threads)))
+        losses, _, _ = train(corpus, out, threads, flags, extra)
         acc = score(out, questions)
         assert acc["seen"] == acc["questions"] == 7728
-        res[name] = (np.array(losses), acc["total"])
-        print("FIDELITY %s threads=%d %s: losses %s acc %.2f | reference mean %s acc band [%.2f, %.2f]" %
-              (config, threads, name, np.round(losses).tolist(), acc["total"], np.round(want).tolist(), acc_lo, acc_hi))
-    first, later = LOSS_RTOL[threads]
-    tol = np.array([first] + [later] * (len(want) - 1))
-    for name, (losses, acc) in res.items():
-        assert len(losses) == len(want)
-        assert np.all(np.abs(losses - want) <= tol * np.abs(want)), (name, losses.tolist(), want.tolist())
-        assert acc_lo - ACC_MARGIN <= acc <= acc_hi + ACC_MARGIN, (name, acc, acc_lo, acc_hi)
-    r, p = res["resident"][0], res["plain"][0]
-    assert np.all(np.abs(r - p) <= RESIDENT_VS_PLAIN_RTOL * np.abs(p)), (r.tolist(), p.tolist())
+        print("FIDELITY %s threads=%d %s: accuracy %.2f | reference %s +- %.1f" %
+              (job, threads, kernel, acc["total"], acc_ref.tolist(), margin))
+        check_losses("%s threads=%d %s" % (job, threads, kernel), job, threads, losses)
+        assert acc_ref.min() - margin <= acc["total"] <= acc_ref.max() + margin, (kernel, acc["total"], acc_ref.tolist())
 
 
-@pytest.mark.parametrize("threads", [8, 64])
-def test_planted_1bit_matches_reference_at_equal_thread_count(gpu, planted, threads):
-    """bitlevel 1, size 200, window 8, negative 24, iter 5 (BASELINE configs[0] shape, 5 epochs)"""
-    check_against_reference("b1_d200", threads, planted)
-
-
-@pytest.mark.parametrize("threads", [8, 64])
-def test_cfg2_shape_2bit_d400_accuracy_parity(gpu, planted, threads):
-    """BASELINE configs[2] shape: bitlevel 2, size 400, negative 24, iter 5 -- epoch losses and compute-accuracy
-    parity against the reference CPU program at the same thread count"""
-    check_against_reference("cfg2_b2_d400", threads, planted)
-
-
-def test_planted_512_workers_bounded(gpu, planted):
-    """512 workers on a 564 K-token corpus is a regime `-threads 0` never selects (1 100 words per worker: alpha is
-    never re-computed, ref :379-393) -- the reference's own 512-thread runs train at the starting alpha for all five
-    epochs (last-epoch loss -383 K against -402 K with 8 threads, accuracy 77 % against 44 %).  A GPU runs the 512
-    workers truly concurrently on 3 310 rows where the 8-core reference host time-slices them, so only the end state
-    is bounded: last-epoch loss within 15 % of the reference's 512-thread mean, every epoch better than the one before."""
+def test_more_workers_than_the_corpus_supports_is_warned_about(gpu, planted):
+    """512 workers on a 564 K-token corpus leaves 1 100 words per worker and epoch: alpha (re-computed per worker every
+    10 000 words, ref :379-393) never moves.  The reference accepts that silently (its own 512-thread runs end 4 % off its
+    8-thread ones, and diverge at bitlevel 2); `-threads 0` never picks such a count, and an explicit one is accepted with
+    a warning.  The run itself is only bounded: bitlevel 1, plain kernel, epoch losses within 2 x the planted floor of the
+    reference's 512-thread runs (measured: -1.3 % / +0.7 %)."""
     corpus, questions, d = planted
-    flags = GOLD["configs"]["b1_d200"]["flags"]
-    want, acc_lo, acc_hi = reference_band("b1_d200", 512)
-    for name, extra in (("resident", ["-window-cache", "1"]), ("plain", ["-window-cache", "0"])):
-        out = str(d / ("w512_%s.bin" % name))
-        losses = np.array(train(corpus, out, 512, flags, extra))
-        acc = score(out, questions)["total"]
-        print("FIDELITY b1_d200 threads=512 %s: losses %s acc %.2f | reference mean %s acc band [%.2f, %.2f]" %
-              (name, np.round(losses).tolist(), acc, np.round(want).tolist(), acc_lo, acc_hi))
-        assert abs(losses[-1] - want[-1]) <= 0.15 * abs(want[-1]), (name, losses.tolist(), want.tolist())
-        assert np.all(np.diff(losses) > 0), (name, losses.tolist())
+    flags = BANDS["planted_b1_d200"]["flags"]
+    losses, _, err = train(corpus, str(d / "w512.bin"), 512, flags, ["-window-cache", "0"])
+    assert "warning: -threads 512" in err and "-threads 0 picks at most" in err
+    mean, _, _ = band("planted_b1_d200", 512)
+    dev = (losses - mean) / np.abs(mean)
+    print("FIDELITY planted_b1_d200 threads=512 plain: deviation %s %%" % np.round(100 * dev, 2).tolist())
+    assert np.all(np.abs(dev) <= 2 * FLOOR["planted_b1_d200"])
+    losses8, _, err8 = train(corpus, str(d / "w8.bin"), 8, dict(flags, iter=1), [])
+    assert "warning" not in err8
 
 
-def test_text8_size_threads0_resident_vs_plain_vs_reference(gpu, tmp_path_factory):
-    """17 M tokens, 70 K words, bitlevel 1, size 200, window 8, negative 24, 3 epochs with `-threads 0` (as many workers as
-    the GPU holds, capped at train_words / 20000): the default (sentence-resident) kernel against the plain coherent
-    kernel and against the unmodified reference program's epoch losses on the same file."""
+@pytest.fixture(scope="module")
+def text8size(tmp_path_factory):
     from w2b_testlib import write_zipf_text_corpus
-    gold = json.load(open(os.path.join(GOLDEN, "fidelity_text8size.json")))
     d = tmp_path_factory.mktemp("t8")
-    corpus = write_zipf_text_corpus(str(d / "c.txt"))
-    flags = dict(bitlevel=1, size=200, window=8, negative=24, iter=3)
-    res = {}
-    for name, extra in (("resident", ["-window-cache", "1"]), ("plain", ["-window-cache", "0"])):
-        res[name] = np.array(train(corpus, str(d / "o.bin"), 0, flags, extra))
-        print("FIDELITY text8size threads=0 %s: %s | reference (%d threads) %s" %
-              (name, np.round(res[name]).tolist(), gold["threads"], np.round(gold["epoch_losses"]).tolist()))
-    want = np.array(gold["epoch_losses"])
-    # 850 concurrent workers against the reference's 8 threads.  Measured: plain kernel -57.5 / -54.3 / -53.4 M, sentence-
-    # resident kernel with its (at most four) private hot target rows merged every 8 steps about -60 / -55.5 / -54 M,
-    # reference -59.0 / -55.6 / -54.7 M.  (The window rows cost nothing here: with W2B_HOT_ROWS=0 the resident kernel
-    # reproduces the plain kernel's losses; what moves the first epoch is the merge period of the private hot rows --
-    # -64 M at 32 steps, -59 M at 4 -- see DESIGN.md section 6.)
-    tol = np.array([0.05, 0.03, 0.03])
-    for name, losses in res.items():
-        assert np.all(np.abs(losses - want) <= tol * np.abs(want)), (name, losses.tolist(), want.tolist())
-    assert np.all(np.abs(res["resident"] - res["plain"]) <= np.array([0.07, 0.035, 0.025]) * np.abs(res["plain"]))
+    return write_zipf_text_corpus(str(d / "c.txt")), d
 
 
-def test_text8_size_window_residency_alone_is_loss_neutral(gpu, tmp_path_factory):
-    """same corpus, 128 workers, private hot rows switched off: what remains of the sentence-resident kernel (LDS window,
-    scratch entries, exact-or-merge write-back) must give the plain kernel's epoch losses (measured: -58.667 M vs
-    -58.675 M in the first epoch)"""
-    from w2b_testlib import write_zipf_text_corpus
-    d = tmp_path_factory.mktemp("t8b")
-    corpus = write_zipf_text_corpus(str(d / "c.txt"))
-    flags = dict(bitlevel=1, size=200, window=8, negative=24, iter=1)
-    r = np.array(train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "1", "-hot-rows", "0"]))
-    p = np.array(train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "0", "-hot-rows", "0"]))
+@pytest.mark.parametrize("threads,ref_threads,kernels", [(64, 64, ("resident", "plain")), (256, 256, ("resident", "plain")),
+                                                         (0, 256, ("auto",))])
+def test_text8_size_matches_reference(gpu, text8size, threads, ref_threads, kernels):
+    """17 M tokens, 70 K words, bitlevel 1, size 200, window 8, negative 24, 3 epochs: equal thread counts (64, 256), and
+    `-threads 0` -- as many workers as the GPU holds, 850 here -- against the most threads the host can run at once"""
+    corpus, d = text8size
+    flags = BANDS["text8size"]["flags"]
+    for kernel in kernels:
+        extra = {"resident": ["-window-cache", "1"], "plain": ["-window-cache", "0"], "auto": []}[kernel]
+        losses, workers, _ = train(corpus, str(d / "o.bin"), threads, flags, extra)
+        check_losses("text8size threads=%d (%d workers) %s" % (threads, workers, kernel), "text8size", ref_threads, losses)
+
+
+def test_text8_size_window_residency_alone_is_loss_neutral(gpu, text8size):
+    """same corpus, 128 workers, no hot-row copies: what remains of the sentence-resident kernel (LDS window, scratch
+    entries, exact-or-merge write-back) must give the plain kernel's epoch loss (measured: -58.58 M vs -58.62 M)"""
+    corpus, d = text8size
+    flags = dict(BANDS["text8size"]["flags"], iter=1)
+    r, _, _ = train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "1", "-hot-rows", "0"])
+    p, _, _ = train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "0", "-hot-rows", "0"])
     print("FIDELITY text8size threads=128 hot rows off: resident %s plain %s" % (r.tolist(), p.tolist()))
     assert np.all(np.abs(r - p) <= 0.005 * np.abs(p))
+
+
+@pytest.fixture(scope="module")
+def headline(tmp_path_factory):
+    from w2b_testlib import write_headline_corpus
+    d = tmp_path_factory.mktemp("hl")
+    corpus = write_headline_corpus(str(d / "c.txt"))
+    yield corpus, d
+    os.remove(corpus)
+
+
+@pytest.mark.parametrize("threads,ref_threads", [(0, 256), (256, 256), (64, 64)])
+def test_benchmarked_regime_matches_reference(gpu, headline, threads, ref_threads):
+    """BASELINE configs[1] -- what bench.py times: V = 400 K, size 800, window 8, negative 24, bitlevel 1, -sample 0, with
+    the defaults bench.py runs (`-threads 0`: the kernel and the hot rows the library derives from the word counts), and
+    at the reference's own thread counts."""
+    corpus, d = headline
+    flags = BANDS["headline"]["flags"]
+    losses, workers, _ = train(corpus, "/dev/null", threads, flags)
+    check_losses("headline threads=%d (%d workers)" % (threads, workers), "headline", ref_threads, losses)

@@ -283,7 +283,7 @@ def write_zipf_text_corpus(path, vocab=70000, n_tokens=17_000_000, seed=0, line=
     """A text8-SIZED stand-in (text8 itself is not available offline): n_tokens Zipf(1) draws over `vocab` words
     'w<id>', one line of `line` tokens each (text8 is a single line; the reference cuts sentences at 1000 tokens
     anyway, ref :410).  Deterministic for a given numpy version; used by the fidelity tests and by the script that
-    records what the unmodified reference does on the same file (tests/golden/make_fidelity_golden.py)."""
+    records what the unmodified reference does on the same file (tests/golden/make_fidelity_bands.py)."""
     rng = np.random.default_rng(seed)
     ids = zipf_ids(rng, vocab, n_tokens)
     words = np.array([b"w%d" % i for i in range(vocab)], dtype=object)

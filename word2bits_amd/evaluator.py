@@ -76,6 +76,10 @@ class Evaluator:
         finally:
             self._L.w2b_eval_free_text(out)
 
+    def set_kernel(self, variant):
+        """1 = f32 MFMA kernel (default), 0 = the same fused chain on the vector ALU (cross-check)"""
+        _lib.check(self._L.w2b_eval_set_kernel(self._h, int(variant)))
+
     def timing(self):
         """(kernel ms, launches, multiply-adds) of the score kernel since the last call."""
         ms, n, macs = C.c_double(), C.c_int64(), C.c_double()
