@@ -233,11 +233,12 @@ int w2b_comm_unique_id(void *out128);                      /* rank 0 creates, ot
  * creates no communicator (w2b_sync_replicas is then a no-op); with an id a communicator of size 1 is created and the
  * whole exchange path runs (a way to exercise it on a one-GPU machine; the model stays bit-identical). */
 int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id128);
-/* mode 0: delta-sum (a = 1);  mode 1: average of the deltas (a = 1/R);  mode 2: contributor average -- a row's summed
- * delta is divided by the number of replicas that changed the row since the last exchange, so a row only one replica
- * trained keeps its full update and a row all of them trained moves by their mean (what ./word2bits -gpus N uses: with
- * mode 0 the R stale updates every replica makes to the frequent rows add up, with mode 1 rare rows learn R times too
- * slowly; measured in tests/test_gpu_exchange.py).  Asynchronous (see above). */
+/* mode 0: delta-sum (a = 1);  mode 1: average of the deltas (a = 1/R);  mode 2 (what ./word2bits -gpus N uses): delta-sum,
+ * except that SATURATED rows -- rows that have been updated more than a few dozen times in every replica since the last
+ * exchange, so that each replica's delta is already most of the way -- take 1/sqrt(c) of the sum of the c replicas that
+ * changed them (the sum of c such deltas over-shoots c-fold: mode 0 diverges with 4 replicas on the text8-sized corpus;
+ * their mean, mode 1, throws all but one replica's work away).  The more often the replicas exchange, the fewer rows are
+ * saturated.  Measured in tests/test_gpu_exchange.py.  Asynchronous (see above). */
 int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
 /* exchanges since the last call and their summed device time (begin of the first chunk -> end of the last; waits for
  * the exchanges in flight); resets both */
@@ -246,8 +247,8 @@ int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
 /* The same exchange for hosts that bring their own collective (MPI, torch.distributed over gloo or RCCL, ...):
  *   w2b_exchange_init once, while all replicas hold the same model; then per exchange
  *   w2b_exchange_begin(&n_chunks, &my_words)
- *   (contributor average only) w2b_exchange_counts(&cnt, &m): cnt[0..m) = 1 for every row of [u||v] this replica changed;
- *                            the host sums cnt over the replicas in place; w2b_exchange_apply then divides by it
+ *   (mode 2 only) w2b_exchange_counts(&cnt, &m): cnt[0..m) = 1 for every row of [u||v] this replica changed;
+ *                            the host sums cnt over the replicas in place; w2b_exchange_apply then damps the saturated rows with it
  *   for c in [0, n_chunks): w2b_exchange_delta(c, &buf, &n)   -- buf[0..n) = this replica's delta (device memory, complete
  *                            on return);  the host sums buf over all replicas IN PLACE with its collective;
  *                           w2b_exchange_apply(c, a)          -- expects the sum to be complete

@@ -24,11 +24,15 @@ from w2b_testlib import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def small_setup(nw, total, offset, seed=3, V=3000, D=64, n=60000, **kw):
+def small_counts(seed=3, V=3000, n=60000):
     rng = np.random.default_rng(seed)
     ids = (rng.zipf(1.3, n) % (V - 1) + 1).astype(np.int32)
     ids[49::50] = 0
-    counts = np.maximum(np.bincount(ids, minlength=V), 1).astype(np.int64)
+    return ids, np.maximum(np.bincount(ids, minlength=V), 1).astype(np.int64)
+
+
+def small_setup(nw, total, offset, seed=3, V=3000, D=64, n=60000, **kw):
+    ids, counts = small_counts(seed, V, n)
     t = w2b.Trainer(V, D, 5, 5, 1, num_threads=nw, iter=1, sample=0.0, train_words=int(counts.sum()),
                     compute_loss=True, worker_offset=offset, total_threads=total, **kw)
     t.init_net()
@@ -40,6 +44,26 @@ def small_setup(nw, total, offset, seed=3, V=3000, D=64, n=60000, **kw):
 
 def flat(t):
     return np.concatenate([x.ravel() for x in t.get_model()])
+
+
+def saturated_rows(counts, words, window, negative):
+    """the library's rule for mode 2 restated (w2b_trainer.cpp xchg_saturated): per table, rows 1..n with n the result of
+    the same binary search over `rate x words >= 32` (the vocabulary is meant to be sorted by count)"""
+    c = counts.astype(np.float64)
+    pw, tot = (c ** 0.75).sum(), c.sum()
+    rate = {"v": negative * c ** 0.75 / pw + c / tot, "u": (window + 1) * c / tot}
+    V = len(c)
+    out = np.zeros(2 * V, bool)
+    for tab, off in (("u", 0), ("v", V)):
+        lo, hi = 0, V - 1
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if rate[tab][mid] * words >= 32.0:
+                lo = mid
+            else:
+                hi = mid - 1
+        out[off + 1:off + lo + 1] = True
+    return out
 
 
 def test_size_one_communicator_runs_the_whole_exchange_and_changes_nothing(gpu):
@@ -100,8 +124,8 @@ def local_exchange(ts, mode=0):
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_phase_api_arithmetic_two_replicas(gpu, mode):
-    """W_r += a * sum - d_r on top of the CURRENT rows, base += a * sum (a = 1, 1/R, or per row 1 / number of replicas
-    that changed the row): against host arithmetic on copies of both replicas."""
+    """W_r += a * sum - d_r on top of the CURRENT rows, base += a * sum (a = 1; 1/R; or 1 / sqrt(number of replicas that
+    changed the row) for the saturated rows and 1 for the others): against host arithmetic on copies of both replicas."""
     R, nw = 2, 4
     ts = [small_setup(nw, R * nw, r * nw, seed=3) for r in range(R)]
     for t in ts:
@@ -118,7 +142,9 @@ def test_phase_api_arithmetic_two_replicas(gpu, mode):
         d = [m - base for m in mine]
         if mode == 2:
             c = sum((x.reshape(V2, D) != 0).any(1).astype(np.float32) for x in d)
-            a = (np.float32(1) / np.maximum(c, 1))[:, None].repeat(D, 1).ravel()
+            sat = saturated_rows(small_counts(3)[1], 3 * 150 * nw, 5, 5)   # 3 launches x 150 positions x nw workers
+            assert sat.any() and not sat.all() and c[sat].max() == 2
+            a = np.where(sat, np.float32(1) / np.sqrt(np.maximum(c, 1)), np.float32(1)).astype(np.float32)[:, None].repeat(D, 1).ravel()
         else:
             a = np.float32(1.0 if mode == 0 else 1.0 / R)
         total = a * (d[0] + d[1])

@@ -121,5 +121,5 @@ hipError_t w2b_launch_wca_unpack(W2bShared *sh, const unsigned long long *buf, h
 hipError_t w2b_launch_xchg_delta(float *w, const float *base, float *d, float *s_, long long n, hipStream_t s);
 hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n,
                                  const float *cnt /* per-row contributor counts or nullptr */, long long first, int dim,
-                                 hipStream_t s);
+                                 long long V, int hot_u, int hot_v, hipStream_t s);
 hipError_t w2b_launch_xchg_touched(const float *w, const float *base, float *cnt, long long rows, int dim, hipStream_t s);

@@ -68,19 +68,26 @@ __global__ void k_xchg_delta(float *w, const float *__restrict__ base, float *__
 // s now holds the sum over all replicas.  What the OTHER replicas added, a * s - d (a = 1: delta-sum, a = 1 / replicas:
 // average of the deltas), goes on top of the rows as they are NOW -- whatever this replica has trained since the delta
 // was taken stays -- and base becomes the common state base + a * s.  Elements nobody else touched are not written.
-// cnt (optional): per ROW of [u || v], how many replicas have changed the row since the last exchange; then a is divided
-// by it -- the sum of a row's deltas is shared among the replicas that contributed to it (a row only one replica touched
-// keeps that replica's full delta, a row all of them trained moves by their average).  first = index of w[0] in [u || v].
+// cnt (optional): per ROW of [u || v], how many replicas have changed the row since the last exchange.  Rows 1..sat_u of
+// u and 1..sat_v of v -- the rows that have received so many updates in every replica since the last exchange that each
+// replica's delta is already most of the way to where the row wants to be (w2b_trainer.cpp, xchg_saturated) -- take
+// a / sqrt(cnt) of the summed delta: the sum of c such deltas over-shoots c-fold, their mean wastes all but one replica's
+// work, and the square root is the usual conservative rule for combining c gradient batches.  Every other row keeps
+// the sum: few updates, no saturation, and the sum of the replicas' deltas is what one shared model would have received.
+// first = index of w[0] in [u || v]; V = rows per table.
 __global__ void k_xchg_apply(float *w, float *__restrict__ base, const float *__restrict__ d, const float *__restrict__ s,
-                             float a, long long n, const float *__restrict__ cnt, long long first, int dim) {
+                             float a, long long n, const float *__restrict__ cnt, long long first, int dim, long long V,
+                             int sat_u, int sat_v) {
   const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (int)(n * 4), 0x27000);
   w2b_f4 *b4 = reinterpret_cast<w2b_f4 *>(base);
   const w2b_f4 *d4 = reinterpret_cast<const w2b_f4 *>(d), *s4 = reinterpret_cast<const w2b_f4 *>(s);
   auto scale = [&](long long i) -> float {          // i: float index inside this chunk
     if (!cnt) return a;
-    const float c = cnt[(first + i) / dim];
-    return c > 1.f ? a / c : a;
+    const long long g = (first + i) / dim, r = g >= V ? g - V : g;
+    if (r < 1 || r > (g >= V ? sat_v : sat_u)) return a;
+    const float c = cnt[g];
+    return c > 1.f ? a / sqrtf(c) : a;
   };
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     w2b_f4 sum = s4[i];
@@ -220,8 +227,8 @@ hipError_t w2b_launch_xchg_delta(float *w, const float *base, float *d, float *s
   return hipGetLastError();
 }
 hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n,
-                                 const float *cnt, long long first, int dim, hipStream_t s) {
-  hipLaunchKernelGGL(k_xchg_apply, dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n, cnt, first, dim);
+                                 const float *cnt, long long first, int dim, long long V, int hot_u, int hot_v, hipStream_t s) {
+  hipLaunchKernelGGL(k_xchg_apply, dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n, cnt, first, dim, V, hot_u, hot_v);
   return hipGetLastError();
 }
 hipError_t w2b_launch_xchg_touched(const float *w, const float *base, float *cnt, long long rows, int dim, hipStream_t s) {

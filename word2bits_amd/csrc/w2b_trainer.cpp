@@ -50,6 +50,7 @@ struct w2b_trainer {
   // XCD-shared copies of the hottest rows (XHot in w2b_device.hpp)
   w2b_tuning tune{};            // knobs of include/word2bits_hip.h (defaults set in w2b_trainer_create)
   std::vector<double> rate_v, rate_u;   // [k]: uses of row k + 1 of v (as a target) / of u (as a context row) per centre word
+  std::vector<double> ctx_share;        // [k]: share of the KEPT (sub-sampled) context positions that rows 1..k+1 hold
   std::vector<int64_t> counts;          // vocab[].cn as given to w2b_set_vocab_counts (sorted by count behind row 0)
   double counts_pw = 0, counts_tot = 0; // sum cn^0.75, sum cn
   float *wide_scratch = nullptr;        // process_word_wide: [workgroups][2][dim]
@@ -89,7 +90,10 @@ struct w2b_trainer {
   hipStream_t xs[2] = {nullptr, nullptr};
   float *xd[2] = {nullptr, nullptr}, *xsum[2] = {nullptr, nullptr};   // per slot: own delta / sum over the replicas
   float *xcnt = nullptr;                    // [2 * vocab_size]: replicas that changed each row (contributor-average mode)
-  bool x_use_cnt = false;                   // the exchange in progress divides by xcnt
+  bool x_use_cnt = false;                   // the exchange in progress damps the saturated rows' sums by xcnt
+  int x_sat_u = 0, x_sat_v = 0;             // rows 1..x_sat_* of u / v count as saturated in the exchange in progress
+  long long x_words = 0;                    // centre words this replica can have trained since the previous exchange (launches x
+                                            // positions x workers: the same number on every replica of a symmetric job)
   long long xchunk = 0;                     // floats per chunk
   hipEvent_t x_train = nullptr;             // "the launches issued so far": the exchange streams wait for it
   hipEvent_t x_done[2] = {nullptr, nullptr};     // last operation of the latest exchange on each exchange stream
@@ -494,10 +498,18 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
     const int n = (int)(V - 1 < W2B_XHOT_MAX ? V - 1 : W2B_XHOT_MAX);
     t->rate_v.assign((size_t)(n > 0 ? n : 0), 0.0);
     t->rate_u.assign((size_t)(n > 0 ? n : 0), 0.0);
+    t->ctx_share.assign((size_t)(n > 0 ? n : 0), 0.0);
+    {
+      double acc = 0;
+      for (int k = 0; k < n; k++) { acc += tot_kept > 0 ? kept(k + 1) / tot_kept : 0; t->ctx_share[(size_t)k] = acc; }
+    }
     for (int k = 0; k < n; k++) {
       const double c = (double)cn[k + 1];
-      t->rate_v[k] = (pw > 0 ? t->cfg.negative * pow(c, 0.75) / pw : 0) + (tot_kept > 0 ? kept(k + 1) / tot_kept : 0);
-      t->rate_u[k] = tot_kept > 0 ? (t->cfg.window + 1) * kept(k + 1) / tot_kept : 0;
+      // (raw counts for the choice of the rows: measured on the text8-sized corpus at 256 workers, the larger set that the
+      // raw counts give -- sub-sampling thins exactly these words -- keeps the later epochs within 1 % of the
+      // reference's losses, the set from the kept counts leaves them 2.4 % off)
+      t->rate_v[k] = (pw > 0 ? t->cfg.negative * pow(c, 0.75) / pw : 0) + (tot > 0 ? c / tot : 0);
+      t->rate_u[k] = tot > 0 ? (t->cfg.window + 1) * c / tot : 0;
     }
   }
   if (table_size > 0) {
@@ -666,9 +678,12 @@ static int worker_plan(const w2b_trainer *t) {
     int nu = 0, nv = 0;       // (judged for a full device, so that a probe trainer with one worker decides as the real one will)
     const long long full = 2ll * t->num_cus;
     xhot_plan(t, t->cfg.num_threads > full ? t->cfg.num_threads : full, true, &nu, &nv);
-    double share = 0;
-    for (int k = 0; k < nu && k < (int)t->rate_u.size(); k++) share += t->rate_u[(size_t)k];
-    if (share / (t->cfg.window + 1) > W2B_PLAIN_CTX_SHARE) return -1;
+    const double share = (nu > 0 && nu <= (int)t->ctx_share.size()) ? t->ctx_share[(size_t)nu - 1] : 0.0;
+    // ... where the plain kernel is competitive: long rows and at least as many target rows as two windows' worth of
+    // context rows (measured, Zipf ids without sub-sampling, plain vs sentence-resident, % of the HBM roofline: size 800
+    // negative 24: 71.2 vs 72.7; size 1000 negative 12: 75 vs 92; size 400: 61 vs 71; size 200: 42 vs 58)
+    const bool competitive = t->cfg.layer1_size >= 512 && t->cfg.negative >= 2 * (t->cfg.window + 1);
+    if (competitive && share > W2B_PLAIN_CTX_SHARE) return -1;
   }
   return w2b_resident_plan(t->cfg.layer1_size, t->cfg.window, t->cfg.negative);
 }
@@ -852,6 +867,8 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   // per-XCD copies of the hottest rows: v only for the sentence-resident kernel (its context rows live in LDS)
   if (int rc = xhot_prepare(t, p, t->cfg.num_threads, radius < 0)) return rc;
   if (int rc = wide_prepare(t, p, t->cfg.num_threads)) return rc;
+
+  t->x_words += (long long)max_positions * t->cfg.num_threads;
   HIPCHK(timing_begin(t));
   if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream, t->debug));
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
@@ -1114,10 +1131,11 @@ static int xchg_apply(w2b_trainer *t, long long c, float scale) {
   const long long n = 2 * t->table_elems, o = c * t->xchunk, m = (n - o < t->xchunk) ? n - o : t->xchunk;
   const int k = (int)(c & 1);
   HIPCHK(w2b_launch_xchg_apply(t->uv + o, t->base + o, t->xd[k], t->xsum[k], scale, m, t->x_use_cnt ? t->xcnt : nullptr, o,
-                               t->cfg.layer1_size, t->xs[k]));
+                               t->cfg.layer1_size, t->cfg.vocab_size, t->x_sat_u, t->x_sat_v, t->xs[k]));
   return W2B_OK;
 }
 static int xchg_end(w2b_trainer *t) {
+  t->x_words = 0;
   // x_ev.back() = the end of this exchange: stream 0 waits for stream 1's last operation first
   HIPCHK(hipEventRecord(t->x_done[1], t->xs[1]));
   HIPCHK(hipStreamWaitEvent(t->xs[0], t->x_done[1], 0));
@@ -1127,6 +1145,30 @@ static int xchg_end(w2b_trainer *t) {
   t->sync_count++;
   t->sync_bytes += 2 * t->table_elems * (long long)sizeof(float);
   return W2B_OK;
+}
+
+// Mode 2 of the exchange: which rows are SATURATED -- have been updated so often in this replica since the last exchange
+// (`words` centre words ago) that the replica's delta is no longer a small step.  A row that is a target (v) / a context
+// row (u) of `rate` centre words has received rate x words updates; at alpha = 0.05 a few dozen updates move a row most
+// of the way, so W2B_SAT_UPDATES = 32 of them make it saturated.  The vocabulary is sorted by count: a prefix per table.
+static const double W2B_SAT_UPDATES = 32.0;
+static void xchg_saturated(w2b_trainer *t, long long words) {
+  t->x_sat_u = t->x_sat_v = 0;
+  const long long V = t->cfg.vocab_size;
+  if (t->counts.empty() || t->counts_tot <= 0 || words <= 0) return;
+  auto prefix = [&](bool is_v) -> int {
+    long long lo = 0, hi = V - 1;
+    while (lo < hi) {
+      const long long mid = (lo + hi + 1) / 2;
+      const double c = (double)t->counts[(size_t)mid];
+      const double rate = is_v ? t->cfg.negative * pow(c, 0.75) / t->counts_pw + c / t->counts_tot
+                               : (t->cfg.window + 1) * c / t->counts_tot;
+      if (rate * (double)words >= W2B_SAT_UPDATES) lo = mid; else hi = mid - 1;
+    }
+    return (int)lo;
+  };
+  t->x_sat_u = prefix(false);
+  t->x_sat_v = prefix(true);
 }
 
 extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
@@ -1142,6 +1184,7 @@ extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
   const float scale = mode == 1 ? 1.f / (float)t->nranks : 1.f;
   t->x_use_cnt = mode == 2;
   if (mode == 2) {          // who has trained which row since the last exchange (2 V floats), before the first apply
+    xchg_saturated(t, t->x_words);
     HIPCHK(w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, 2 * t->cfg.vocab_size, t->cfg.layer1_size, t->xs[0]));
     NCCLCHK(ncclAllReduce(t->xcnt, t->xcnt, (size_t)(2 * t->cfg.vocab_size), ncclFloat, ncclSum, t->comm, t->xs[0]));
     HIPCHK(hipEventRecord(t->x_done[0], t->xs[0]));
@@ -1175,6 +1218,7 @@ extern "C" int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *lo
     HIPCHK(hipStreamSynchronize(t->xs[0]));
     *local_word_count = (int64_t)v;
   }
+  xchg_saturated(t, t->x_words);                  // (used when the host asks for w2b_exchange_counts: mode 2)
   return W2B_OK;
 }
 extern "C" int w2b_exchange_counts(w2b_trainer *t, void **buf_dev, int64_t *elems) {
