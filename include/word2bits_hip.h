@@ -235,10 +235,11 @@ int w2b_comm_unique_id(void *out128);                      /* rank 0 creates, ot
 int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id128);
 /* mode 0: delta-sum (a = 1);  mode 1: average of the deltas (a = 1/R);  mode 2 (what ./word2bits -gpus N uses): delta-sum,
  * except that SATURATED rows -- rows that have been updated more than a few dozen times in every replica since the last
- * exchange, so that each replica's delta is already most of the way -- take 1/sqrt(c) of the sum of the c replicas that
- * changed them (the sum of c such deltas over-shoots c-fold: mode 0 diverges with 4 replicas on the text8-sized corpus;
- * their mean, mode 1, throws all but one replica's work away).  The more often the replicas exchange, the fewer rows are
- * saturated.  Measured in tests/test_gpu_exchange.py.  Asynchronous (see above). */
+ * exchange, so that each replica's delta is already most of the way -- move by the MEAN of the deltas of the c replicas
+ * that changed them (the sum of c such deltas over-shoots c-fold: mode 0 diverges with 4 replicas on the text8-sized
+ * corpus), while every other row, in particular a row that only one replica saw, keeps the full sum (mode 1 divides that
+ * by R as well).  The more often the replicas exchange, the fewer rows are saturated.  Measured in
+ * tests/test_gpu_exchange.py.  Asynchronous (see above). */
 int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
 /* exchanges since the last call and their summed device time (begin of the first chunk -> end of the last; waits for
  * the exchanges in flight); resets both */
