@@ -43,28 +43,20 @@ def matrix(job, corpus, flags, cases, refs):
               np.round(100 * (losses - m) / np.abs(m), 2).tolist(), info[0], info[1]), flush=True)
 
 
-jobs = sys.argv[1:] or ["text8size", "headline"]
+jobs = [a for a in sys.argv[1:] if not a.startswith("-")] or ["text8size", "headline"]
+EXTRA = [a for a in sys.argv[1:] if a.startswith("-")]          # e.g. -hot-period=32  ->  "-hot-period 32" on every run
+EXTRA = sum(([a.split("=")[0], a.split("=")[1]] for a in EXTRA), [])
 K = {"resident": ["-window-cache", "1"], "plain": ["-window-cache", "0"], "auto": []}
 if "text8size" in jobs:
     c = write_zipf_text_corpus(os.path.join(TMP, "t8.txt"))
     fl = dict(bitlevel=1, size=200, window=8, negative=24, iter=3)
-    cases = [("text8size threads=0 auto", 0, [], 256),
-             ("text8size threads=0 plain hot-weight=500", 0, K["plain"] + ["-hot-weight", "500"], 256),
-             ("text8size threads=0 plain hot-weight=1000", 0, K["plain"] + ["-hot-weight", "1000"], 256)]
-    matrix("text8size", c, fl, cases, (256,))
+    cases = [("text8size threads=%d %s %s" % (th, k, " ".join(EXTRA)), th, K[k] + EXTRA, ref)
+             for th, ref in ((0, 256), (256, 256), (64, 64)) for k in (("auto",) if th == 0 else ("resident", "plain"))]
+    matrix("text8size", c, fl, cases, (64, 256))
     os.remove(c)
 if "headline" in jobs:
     c = write_headline_corpus(os.path.join(TMP, "hl.txt"))
     fl = dict(bitlevel=1, size=800, window=8, negative=24, iter=1, sample=0)
-    cases = [("headline threads=0 auto", 0, [], 256)]
-    for th, ref in ((512, 256), (256, 256), (64, 64)):
-        cases.append(("headline threads=%d auto" % th, th, [], ref))
-    for name, extra in (("hot-weight=250", ["-hot-weight", "250"]), ("hot-weight=500", ["-hot-weight", "500"]),
-                        ("hot-weight=1000", ["-hot-weight", "1000"]), ("hot-period=2", ["-hot-period", "2"]),
-                        ("hot-period=32", ["-hot-period", "32"]), ("hot-cap=16", ["-hot-cap", "16"]), ("hot-cap=128", ["-hot-cap", "128"])):
-        cases.append(("headline threads=0 plain %s" % name, 0, K["plain"] + extra, 256))
-    for name, extra in (("hot-weight=500", ["-hot-weight", "500"]), ("hot-weight=1000", ["-hot-weight", "1000"])):
-        cases.append(("headline threads=256 plain %s" % name, 256, K["plain"] + extra, 256))
-        cases.append(("headline threads=64 plain %s" % name, 64, K["plain"] + extra, 64))
+    cases = [("headline threads=%d auto %s" % (th, " ".join(EXTRA)), th, EXTRA, ref) for th, ref in ((0, 256), (256, 256), (64, 64))]
     matrix("headline", c, fl, cases, (64, 256))
     os.remove(c)
