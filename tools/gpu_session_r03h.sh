@@ -1,12 +1,9 @@
 #!/bin/bash
-# round 3, session f: exchange mode 2 (sqrt damping of saturated rows), fidelity gates after the rate / policy changes
+# round 3, session h: does a longer hot-row merge period (w2b_tuning.hot_period 8 -> 32) keep the fidelity gates and buy speed?
 set +e
 export TMPDIR=/tmp
-OUT=gpurun_out/r03f
+OUT=gpurun_out/r03h
 mkdir -p $OUT
-echo "== pytest"
-timeout 1500 python -m pytest tests/test_gpu_fidelity.py tests/test_gpu_exchange.py -m gpu -q --no-header -p no:cacheprovider --tb=short -s 2>&1 > $OUT/pytest.txt
-grep -E "FIDELITY|EXCHANGE|passed|failed|^E  |Error|^FAILED" $OUT/pytest.txt | cut -c1-420 | tail -70
 short() { python -c "
 import json,sys
 for l in sys.stdin:
@@ -17,8 +14,14 @@ for l in sys.stdin:
 B="python bench.py --cpu-baseline none --also-relaxed 0 --also-legs 0 --also-shapes 0 --tokens 30000000 --steps 10 --warmup 3"
 run() { name="$1"; shift; timeout 600 $B "$@" 2>$OUT/err.txt | tee -a $OUT/bench_lines.jsonl | short "$name"; }
 echo "== bench"
-run "cfg2 auto"
-run "d200 V60K auto" --dim 200 --vocab 60238
-run "d400 b2 V60K auto" --dim 400 --vocab 60238 --bitlevel 2
-run "cfg5 b1 auto" --vocab 3700000 --dim 1000 --negative 12
+for p in 8 32; do
+  run "cfg2 period $p" --hot-period $p
+  run "cfg2 period $p cap 128" --hot-period $p --hot-cap 128
+  run "d200 period $p" --dim 200 --vocab 60238 --hot-period $p
+  run "d400 b2 period $p" --dim 400 --vocab 60238 --bitlevel 2 --hot-period $p
+  run "cfg5 b1 period $p" --vocab 3700000 --dim 1000 --negative 12 --hot-period $p
+  run "tuples period $p" --form tuples --hot-period $p
+done
+echo "== fidelity with -hot-period 32"
+timeout 900 python tests/experiments/fidelity_matrix.py text8size headline -hot-period=32 2>&1 | tee $OUT/fidelity_period32.txt | cut -c1-250
 echo "== done"
