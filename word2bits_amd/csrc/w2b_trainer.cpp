@@ -207,7 +207,8 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.exact = t->cfg.exact_reduction != 0;
   if (p.exact) p.mem_mode = 0;             // the exact mode exists for coherent rows only
   p.entry = t->entry;
-  p.hot_period = t->tune.hot_period;   // centre words between two merge events of a worker (power of two)
+  p.hot_period = t->tune.hot_period > 0 ? t->tune.hot_period : 8;   // centre words between two merge events of a worker
+                                       // (power of two; 0 = automatic: set per launch in xhot_prepare)
   p.xhot = nullptr;                    // set by xhot_prepare() for the launch that uses the copies
   p.xhot_u = p.xhot_v = 0;
   p.xhot_m = 1;
@@ -247,8 +248,8 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
   t->debug = getenv("W2B_DEBUG") != nullptr;
   t->tune.struct_size = (int32_t)sizeof(w2b_tuning);
   t->tune.hot_rows_v = t->tune.hot_rows_u = -1;
-  t->tune.hot_period = 8;
-  t->tune.hot_cap = 64;
+  t->tune.hot_period = 0;         // automatic
+  t->tune.hot_cap = 128;
   t->tune.force_row_desc = 0;
   t->tune.grid_per_cu = 0;
   t->tune.mem_mode = -1;
@@ -340,8 +341,8 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
     return fail(W2B_EINVAL, "w2b_set_tuning: struct_size does not match this library's w2b_tuning");
   if (in->hot_rows_v < -1 || in->hot_rows_v > W2B_XHOT_MAX || in->hot_rows_u < -1 || in->hot_rows_u > W2B_XHOT_MAX)
     return fail(W2B_EINVAL, "w2b_set_tuning: hot_rows_* must be -1 (automatic) or 0..128");
-  if (in->hot_period < 1 || in->hot_period > 4096 || (in->hot_period & (in->hot_period - 1)) != 0)
-    return fail(W2B_EINVAL, "w2b_set_tuning: hot_period must be a power of two in 1..4096");
+  if (in->hot_period < 0 || in->hot_period > 4096 || (in->hot_period & (in->hot_period - 1)) != 0)
+    return fail(W2B_EINVAL, "w2b_set_tuning: hot_period must be 0 (automatic) or a power of two in 1..4096");
   if (in->hot_cap < 0 || in->hot_cap > W2B_XHOT_MAX) return fail(W2B_EINVAL, "w2b_set_tuning: hot_cap must be 0..128");
   if (in->grid_per_cu < 0 || in->grid_per_cu > 32) return fail(W2B_EINVAL, "w2b_set_tuning: grid_per_cu must be 0..32");
 #ifdef W2B_EXPERIMENTAL_MEMMODES
@@ -791,6 +792,10 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   const long long per_xcd = workers / W2B_NXCD > 0 ? workers / W2B_NXCD : 1;
   const int most = nu > nv ? nu : nv;
   p.xhot_m = (int)((most + per_xcd - 1) / per_xcd);       // every copy of an XCD is merged about once per hot_period steps
+  // Automatic merge period (measured): with 512 and more workers a worker merges every 32 centre words
+  // (benchmarked regime at 1024 workers: +0.06 % of the reference's epoch loss and 75 % of the roofline, against +0.9 % and
+  // 71 % at 8); with fewer workers every 8 (256 workers: -2.9 % at 8, -3.4 % at 32).
+  if (t->tune.hot_period <= 0) p.hot_period = workers >= 512 ? 32 : 8;
   if (fresh) {         // copy == entry (== 0) everywhere: the fold below adopts the master rows
     HIPCHK(hipMemsetAsync(t->xhot, 0, sizeof(float) * need, t->stream));
     t->xhot_nu = nu;
