@@ -129,7 +129,7 @@ typedef struct w2b_tuning {
    * load / modify / store: nothing another worker adds during the ~10 us a chunk of rows is in flight is lost, at the
    * price of more memory time per update.  -1 = automatic: every row when the vocabulary is so small and flat that even
    * its least frequent row is hit by several workers at once (computed from the word counts and the number of
-   * workers), none otherwise; atomic_cap > 0 limits the number of rows. */
+   * workers) and a table is at most 8 MB, none otherwise; atomic_cap > 0 limits the number of rows. */
   int32_t atomic_rank;
   int32_t atomic_cap;
   int32_t hot_weight_permille;   /* weight of one XCD's copy of a hot row when it meets the master row; default 125 (1/8) */

@@ -726,7 +726,8 @@ static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int 
 // -31 %); on Zipf vocabularies they change nothing that matters (the rows that collide are the hot rows, which have
 // their own scheme, and summing the hundreds of stale gradients a hot row collects per window over-shoots) and cost
 // 20-30 % of the throughput.  Automatic therefore means: all rows when even the least frequent row collides
-// (0.6 x workers x rate >= W2B_ATOMIC_LOAD), none otherwise; atomic_cap > 0 limits the number of rows.
+// (0.6 x workers x rate >= W2B_ATOMIC_LOAD) and the tables are cache-sized, none otherwise; atomic_cap > 0 limits the
+// number of rows.
 static const double W2B_ATOMIC_LOAD = 0.25;
 static int atomic_plan(const w2b_trainer *t, long long workers) {
   int wide = 0;
@@ -740,7 +741,11 @@ static int atomic_plan(const w2b_trainer *t, long long workers) {
   else if (!t->counts.empty() && t->counts_pw > 0 && t->counts_tot > 0) {
     const double c = (double)t->counts[(size_t)(V - 1)];           // the least frequent row (counts are sorted)
     const double rate = t->cfg.negative * pow(c, 0.75) / t->counts_pw + c / t->counts_tot;
-    if (0.6 * (double)workers * rate >= W2B_ATOMIC_LOAD) n = V - 1;
+    // ... and the tables are small enough to live in the caches: atomic adds are executed by the memory system, and on
+    // tables that do not fit they cost a multiple of a store (uniform ids over 60 K words x 200 floats: 15 M words/s
+    // instead of 100 M).  8 MB per table covers the corpora where a flat small vocabulary occurs (planted: 1.7 MB).
+    const bool cacheable = (double)V * t->cfg.layer1_size * sizeof(float) <= 8.0e6;
+    if (cacheable && 0.6 * (double)workers * rate >= W2B_ATOMIC_LOAD) n = V - 1;
     if (t->tune.atomic_cap > 0 && n > t->tune.atomic_cap) n = t->tune.atomic_cap;
   }
   return (int)(n < V - 1 ? n : V - 1);
