@@ -57,6 +57,7 @@ if "text8size" in jobs:
 if "headline" in jobs:
     c = write_headline_corpus(os.path.join(TMP, "hl.txt"))
     fl = dict(bitlevel=1, size=800, window=8, negative=24, iter=1, sample=0)
-    cases = [("headline threads=%d auto %s" % (th, " ".join(EXTRA)), th, EXTRA, ref) for th, ref in ((0, 256), (256, 256), (64, 64))]
+    counts = [int(x) for x in os.environ.get("W2B_MATRIX_THREADS", "0,256,64").split(",")]      # 0 = -threads 0
+    cases = [("headline threads=%d auto %s" % (th, " ".join(EXTRA)), th, EXTRA, 64 if 0 < th <= 64 else 256) for th in counts]
     matrix("headline", c, fl, cases, (64, 256))
     os.remove(c)

@@ -797,10 +797,11 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   const long long per_xcd = workers / W2B_NXCD > 0 ? workers / W2B_NXCD : 1;
   const int most = nu > nv ? nu : nv;
   p.xhot_m = (int)((most + per_xcd - 1) / per_xcd);       // every copy of an XCD is merged about once per hot_period steps
-  // Automatic merge period (measured): with 512 and more workers a worker merges every 32 centre words
+  // Automatic merge period (measured): with 768 and more workers a worker merges every 32 centre words
   // (benchmarked regime at 1024 workers: +0.06 % of the reference's epoch loss and 75 % of the roofline, against +0.9 % and
-  // 71 % at 8); with fewer workers every 8 (256 workers: -2.9 % at 8, -3.4 % at 32).
-  if (t->tune.hot_period <= 0) p.hot_period = workers >= 512 ? 32 : 8;
+  // 71 % at 8; 768 workers: -1.4 %); with fewer workers every 8 (512 workers: -1.4 % at 8, -2.5 % at 32; 256 workers: -2.9 %
+  // at 8, -3.4 % at 32).
+  if (t->tune.hot_period <= 0) p.hot_period = workers >= 768 ? 32 : 8;
   if (fresh) {         // copy == entry (== 0) everywhere: the fold below adopts the master rows
     HIPCHK(hipMemsetAsync(t->xhot, 0, sizeof(float) * need, t->stream));
     t->xhot_nu = nu;
