@@ -38,7 +38,7 @@ BANDS = json.load(open(os.path.join(GOLDEN, "fidelity_bands.json")))["jobs"]
 # has a chunk of 13 rows in flight for ~10 us between load and store, dozens to hundreds of workers at once; the
 # reference's thread has ONE row open for ~0.1 us.  Updates that the reference applies one after the other are here
 # computed from the same stale row and then either lost (plain stores), averaged (hot rows) or
-# summed (atomic rows) -- none of which is the reference's sequence.  Measured in round 3 (gpurun_out/r03*/):
+# summed (atomic rows) -- none of which is the reference's sequence.  Measured in round 3 (profiles/r03_sessions/):
 FLOOR = {
     # planted corpus, bitlevel 1: 8 workers -1.0 ... +0.1 %; 64 workers (every row updated atomically: small flat
     # vocabulary) -1.05 ... +0.3 %
