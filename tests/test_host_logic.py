@@ -254,3 +254,35 @@ def test_replica_token_slice_covers_what_the_workers_read():
                 if cur >= n or wc > quota:
                     break
             assert cur <= hi, (trial, s, cur, hi)
+
+
+def test_cli_warns_about_more_workers_than_the_corpus_supports(tmp_path):
+    """a worker re-computes alpha only after 10 000 of its own words (ref :379-393): `-threads 512` on a 5 K-token file is
+    accepted (as the reference accepts it) but warned about on stderr -- before any device is touched, so this runs here"""
+    exe = os.path.join(ROOT, "word2bits")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    out = str(tmp_path / "o.vec")
+    r = subprocess.run([exe, "-train", CORPUS, "-output", out, "-threads", "512", "-min-count", "1"], capture_output=True, text=True)
+    assert "warning: -threads 512" in r.stderr and "-threads 0 picks at most" in r.stderr
+    r = subprocess.run([exe, "-train", CORPUS, "-output", out, "-threads", "12", "-min-count", "1"], capture_output=True, text=True)
+    assert "warning" not in r.stderr
+
+
+def test_bench_names_the_workload_it_runs():
+    """round 2 labelled every shape 'BASELINE configs[1]'; the label is built from the arguments now"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import argparse
+    base = dict(vocab=400_000, dim=800, window=8, negative=24, bitlevel=1, ids="zipf", tokens=100_000_000)
+    name = lambda **kw: bench.workload_name(argparse.Namespace(**dict(base, **kw)))
+    assert name() == "BASELINE configs[1]"
+    assert name(tokens=30_000_000).startswith("BASELINE configs[1] shape")
+    assert "configs[4]" in name(vocab=3_700_000, dim=1000, negative=12)
+    assert "configs[4]" in name(vocab=3_700_000, dim=1000, negative=12, bitlevel=0)
+    assert "configs[0]" in name(vocab=60238, dim=200)
+    assert "configs[2]" in name(vocab=60238, dim=400, bitlevel=2)
+    assert name(ids="uniform") == "custom shape" and name(dim=640) == "custom shape"
+    assert bench.algorithmic_bytes_per_word(800, 9, 24) == 217_736          # SURVEY 8d

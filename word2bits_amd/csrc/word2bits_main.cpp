@@ -148,6 +148,13 @@ int main(int argc, char **argv) {
   }
   if (o.output_file.empty()) return 0;                       // ref :527
 
+  // A worker re-computes alpha only after more than 10000 of its own words (ref :379-393).  The reference has the same
+  // property, but nobody starts it with hundreds of threads on a small file; a GPU invites exactly that.
+  if (o.num_threads > 32 && train_words / o.num_threads < 20000)      // (worker counts no CPU run would use)
+    fprintf(stderr, "word2bits: warning: -threads %d leaves %lld words per worker and epoch; below 20000 the learning "
+                    "rate schedule (re-computed per worker every 10000 words) hardly runs -- -threads 0 picks at most "
+                    "%lld workers for this file\n", o.num_threads, train_words / o.num_threads,
+            train_words / 20000 > 1 ? train_words / 20000 : 1);
   int ndev = w2b_device_count();
   if (ndev <= 0) {
     fprintf(stderr, "word2bits: no HIP device visible; this build has no CPU path\n");
@@ -181,13 +188,6 @@ int main(int argc, char **argv) {
     o.num_threads = per_gpu * o.gpus;
     if (o.debug_mode > 0) printf("Hogwild workers (workgroups): %d\n", o.num_threads);
   }
-  // A worker re-computes alpha only after more than 10000 of its own words (ref :379-393).  The reference has the same
-  // property, but nobody starts it with hundreds of threads on a small file; a GPU invites exactly that.
-  if (o.num_threads > 1 && train_words / o.num_threads < 20000)
-    fprintf(stderr, "word2bits: warning: -threads %d leaves %lld words per worker and epoch; below 20000 the learning "
-                    "rate schedule (re-computed per worker every 10000 words) hardly runs -- -threads 0 picks at most "
-                    "%lld workers for this file\n", o.num_threads, train_words / o.num_threads,
-            train_words / 20000 > 1 ? train_words / 20000 : 1);
   if (o.gpus > 1 && o.num_threads % o.gpus != 0) {
     fprintf(stderr, "word2bits: -threads must be a multiple of -gpus\n");
     return 2;
