@@ -19,6 +19,13 @@ typedef struct w2b_corpus w2b_corpus;
  * tokenise the file once into vocabulary ids (0 = "</s>", out-of-vocabulary words dropped as the
  * reference's reader does at ref :398).  Returns 0, or W2B_EIO if the file cannot be read. */
 int w2b_corpus_load(const char *train_file, int32_t min_count, w2b_corpus **out);
+/* The same with the reference's `vocab_hash_size` (ref :35) as an argument; 0 = its value, 30 000 000.  The constant
+ * matters in one place: while the reference learns the vocabulary, ReduceVocab (ref :245-263) drops every word whose
+ * count so far is not above `min_reduce` (1, 2, 3, ... from call to call) whenever the table holds more than
+ * 0.7 x vocab_hash_size words (ref :293) -- from 21 M distinct words on.  Reproduced exactly, including what depends
+ * on the order of the stream (a dropped word that returns starts again at 1 and sorts behind its peers) and the
+ * reference's quirk that "</s>" itself can be dropped, after which another word owns row 0 and ends sentences. */
+int w2b_corpus_load_ex(const char *train_file, int32_t min_count, int32_t vocab_hash_size, w2b_corpus **out);
 void w2b_corpus_free(w2b_corpus *c);
 
 int64_t w2b_corpus_vocab_size(const w2b_corpus *c);    /* vocab_size,  ref :49 */

@@ -395,8 +395,24 @@ static int by_count_desc(const void *a, const void *b) { /* ref :207-212 */
   return d > 0 ? 1 : (d < 0 ? -1 : 0);
 }
 
-w2bo_vocab *w2bo_vocab_learn(const char *train_file, int min_count) { /* ref :265-301, 215-242 */
-  long long size, pos = 0, begin;
+/* ReduceVocab (ref :245-263): called from the learning loop whenever the vocabulary outgrows 70 % of the hash table
+ * (ref :293).  Every entry -- "</s>" at index 0 included, the reference does not protect it -- whose count is not
+ * above min_reduce is removed, the survivors keep their relative order, and min_reduce goes up by one. */
+static void reduce_vocab(w2bo_vocab *v, long long *min_reduce) {
+  long long b = 0;
+  for (long long a = 0; a < v->size; a++) {
+    if (v->cn[a] > *min_reduce) { v->cn[b] = v->cn[a]; v->word[b] = v->word[a]; b++; }
+    else free(v->word[a]);
+  }
+  v->size = b;
+  map_rebuild(v);
+  (*min_reduce)++;
+}
+
+/* ref :265-301, 215-242.  vocab_hash_size is the reference's constant of that name (ref :35: 30 000 000); it only
+ * matters through the ReduceVocab trigger `vocab_size > vocab_hash_size * 0.7` (int times double, as written there). */
+w2bo_vocab *w2bo_vocab_learn_ex(const char *train_file, int min_count, int vocab_hash_size) {
+  long long size, pos = 0, begin, min_reduce = 1;          /* min_reduce: ref :48 */
   unsigned char *buf = slurp(train_file, &size);
   if (!buf) return NULL;
   w2bo_vocab *v = (w2bo_vocab *)calloc(1, sizeof(*v));
@@ -407,8 +423,8 @@ w2bo_vocab *w2bo_vocab_learn(const char *train_file, int min_count) { /* ref :26
     int i = w2bo_vocab_search(v, word);
     if (i == -1) { long long a = vocab_add(v, word); v->cn[a] = 1; }
     else v->cn[i]++;
+    if (v->size > vocab_hash_size * 0.7) reduce_vocab(v, &min_reduce);   /* ref :293 */
   }
-  /* (ReduceVocab, ref :245-263, only triggers above 21 M distinct words: not restated) */
   vw_pair *p = (vw_pair *)malloc(sizeof(vw_pair) * v->size);
   for (long long i = 0; i < v->size; i++) { p[i].w = v->word[i]; p[i].cn = v->cn[i]; }
   qsort(p + 1, v->size - 1, sizeof(vw_pair), by_count_desc); /* same libc qsort as the reference */
@@ -425,6 +441,9 @@ w2bo_vocab *w2bo_vocab_learn(const char *train_file, int min_count) { /* ref :26
   v->file_size = size;
   free(buf);
   return v;
+}
+w2bo_vocab *w2bo_vocab_learn(const char *train_file, int min_count) {
+  return w2bo_vocab_learn_ex(train_file, min_count, 30000000);          /* ref :35 */
 }
 void w2bo_vocab_free(w2bo_vocab *v) {
   if (!v) return;
@@ -498,7 +517,14 @@ static void save_vectors(const char *path, const w2bo_vocab *vb, const w2bo_mode
 int w2bo_run(const char *train_file, const char *output_file, int bitlevel, int dim, int window,
              int negative, int num_threads, int iter, int min_count, float alpha, float sample,
              float reg, int binary, double *epoch_losses) {
-  w2bo_vocab *vb = w2bo_vocab_learn(train_file, min_count);
+  return w2bo_run_ex(train_file, output_file, bitlevel, dim, window, negative, num_threads, iter, min_count, alpha,
+                     sample, reg, binary, epoch_losses, 30000000);
+}
+
+int w2bo_run_ex(const char *train_file, const char *output_file, int bitlevel, int dim, int window,
+                int negative, int num_threads, int iter, int min_count, float alpha, float sample,
+                float reg, int binary, double *epoch_losses, int vocab_hash_size) {
+  w2bo_vocab *vb = w2bo_vocab_learn_ex(train_file, min_count, vocab_hash_size);
   if (!vb) return 1;
   w2bo_model m;
   memset(&m, 0, sizeof m);

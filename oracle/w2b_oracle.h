@@ -86,6 +86,9 @@ double w2bo_train_epoch_tokens(w2bo_model *m, const int *ids, long long n,
 /* ---- file level: vocabulary + tokenisation (src/word2bits.cpp:131-301) --------------- */
 typedef struct w2bo_vocab w2bo_vocab;
 w2bo_vocab *w2bo_vocab_learn(const char *train_file, int min_count);   /* :265-301 */
+/* the same with the reference's vocab_hash_size (:35) as a parameter: ReduceVocab (:245-263) runs whenever the
+ * vocabulary outgrows 70 % of it (:293) */
+w2bo_vocab *w2bo_vocab_learn_ex(const char *train_file, int min_count, int vocab_hash_size);
 void w2bo_vocab_free(w2bo_vocab *);
 long long w2bo_vocab_size(const w2bo_vocab *);
 long long w2bo_vocab_train_words(const w2bo_vocab *);
@@ -111,6 +114,10 @@ long long w2bo_shard_start(const w2bo_vocab *, const char *train_file, long long
 int w2bo_run(const char *train_file, const char *output_file, int bitlevel, int dim, int window,
              int negative, int num_threads, int iter, int min_count, float alpha, float sample,
              float reg, int binary, double *epoch_losses /*[iter] or NULL*/);
+/* the same program with the reference's vocab_hash_size (:35) as a parameter (ReduceVocab, :245-263,293) */
+int w2bo_run_ex(const char *train_file, const char *output_file, int bitlevel, int dim, int window,
+                int negative, int num_threads, int iter, int min_count, float alpha, float sample,
+                float reg, int binary, double *epoch_losses /*[iter] or NULL*/, int vocab_hash_size);
 
 /* ------------------------------------------------------------------ evaluator (src/compute-accuracy.c)
  * Numerics of the analogy evaluator, restated; file parsing and the stdout transcript are

@@ -90,6 +90,8 @@ def oracle(fma=False):
                                           C.c_int]
     L.w2bo_vocab_learn.restype = C.c_void_p
     L.w2bo_vocab_learn.argtypes = [C.c_char_p, C.c_int]
+    L.w2bo_vocab_learn_ex.restype = C.c_void_p
+    L.w2bo_vocab_learn_ex.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.w2bo_vocab_free.argtypes = [C.c_void_p]
     for f in ("w2bo_vocab_size", "w2bo_vocab_train_words", "w2bo_vocab_file_size"):
         getattr(L, f).restype = C.c_longlong
@@ -107,6 +109,8 @@ def oracle(fma=False):
     L.w2bo_run.restype = C.c_int
     L.w2bo_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_double)]
+    L.w2bo_run_ex.restype = C.c_int
+    L.w2bo_run_ex.argtypes = L.w2bo_run.argtypes + [C.c_int]
     _oracle[fma] = L
     return L
 
@@ -308,4 +312,33 @@ def write_headline_corpus(path, vocab=400_000, n_zipf=20_000_000, seed=1234, lin
         for o in range(0, len(ids), line):
             f.write(b" ".join(words[ids[o:o + line]]))
             f.write(b"\n")
+    return path
+
+
+def write_reduce_vocab_corpus(path, kind, seed=0):
+    """Corpora on which ReduceVocab (ref :245-263) runs when vocab_hash_size is 3000 (more than 2100 words in the
+    table, ref :293).  Generated with the reference's LCG in pure Python integers, so the bytes do not depend on the
+    numpy version (tests/golden/reduce_vocab.json holds what the reference does on exactly these bytes).
+      "zipf": 30 000 log-uniform draws over 6000 words, a newline every 50 tokens -- several reductions, "</s>" survives;
+      "wipe": 2300 words that occur once and no newline first -- the first reduction empties the whole table, "</s>"
+              included (the reference does not protect it), then 20 000 draws over 5000 words with newlines: another
+              word ends up owning row 0 (and ends sentences), "</s>" comes back as an ordinary word."""
+    x = 20240924 + seed          # seed 0 = the corpora of the committed fixture
+
+    def draw():
+        nonlocal x
+        x = (x * 25214903917 + 11) & 0xFFFFFFFFFFFFFFFF
+        return (x >> 16) & 0xFFFFF
+
+    out = []
+    if kind == "wipe":
+        out.append(" ".join("u%d" % i for i in range(2300)) + " ")
+        n, vocab, line = 20000, 5000, 40
+    else:
+        n, vocab, line = 30000, 6000, 50
+    toks = ["w%d" % int(vocab ** (draw() / float(1 << 20))) for _ in range(n)]
+    for o in range(0, n, line):
+        out.append(" ".join(toks[o:o + line]) + "\n")
+    with open(path, "w") as f:
+        f.write("".join(out))
     return path

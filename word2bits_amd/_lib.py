@@ -94,6 +94,7 @@ SIGNATURES = {
     "w2b_exchange_end": (C.c_int, [vp, C.c_int64]),
     # include/word2bits_corpus.h
     "w2b_corpus_load": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(vp)]),
+    "w2b_corpus_load_ex": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]),
     "w2b_corpus_free": (None, [vp]),
     "w2b_corpus_vocab_size": (C.c_int64, [vp]),
     "w2b_corpus_train_words": (C.c_int64, [vp]),

@@ -131,7 +131,12 @@ extern "C" void w2b_corpus_free(w2b_corpus *c) {
 }
 
 extern "C" int w2b_corpus_load(const char *train_file, int32_t min_count, w2b_corpus **out) {
-  if (!train_file || !out) return W2B_EINVAL;
+  return w2b_corpus_load_ex(train_file, min_count, 0, out);
+}
+
+extern "C" int w2b_corpus_load_ex(const char *train_file, int32_t min_count, int32_t vocab_hash_size, w2b_corpus **out) {
+  if (!train_file || !out || vocab_hash_size < 0) return W2B_EINVAL;
+  if (vocab_hash_size == 0) vocab_hash_size = 30000000;    // ref :35
   *out = nullptr;
   const int fd = open(train_file, O_RDONLY);
   if (fd < 0) return W2B_EIO;
@@ -228,14 +233,47 @@ extern "C" int w2b_corpus_load(const char *train_file, int32_t min_count, w2b_co
     }
   }
   lap("merge");
-  // ---- SortVocab (ref :215-242): "</s>" stays first, the rest by count descending.  glibc's qsort
-  // is a merge sort for arrays of this size, i.e. ties keep first-appearance order: stable_sort.
+  // ---- ReduceVocab (ref :245-263, called at :293 whenever `vocab_size > vocab_hash_size * 0.7`).  The number of
+  // entries the sequential scan holds never exceeds the number of distinct words, so below that limit it never runs
+  // (every corpus with fewer than 21 M distinct words).  Above it, what survives depends on the order of the stream:
+  // replay the raw tokens once, sequentially, keeping per word its running count, whether it is in the table, and when
+  // it (last) entered -- ReduceVocab compacts the array in place, so the survivors keep their order and a word that
+  // comes back after having been removed is appended at the end with a count of 1.
   const int32_t nseen = (int32_t)cn.size();
-  std::vector<int32_t> order(nseen);
-  for (int32_t i = 0; i < nseen; i++) order[i] = i;
-  std::stable_sort(order.begin() + 1, order.end(), [&](int32_t a, int32_t b) { return cn[a] > cn[b]; });
+  std::vector<int32_t> order;                 // the vocabulary array as SortVocab finds it (ids of `seen`)
+  const double reduce_above = vocab_hash_size * 0.7;       // int times double, as the reference writes it
+  if (!((double)nseen > reduce_above)) {
+    order.resize(nseen);
+    for (int32_t i = 0; i < nseen; i++) order[i] = i;       // first-appearance order, "</s>" first
+  } else {
+    std::vector<int64_t> run(nseen, 0), entered(nseen, -1);
+    int64_t clock = 0, live = 1, min_reduce = 1;            // min_reduce: ref :48
+    entered[0] = clock++;                                   // AddWordToVocab("</s>"), count 0 (ref :276)
+    for (int t = 0; t < npieces; t++) {
+      const std::vector<int32_t> &g = to_global[t];
+      for (const int32_t r : pieces[t].raw) {
+        const int32_t id = g[r];
+        if (entered[id] < 0) { entered[id] = clock++; run[id] = 1; live++; }
+        else run[id]++;
+        if ((double)live > reduce_above) {                  // ReduceVocab: nothing is protected, not even "</s>"
+          for (int32_t i = 0; i < nseen; i++)
+            if (entered[i] >= 0 && !(run[i] > min_reduce)) { entered[i] = -1; run[i] = 0; live--; }
+          min_reduce++;
+        }
+      }
+    }
+    for (int32_t i = 0; i < nseen; i++) if (entered[i] >= 0) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return entered[a] < entered[b]; });
+    cn.swap(run);                                           // the counts the reference ends up with
+  }
+  lap("reduce");
+  // ---- SortVocab (ref :215-242): entry 0 ("</s>", unless ReduceVocab has removed it: then whatever word came
+  // next) stays first, the rest by count descending.  glibc's qsort is a merge sort for arrays of this size, i.e.
+  // ties keep their order in the array: stable_sort.
+  if (order.size() > 1)
+    std::stable_sort(order.begin() + 1, order.end(), [&](int32_t a, int32_t b) { return cn[a] > cn[b]; });
   std::vector<int32_t> remap(nseen, -1);
-  for (int32_t k = 0; k < nseen; k++) {
+  for (size_t k = 0; k < order.size(); k++) {
     const int32_t id = order[k];
     if (cn[id] < min_count && k != 0) continue;          // ref :225
     remap[id] = (int32_t)c->words.size();

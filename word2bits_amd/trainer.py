@@ -27,9 +27,11 @@ def _i64(a):
 class Corpus:
     """Vocabulary + token stream of a training file (LearnVocabFromTrainFile, ref :265-301)."""
 
-    def __init__(self, train_file, min_count=5):
+    def __init__(self, train_file, min_count=5, vocab_hash_size=0):
+        """vocab_hash_size: the reference's constant of that name (ref :35; 0 = 30 000 000) -- it decides when
+        ReduceVocab (ref :245-263) runs while the vocabulary is learned (w2b_corpus_load_ex)."""
         self._h = _lib.vp()
-        rc = lib().w2b_corpus_load(train_file.encode(), int(min_count), C.byref(self._h))
+        rc = lib().w2b_corpus_load_ex(train_file.encode(), int(min_count), int(vocab_hash_size), C.byref(self._h))
         if rc != 0:
             raise _lib.W2bError(rc, "ERROR: training data file not found!")   # ref :272
         L = lib()
