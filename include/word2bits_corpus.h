@@ -49,6 +49,27 @@ int w2b_corpus_shards(const w2b_corpus *c, int32_t num_threads, int64_t *starts,
 int w2b_save_vectors(const char *path, const w2b_corpus *c, const float *values, int64_t dim,
                      int32_t binary);
 
+/* ---- bit-packed vectors ("optional bit-packed output"; not a format of the reference) ----------------
+ * A 1-bit (2-bit) model is 1 (2) bits of information per value; the reference's file spends 32.  Packed layout of a row
+ * of `dim` values quantized at -bitlevel 1 or 2: ceil(dim / 64) blocks of 64 consecutive columns; per block one 64-bit
+ * word of SIGN bits (bit c % 64 set: the value of column c is negative) and, at bitlevel 2, a second word of MAGNITUDE
+ * bits (set: 0.75, clear: 0.25; bitlevel 1 has the single magnitude 1/3).  Bits of columns >= dim are zero.
+ * w2b_packed_words_per_row = ceil(dim / 64) * bitlevel, or -1 when bitlevel is neither 1 nor 2.  Lossless: unpacking
+ * returns the exact float bit patterns quantize() (ref :73-108) produces.  Pure host code; the device-side producer is
+ * w2b_export_packed (word2bits_hip.h). */
+int64_t w2b_packed_words_per_row(int64_t dim, int32_t bitlevel);
+/* values[rows][dim] must already be quantize()d at `bitlevel` (anything else is W2B_EINVAL) */
+int w2b_pack_quantized(const float *values, int64_t rows, int64_t dim, int32_t bitlevel, uint64_t *out);
+int w2b_unpack_quantized(const uint64_t *packed, int64_t rows, int64_t dim, int32_t bitlevel, float *out);
+/* Packed model file: "W2BP1 <vocab_size> <dim> <bitlevel>\n", the vocabulary (one word per line, row order), then
+ * vocab_size x words_per_row little-endian 64-bit words. */
+int w2b_save_vectors_packed(const char *path, const w2b_corpus *c, const uint64_t *packed, int64_t dim, int32_t bitlevel);
+/* Packed file -> the reference's output file (ref :560-576; binary != 0: raw float32, else "%lf "), byte for byte what
+ * w2b_save_vectors / the reference would have written for the same model, so that the unmodified compute_accuracy (or any
+ * other consumer of the reference's format) can read it.  ./compute_accuracy and w2b_eval_load also take a packed file
+ * directly. */
+int w2b_unpack_vectors_file(const char *packed_path, const char *out_path, int32_t binary);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,11 @@ int w2b_get_model(w2b_trainer *t, float *u, float *v);              /* device ->
 int w2b_model_device_ptrs(w2b_trainer *t, void **u_dev, void **v_dev);
 /* quantize(u+v) of the save loop (ref :549-550,568-569) into a host buffer [V][D] */
 int w2b_export_quantized(w2b_trainer *t, float *out);
+/* the same values bit-packed on the device ("optional bit-packed output"; -bitlevel 1 and 2 only, else
+ * W2B_EUNSUPPORTED): out[vocab_size * w2b_packed_words_per_row(layer1_size, bitlevel)] 64-bit words in the layout of
+ * include/word2bits_corpus.h -- 1/32 (1/16) of the bytes of w2b_export_quantized leave the device; w2b_unpack_quantized
+ * gives back exactly the floats w2b_export_quantized would have delivered. */
+int w2b_export_packed(w2b_trainer *t, uint64_t *out);
 
 /* ---- sampler state ------------------------------------------------------------------------ */
 /* word counts vocab[].cn: builds the keep-probability table and, when table_size > 0, the

@@ -5,4 +5,5 @@ mirror of the reference's training interface.  Importing the package never pulls
 """
 from ._lib import W2bError, LIB_PATH, lib        # noqa: F401
 from .trainer import Corpus, Trainer, comm_unique_id, train_model   # noqa: F401
+from .trainer import packed_words_per_row, pack_quantized, unpack_quantized, unpack_vectors_file   # noqa: F401
 from .evaluator import Evaluator, compute_accuracy   # noqa: F401

@@ -45,6 +45,7 @@ class Tuning(C.Structure):
 
 vp, i32p, i64p, f32p, f64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), \
     C.POINTER(C.c_float), C.POINTER(C.c_double)
+u64p = C.POINTER(C.c_uint64)
 
 # name -> (restype, argtypes); every symbol declared in include/*.h
 SIGNATURES = {
@@ -64,6 +65,7 @@ SIGNATURES = {
     "w2b_get_model": (C.c_int, [vp, f32p, f32p]),
     "w2b_model_device_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "w2b_export_quantized": (C.c_int, [vp, f32p]),
+    "w2b_export_packed": (C.c_int, [vp, u64p]),
     "w2b_set_vocab_counts": (C.c_int, [vp, i64p, C.c_int64]),
     "w2b_set_unigram_table": (C.c_int, [vp, i32p, C.c_int64]),
     "w2b_set_exp_table": (C.c_int, [vp, f32p]),
@@ -105,6 +107,11 @@ SIGNATURES = {
     "w2b_corpus_num_tokens": (C.c_int64, [vp]),
     "w2b_corpus_tokens": (i32p, [vp]),
     "w2b_corpus_shards": (C.c_int, [vp, C.c_int32, i64p, i32p]),
+    "w2b_packed_words_per_row": (C.c_int64, [C.c_int64, C.c_int32]),
+    "w2b_pack_quantized": (C.c_int, [f32p, C.c_int64, C.c_int64, C.c_int32, u64p]),
+    "w2b_unpack_quantized": (C.c_int, [u64p, C.c_int64, C.c_int64, C.c_int32, f32p]),
+    "w2b_save_vectors_packed": (C.c_int, [C.c_char_p, vp, u64p, C.c_int64, C.c_int32]),
+    "w2b_unpack_vectors_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32]),
     "w2b_save_vectors": (C.c_int, [C.c_char_p, vp, f32p, C.c_int64, C.c_int32]),
     # include/word2bits_eval.h
     "w2b_eval_load": (C.c_int, [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(vp)]),

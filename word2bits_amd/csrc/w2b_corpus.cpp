@@ -401,19 +401,18 @@ static inline char *format_lf(char *p, float x) {
   return p;
 }
 
-extern "C" int w2b_save_vectors(const char *path, const w2b_corpus *c, const float *values, int64_t dim,
-                                int32_t binary) {
-  if (!path || !c || !values) return W2B_EINVAL;
+// the writer of ref :560-576 over any source of row names
+template <typename NameOf>
+static int write_vectors(const char *path, int64_t V, NameOf &&name_of, const float *values, int64_t dim, int32_t binary) {
   FILE *fo = fopen(path, "wb");
   if (!fo) return W2B_EIO;
   std::vector<char> big(1 << 20);          // stdio buffer of this call (released after fclose)
   setvbuf(fo, big.data(), _IOFBF, big.size());
-  const int64_t V = (int64_t)c->words.size();
   fprintf(fo, "%lld %lld\n", (long long)V, (long long)dim);
   std::vector<char> line;
   if (!binary) line.resize((size_t)dim * 64 + 64);
   for (int64_t a = 0; a < V; a++) {
-    fputs(c->words[a].c_str(), fo);
+    fputs(name_of(a), fo);
     fputc(' ', fo);
     const float *row = values + a * dim;
     if (binary) {
@@ -426,4 +425,121 @@ extern "C" int w2b_save_vectors(const char *path, const w2b_corpus *c, const flo
     fputc('\n', fo);
   }
   return fclose(fo) == 0 ? W2B_OK : W2B_EIO;
+}
+
+extern "C" int w2b_save_vectors(const char *path, const w2b_corpus *c, const float *values, int64_t dim,
+                                int32_t binary) {
+  if (!path || !c || !values) return W2B_EINVAL;
+  return write_vectors(path, (int64_t)c->words.size(), [&](int64_t a) { return c->words[(size_t)a].c_str(); }, values, dim, binary);
+}
+
+// ------------------------------------------------------------------------------------ bit-packed vectors
+// (include/word2bits_corpus.h: layout and file format)
+extern "C" int64_t w2b_packed_words_per_row(int64_t dim, int32_t bitlevel) {
+  if (dim < 1 || (bitlevel != 1 && bitlevel != 2)) return -1;
+  return (dim + 63) / 64 * bitlevel;
+}
+
+static inline uint32_t f32_bits(float x) { uint32_t b; memcpy(&b, &x, 4); return b; }
+static inline float bits_f32(uint32_t b) { float x; memcpy(&x, &b, 4); return x; }
+static const uint32_t kThird = 0x3EAAAAABu, kQuarter = 0x3E800000u, kThreeQuarters = 0x3F400000u;   // 1/3, .25, .75
+
+extern "C" int w2b_pack_quantized(const float *values, int64_t rows, int64_t dim, int32_t bitlevel, uint64_t *out) {
+  const int64_t wpr = w2b_packed_words_per_row(dim, bitlevel);
+  if (!values || !out || rows < 0) return W2B_EINVAL;
+  if (wpr < 0) return W2B_EUNSUPPORTED;
+  for (int64_t r = 0; r < rows; r++) {
+    const float *row = values + r * dim;
+    uint64_t *o = out + r * wpr;
+    for (int64_t w = 0; w < wpr; w++) o[w] = 0;
+    for (int64_t c = 0; c < dim; c++) {
+      const uint32_t b = f32_bits(row[c]), mag = b & 0x7FFFFFFFu;
+      const uint64_t bit = 1ull << (c & 63);
+      uint64_t *blk = o + (c >> 6) * bitlevel;
+      if (bitlevel == 1) { if (mag != kThird) return W2B_EINVAL; }
+      else if (mag == kThreeQuarters) blk[1] |= bit;
+      else if (mag != kQuarter) return W2B_EINVAL;
+      if (b >> 31) blk[0] |= bit;
+    }
+  }
+  return W2B_OK;
+}
+
+extern "C" int w2b_unpack_quantized(const uint64_t *packed, int64_t rows, int64_t dim, int32_t bitlevel, float *out) {
+  const int64_t wpr = w2b_packed_words_per_row(dim, bitlevel);
+  if (!packed || !out || rows < 0) return W2B_EINVAL;
+  if (wpr < 0) return W2B_EUNSUPPORTED;
+  for (int64_t r = 0; r < rows; r++) {
+    const uint64_t *in = packed + r * wpr;
+    float *row = out + r * dim;
+    for (int64_t c = 0; c < dim; c++) {
+      const uint64_t *blk = in + (c >> 6) * bitlevel;
+      const int sh = (int)(c & 63);
+      const uint32_t mag = bitlevel == 1 ? kThird : (((blk[1] >> sh) & 1) ? kThreeQuarters : kQuarter);
+      row[c] = bits_f32(mag | ((uint32_t)((blk[0] >> sh) & 1) << 31));
+    }
+  }
+  return W2B_OK;
+}
+
+extern "C" int w2b_save_vectors_packed(const char *path, const w2b_corpus *c, const uint64_t *packed, int64_t dim,
+                                       int32_t bitlevel) {
+  const int64_t wpr = w2b_packed_words_per_row(dim, bitlevel);
+  if (!path || !c || !packed) return W2B_EINVAL;
+  if (wpr < 0) return W2B_EUNSUPPORTED;
+  FILE *fo = fopen(path, "wb");
+  if (!fo) return W2B_EIO;
+  const int64_t V = (int64_t)c->words.size();
+  fprintf(fo, "W2BP1 %lld %lld %d\n", (long long)V, (long long)dim, (int)bitlevel);
+  for (int64_t a = 0; a < V; a++) { fputs(c->words[(size_t)a].c_str(), fo); fputc('\n', fo); }
+  fwrite(packed, sizeof(uint64_t), (size_t)(V * wpr), fo);
+  return fclose(fo) == 0 ? W2B_OK : W2B_EIO;
+}
+
+// A packed file in memory -> its vocabulary and unpacked rows.  Shared with the evaluator's loader (w2b_eval.cpp).
+bool w2b_internal_is_packed(const unsigned char *d, size_t n) { return n >= 6 && !memcmp(d, "W2BP1 ", 6); }
+int w2b_internal_parse_packed(const unsigned char *d, size_t n, std::vector<std::string> &words, std::vector<float> &values,
+                              int64_t *dim_out) {
+  if (!w2b_internal_is_packed(d, n)) return W2B_EINVAL;
+  const unsigned char *nl = (const unsigned char *)memchr(d, '\n', n);
+  if (!nl || nl - d > 100) return W2B_EIO;
+  long long V = 0, D = 0;
+  int bitlevel = 0;
+  if (sscanf(std::string((const char *)d + 6, (size_t)(nl - d) - 6).c_str(), "%lld %lld %d", &V, &D, &bitlevel) != 3) return W2B_EIO;
+  const int64_t wpr = w2b_packed_words_per_row(D, bitlevel);
+  if (V < 0 || wpr < 0 || V > 0x7FFFFF00ll || D > (1 << 24)) return W2B_EIO;
+  size_t pos = (size_t)(nl - d) + 1;
+  words.clear();
+  words.reserve((size_t)V);
+  for (long long a = 0; a < V; a++) {
+    const unsigned char *e = pos < n ? (const unsigned char *)memchr(d + pos, '\n', n - pos) : nullptr;
+    if (!e) return W2B_EIO;
+    words.emplace_back((const char *)d + pos, (size_t)(e - (d + pos)));
+    pos = (size_t)(e - d) + 1;
+  }
+  if (n - pos < (size_t)(V * wpr) * sizeof(uint64_t)) return W2B_EIO;
+  std::vector<uint64_t> packed((size_t)(V * wpr));
+  if (!packed.empty()) memcpy(packed.data(), d + pos, packed.size() * sizeof(uint64_t));     // (unaligned in the file)
+  values.assign((size_t)(V * D), 0.f);
+  if (dim_out) *dim_out = D;
+  return V > 0 ? w2b_unpack_quantized(packed.data(), V, D, bitlevel, values.data()) : W2B_OK;
+}
+
+extern "C" int w2b_unpack_vectors_file(const char *packed_path, const char *out_path, int32_t binary) {
+  if (!packed_path || !out_path) return W2B_EINVAL;
+  FILE *f = fopen(packed_path, "rb");
+  if (!f) return W2B_EIO;
+  std::vector<unsigned char> d;
+  fseek(f, 0, SEEK_END);
+  const long long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  d.resize(n > 0 ? (size_t)n : 0);
+  const bool ok = n <= 0 || fread(d.data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  if (!ok) return W2B_EIO;
+  std::vector<std::string> words;
+  std::vector<float> values;
+  int64_t dim = 0;
+  if (int rc = w2b_internal_parse_packed(d.data(), d.size(), words, values, &dim)) return rc;
+  return write_vectors(out_path, (int64_t)words.size(), [&](int64_t a) { return words[(size_t)a].c_str(); }, values.data(), dim, binary);
 }

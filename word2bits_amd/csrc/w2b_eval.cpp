@@ -148,6 +148,27 @@ extern "C" int w2b_eval_load(const char *file, int32_t bitlevel, int64_t thresho
     }
     fclose(f);
   }
+  if (w2b_internal_is_packed(d.data(), d.size())) {
+    // a bit-packed model file (include/word2bits_corpus.h): rebuilt in memory as the bytes of the reference's binary file
+    // (ref src/word2bits.cpp:560-576), which then go through the reader below like any other file
+    std::vector<std::string> names;
+    std::vector<float> values;
+    int64_t dim = 0;
+    if (w2b_internal_parse_packed(d.data(), d.size(), names, values, &dim) != W2B_OK)
+      return efail(W2B_EIO, "w2b_eval_load: damaged bit-packed file");
+    std::vector<unsigned char> b;
+    char head[64];
+    const int hl = snprintf(head, sizeof head, "%lld %lld\n", (long long)names.size(), (long long)dim);
+    b.insert(b.end(), head, head + hl);
+    for (size_t a = 0; a < names.size(); a++) {
+      b.insert(b.end(), names[a].begin(), names[a].end());
+      b.push_back(' ');
+      const unsigned char *row = (const unsigned char *)(values.data() + a * (size_t)dim);
+      b.insert(b.end(), row, row + (size_t)dim * 4);
+      b.push_back('\n');
+    }
+    d.swap(b);
+  }
   size_t pos = 0;
   long long words = 0, size = 0;
   if (!scan_ll(d, pos, &words)) return efail(W2B_EIO, "w2b_eval_load: no <words> header");

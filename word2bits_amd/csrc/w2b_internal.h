@@ -100,6 +100,8 @@ hipError_t w2b_launch_init_net(float *u, float *v, long long n_per_table, const 
                                hipStream_t s);
 hipError_t w2b_launch_export(const float *u, const float *v, float *out, long long n, int bitlevel,
                              hipStream_t s);
+hipError_t w2b_launch_export_packed(const float *u, const float *v, unsigned long long *out, long long rows, int dim,
+                                    int bitlevel, hipStream_t s);      // bitlevel 1 / 2: include/word2bits_corpus.h layout
 // analogy evaluator (w2b_kernels_eval.hip; ref src/compute-accuracy.c:106-110,155-177)
 hipError_t w2b_launch_eval_normalize(float *M, long long words, long long size, long long ld, int bitlevel,
                                      int fused, float *len_scratch, hipStream_t s);
@@ -108,6 +110,12 @@ hipError_t w2b_launch_eval_queries(const float *M, long long ld, long long nq, c
 hipError_t w2b_launch_eval_scores(const float *Q, const float *M, int nq, int words, int size, int ld, int fused,
                                   const int *b1, const int *b2, const int *b3, unsigned long long *best,
                                   int variant /* 0: vector-ALU kernel always; else MFMA when fused */, hipStream_t s);
+// bit-packed model files (w2b_corpus.cpp; format in include/word2bits_corpus.h)
+#include <string>
+#include <vector>
+bool w2b_internal_is_packed(const unsigned char *d, size_t n);
+int w2b_internal_parse_packed(const unsigned char *d, size_t n, std::vector<std::string> &words, std::vector<float> &values,
+                              int64_t *dim_out);
 int w2b_internal_fail(int code, const char *msg);   // sets w2b_last_error() (w2b_trainer.cpp)
 struct w2b_trainer;
 // what the evaluator needs from a live trainer (w2b_trainer.cpp): device tables, shape, bitlevel, device, stream

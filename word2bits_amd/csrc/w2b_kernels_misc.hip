@@ -32,6 +32,32 @@ __global__ void k_export(const float *__restrict__ u, const float *__restrict__ 
     out[i] = quant<QM>(u[i] + v[i], qp);
 }
 
+// Bit-packed form of the same values (SURVEY 8 f2 "optional bit-packed output"; include/word2bits_corpus.h has the
+// layout): one wavefront per block of 64 columns of a row, a coalesced 256-byte read of each table, the bits of the 64
+// quantized values gathered with ballots -- bitlevel 1: one 64-bit word of signs; bitlevel 2: the signs, then the
+// magnitudes (1 = the outer level).  Columns beyond the row contribute zero bits.
+template <int QM>
+__global__ void k_export_packed(const float *__restrict__ u, const float *__restrict__ v, unsigned long long *__restrict__ out,
+                                long long rows, int dim, int blocks_per_row) {
+  const QParam qp{QM, 1, 1.f};
+  const int lane = (int)threadIdx.x & 63;
+  const long long stride = (long long)gridDim.x * (blockDim.x >> 6), total = rows * blocks_per_row;
+  for (long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < total; w += stride) {   // wave-uniform
+    const long long row = w / blocks_per_row;
+    const int col = (int)(w % blocks_per_row) * 64 + lane;
+    const bool in = col < dim;
+    float q = 1.f;
+    if (in) q = quant<QM>(u[row * dim + col] + v[row * dim + col], qp);
+    const unsigned long long sign = __ballot(in && q < 0.f);
+    if (QM == 1) {
+      if (lane == 0) out[w] = sign;
+    } else {
+      const unsigned long long mag = __ballot(in && __builtin_fabsf(q) > .5f);
+      if (lane == 0) { out[2 * w] = sign; out[2 * w + 1] = mag; }
+    }
+  }
+}
+
 // ---- replica exchange (w2b_trainer.cpp, "multi-GPU"): one CHUNK of [u || v] at a time, 16 bytes per lane, on the
 // exchange streams WHILE the training kernels keep updating the same rows.  The model is therefore read and written at
 // agent scope (sc1 buffer accesses, like the training kernels' own row accesses); base / d / s belong to the exchange.
@@ -209,6 +235,15 @@ hipError_t w2b_launch_export(const float *u, const float *v, float *out, long lo
     hipLaunchKernelGGL((k_export<QM>), dim3(2048), dim3(256), 0, s, u, v, out, n, qp);
     return hipGetLastError();
   });
+}
+
+// bitlevel 1 or 2 only (the caller checks); out: rows x ceil(dim / 64) x bitlevel words
+hipError_t w2b_launch_export_packed(const float *u, const float *v, unsigned long long *out, long long rows, int dim,
+                                    int bitlevel, hipStream_t s) {
+  const int bpr = (dim + 63) / 64;
+  if (bitlevel == 1) hipLaunchKernelGGL((k_export_packed<1>), dim3(2048), dim3(256), 0, s, u, v, out, rows, dim, bpr);
+  else hipLaunchKernelGGL((k_export_packed<2>), dim3(2048), dim3(256), 0, s, u, v, out, rows, dim, bpr);
+  return hipGetLastError();
 }
 
 hipError_t w2b_launch_xhot_fold(const W2bParams &p, hipStream_t s) {

@@ -2,6 +2,7 @@
 // Owns device memory, streams, events and the RCCL communicator; all arithmetic of the hot
 // path lives in w2b_kernels.hip.  There is deliberately no CPU fallback in this file.
 #include "../../include/word2bits_hip.h"
+#include "../../include/word2bits_corpus.h"
 #include "w2b_internal.h"
 
 #include <rccl/rccl.h>
@@ -452,6 +453,32 @@ extern "C" int w2b_export_quantized(w2b_trainer *t, float *out) {
     if (e != hipSuccess) {
       (void)hipFree(tmp);
       return fail(W2B_EHIP, std::string("w2b_export_quantized: ") + hipGetErrorString(e));
+    }
+  }
+  HIPCHK(hipFree(tmp));
+  return W2B_OK;
+}
+
+// quantize(u+v) bit-packed (bitlevel 1 / 2): 1/32 resp. 1/16 of the bytes of w2b_export_quantized cross the bus
+extern "C" int w2b_export_packed(w2b_trainer *t, uint64_t *out) {
+  NEED(t);
+  if (!out) return fail(W2B_EINVAL, "w2b_export_packed: null output");
+  const int64_t wpr = w2b_packed_words_per_row(t->cfg.layer1_size, t->cfg.bitlevel);
+  if (wpr < 0) return fail(W2B_EUNSUPPORTED, "w2b_export_packed: bit-packed output exists for -bitlevel 1 and 2");
+  if (int rc = xchg_fence(t)) return rc;
+  const long long V = t->cfg.vocab_size, slab_rows = (32ll << 20) / wpr > 0 ? (32ll << 20) / wpr : 1;   // <= 256 MB of words
+  unsigned long long *tmp = nullptr;
+  HIPCHK(hipMalloc(&tmp, sizeof(unsigned long long) * (size_t)((V < slab_rows ? V : slab_rows) * wpr)));
+  for (long long r = 0; r < V; r += slab_rows) {
+    const long long m = (V - r < slab_rows) ? V - r : slab_rows;
+    const long long o = r * t->cfg.layer1_size;
+    hipError_t e = w2b_launch_export_packed(t->uv + o, t->uv + t->table_elems + o, tmp, m, t->cfg.layer1_size,
+                                            t->cfg.bitlevel, t->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out + r * wpr, tmp, sizeof(uint64_t) * (size_t)(m * wpr), hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(tmp);
+      return fail(W2B_EHIP, std::string("w2b_export_packed: ") + hipGetErrorString(e));
     }
   }
   HIPCHK(hipFree(tmp));

@@ -45,6 +45,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int window_refresh = -1;             // -window-refresh N: w2b_tuning.window_refresh (-1 = default)
   int hot_weight = 0;                  // -hot-weight N: w2b_tuning.hot_weight_permille (0 = default)
   int atomic_cap = -1;                 // -atomic-cap N: most rows the automatic choice takes
+  std::string packed_file;             // -packed FILE: also write the final vectors bit-packed (-bitlevel 1 / 2; word2bits_corpus.h)
   int row_desc = 0;                    // -row-desc 1: the row addressing of tables >= 2 GiB on any table (w2b_tuning.force_row_desc)
 };
 
@@ -124,6 +125,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-window-cache", argc, argv)) > 0) o.window_cache = atoi(argv[i + 1]);
   if ((i = arg_pos("-exact", argc, argv)) > 0) o.exact = atoi(argv[i + 1]);
   if ((i = arg_pos("-eval", argc, argv)) > 0) o.eval_file = argv[i + 1];
+  if ((i = arg_pos("-packed", argc, argv)) > 0) o.packed_file = argv[i + 1];
   if ((i = arg_pos("-hot-rows", argc, argv)) > 0) o.hot_rows = atoi(argv[i + 1]);
   if ((i = arg_pos("-hot-period", argc, argv)) > 0) o.hot_period = atoi(argv[i + 1]);
   if ((i = arg_pos("-hot-cap", argc, argv)) > 0) o.hot_cap = atoi(argv[i + 1]);
@@ -352,6 +354,20 @@ int main(int argc, char **argv) {
     }
   }
   save(o, corpus, reps[0].t, o.output_file);                  // ref :560-576
+  if (!o.packed_file.empty() && o.classes == 0) {
+    // the same vectors at 1 (2) bits per value instead of 32: packed on the device, 1/32 (1/16) of the bytes cross the bus
+    const int64_t wpr = w2b_packed_words_per_row(o.layer1_size, o.bitlevel);
+    if (wpr < 0) {
+      fprintf(stderr, "word2bits: -packed needs -bitlevel 1 or 2\n");
+      return 2;
+    }
+    std::vector<uint64_t> pk((size_t)(V * wpr));
+    CK(w2b_export_packed(reps[0].t, pk.data()));
+    if (w2b_save_vectors_packed(o.packed_file.c_str(), corpus, pk.data(), o.layer1_size, o.bitlevel) != W2B_OK) {
+      fprintf(stderr, "word2bits: cannot write %s\n", o.packed_file.c_str());
+      return 2;
+    }
+  }
   int rc_eval = 0;
   if (!o.eval_file.empty()) {
     // what `compute_accuracy <output> 0 0 < FILE` prints for the vectors just saved (binary format), scored on the GPU

@@ -24,6 +24,33 @@ def _i64(a):
     return a.ctypes.data_as(_lib.i64p)
 
 
+def packed_words_per_row(dim, bitlevel):
+    n = lib().w2b_packed_words_per_row(int(dim), int(bitlevel))
+    if n < 0:
+        raise _lib.W2bError(_lib.W2B_EUNSUPPORTED, "bit-packed vectors exist for bitlevel 1 and 2")
+    return n
+
+
+def pack_quantized(values, bitlevel):
+    """host twin of Trainer.export_packed: values [rows][dim] already quantized at `bitlevel`"""
+    values = np.ascontiguousarray(values, np.float32)
+    out = np.empty((values.shape[0], packed_words_per_row(values.shape[1], bitlevel)), np.uint64)
+    check(lib().w2b_pack_quantized(_f32(values), values.shape[0], values.shape[1], int(bitlevel), out.ctypes.data_as(_lib.u64p)))
+    return out
+
+
+def unpack_quantized(packed, dim, bitlevel):
+    packed = np.ascontiguousarray(packed, np.uint64)
+    out = np.empty((packed.shape[0], dim), np.float32)
+    check(lib().w2b_unpack_quantized(packed.ctypes.data_as(_lib.u64p), packed.shape[0], int(dim), int(bitlevel), _f32(out)))
+    return out
+
+
+def unpack_vectors_file(packed_path, out_path, binary=1):
+    """packed model file -> the reference's output file format (ref :560-576)"""
+    check(lib().w2b_unpack_vectors_file(packed_path.encode(), out_path.encode(), int(binary)))
+
+
 class Corpus:
     """Vocabulary + token stream of a training file (LearnVocabFromTrainFile, ref :265-301)."""
 
@@ -70,6 +97,11 @@ class Corpus:
     def save_vectors(self, path, values, binary):
         values = np.ascontiguousarray(values, np.float32)
         check(lib().w2b_save_vectors(path.encode(), self._h, _f32(values), values.shape[1], int(binary)))
+
+    def save_vectors_packed(self, path, packed, dim, bitlevel):
+        """bit-packed model file (include/word2bits_corpus.h); `packed` as Trainer.export_packed / pack_quantized give it"""
+        packed = np.ascontiguousarray(packed, np.uint64)
+        check(lib().w2b_save_vectors_packed(path.encode(), self._h, packed.ctypes.data_as(_lib.u64p), int(dim), int(bitlevel)))
 
     def close(self):
         if self._h:
@@ -148,6 +180,13 @@ class Trainer:
     def export_quantized(self):
         out = np.empty((self.vocab_size, self.layer1_size), np.float32)
         check(lib().w2b_export_quantized(self._h, _f32(out)))
+        return out
+
+    def export_packed(self):
+        """quantize(u+v) bit-packed on the device (bitlevel 1 / 2): uint64 [vocab_size][words_per_row]"""
+        wpr = packed_words_per_row(self.layer1_size, self.cfg.bitlevel)
+        out = np.empty((self.vocab_size, wpr), np.uint64)
+        check(lib().w2b_export_packed(self._h, out.ctypes.data_as(_lib.u64p)))
         return out
 
     def model_device_ptrs(self):
