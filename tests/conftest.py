@@ -27,9 +27,11 @@ def gpu():
     # torch (used by a few tests for device-side checks of models too large to download) bundles its own HIP runtime:
     # it only finds the GPU when it initialises BEFORE the library's runtime does (observed on the MI355X boxes:
     # "No HIP GPUs are available" otherwise), which is also the order bench.py uses.
+    # (W2B_TEST_NO_TORCH=1: short builder sessions that run only tests without torch skip its minute-long first import)
     try:
-        import torch
-        torch.cuda.is_available() and torch.cuda.init()
+        if os.environ.get("W2B_TEST_NO_TORCH") != "1":
+            import torch
+            torch.cuda.is_available() and torch.cuda.init()
     except Exception:
         pass
     import word2bits_amd
