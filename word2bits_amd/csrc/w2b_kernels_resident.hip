@@ -376,9 +376,10 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
   // of a preparation, so that their latency is not on the producer's critical path either
   int t_pref = 0;
   int pstep = 0;                 // steps prepared so far in this launch (ages of the window slots)
-  bool pref_ok = false;
   float alpha_pref = P.starting_alpha;
-  bool alpha_pref_ok = false;
+  // (whether the two prefetched values are valid is DERIVED inside prepare() from pstep and the sentence length; as
+  // two flags carried from one preparation to the next they ended up in scratch memory: two loads through the vector
+  // memory pipe per step, each behind a wait for everything the producer had in flight)
   // data-wavefront registers: the row that enters the window at the next step, loaded one step early
   Col4 apre = col_zero();
   int apre_row = -1;
@@ -391,6 +392,10 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
       unsigned long long rng = S->rng;
       long long cursor = S->cursor, wc = S->wc, last_wc = S->last_wc;
       int sen_len = S->sen_len, sen_pos = S->sen_pos, ovr = S->override_, eof = S->eof;
+      // Every preparation after the first one of a launch follows a preparation that trained a position (a stop pass is
+      // never followed by another preparation), and that one has requested alpha and -- when its sentence went on, which
+      // is what a non-zero length at entry says -- the table entries of this step's negative draws.
+      const bool alpha_pref_ok = pstep > 0, pref_ok = pstep > 0 && sen_len != 0;
       int done = 0, cw = 0, nt = 0, uc_n = 0, nck = 0, next_row = -1, cdup = 0;
       float alpha = 0.f, alpha_own = 0.f;
       bool new_sentence = false, alpha_set = false;
@@ -594,16 +599,12 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
         if (sen_pos >= sen_len) sen_len = 0;
         // ---- prefetch for the next step (valid unless the next step starts with a sentence read, whose
         // sub-sampling draws come first in the LCG ledger)
-        pref_ok = (sen_len != 0);
-        if (pref_ok && lane < K) {                                       // lane l serves draw d = l + 1
+        if (sen_len != 0 && lane < K) {                                       // lane l serves draw d = l + 1
           const unsigned long long xb = rng * W2B_LCG_A + W2B_LCG_C;     // the next step's window draw
           const unsigned long long x = (L.w->ja[lane + 1] * xb + L.w->jc[lane + 1]);
           t_pref = P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
         }
         alpha_pref = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        alpha_pref_ok = true;
-      } else {
-        pref_ok = false;
       }
       if (lane == 0) {
         S->rng = rng; S->cursor = cursor; S->wc = wc; S->last_wc = last_wc;
