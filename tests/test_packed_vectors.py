@@ -106,6 +106,38 @@ def test_damaged_packed_files_are_io_errors(tmp_path):
     assert words == ["a", "b"] and np.all(M.view(np.uint32) == 0x3EAAAAAB)
 
 
+def test_packed_file_reader_survives_damage(tmp_path):
+    """random truncations, byte flips and header edits of a valid packed file: an error code or a file, never a crash
+    or an allocation sized by a damaged header"""
+    rng = np.random.default_rng(11)
+    words, M = read_vectors(os.path.join(GOLDEN, "b1_d8.vec"), True)
+    c = w2b.Corpus(CORPUS, 2)
+    good, out = str(tmp_path / "g.w2bp"), str(tmp_path / "o.vec")
+    c.save_vectors_packed(good, w2b.pack_quantized(M, 1), M.shape[1], 1)
+    c.close()
+    blob = open(good, "rb").read()
+    bad = str(tmp_path / "b.w2bp")
+    outcomes = set()
+    cases = [blob[:k] for k in rng.integers(0, len(blob), 40)]
+    for _ in range(60):
+        b = bytearray(blob)
+        for k in rng.integers(0, len(b), int(rng.integers(1, 4))):
+            b[k] = int(rng.integers(0, 256))
+        cases.append(bytes(b))
+    for hdr in (b"W2BP1 2147483000 8 1\n", b"W2BP1 99999999999999999999 8 1\n", b"W2BP1 5 16777216 2\n", b"W2BP1 -3 8 1\n",
+                b"W2BP1 5 0 1\n", b"W2BP1 5 8\n", b"W2BP1 " + b"9" * 200 + b"\n"):
+        cases.append(hdr + blob[blob.index(b"\n") + 1:])
+    for data in cases:
+        open(bad, "wb").write(data)
+        try:
+            w2b.unpack_vectors_file(bad, out, 1)
+            outcomes.add("ok")
+        except w2b.W2bError as e:
+            assert e.code in (_lib.W2B_EIO, _lib.W2B_EINVAL, _lib.W2B_EUNSUPPORTED)
+            outcomes.add("error")
+    assert outcomes == {"ok", "error"}          # (a flipped sign bit still is a valid file)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("bitlevel", [1, 2])

@@ -509,6 +509,8 @@ int w2b_internal_parse_packed(const unsigned char *d, size_t n, std::vector<std:
   const int64_t wpr = w2b_packed_words_per_row(D, bitlevel);
   if (V < 0 || wpr < 0 || V > 0x7FFFFF00ll || D > (1 << 24)) return W2B_EIO;
   size_t pos = (size_t)(nl - d) + 1;
+  // a damaged header must not size an allocation: every word takes at least its '\n', every row its words
+  if ((unsigned long long)V > n - pos || (unsigned long long)V * (unsigned long long)wpr > (n - pos) / sizeof(uint64_t)) return W2B_EIO;
   words.clear();
   words.reserve((size_t)V);
   for (long long a = 0; a < V; a++) {
