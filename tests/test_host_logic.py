@@ -286,3 +286,17 @@ def test_bench_names_the_workload_it_runs():
     assert "configs[2]" in name(vocab=60238, dim=400, bitlevel=2)
     assert name(ids="uniform") == "custom shape" and name(dim=640) == "custom shape"
     assert bench.algorithmic_bytes_per_word(800, 9, 24) == 217_736
+
+
+def test_parked_kernel_patch_still_applies():
+    """tools/patches/*.patch are experiments measured but not merged: they must keep applying to
+    the sources they patch, or be refreshed / dropped when those sources move on"""
+    import glob
+    import shutil
+    if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("needs the git checkout")
+    patches = sorted(glob.glob(os.path.join(ROOT, "tools", "patches", "*.patch")))
+    assert patches
+    for p in patches:
+        r = subprocess.run(["git", "apply", "--check", p], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, os.path.basename(p) + ": " + r.stderr[-400:]
