@@ -101,3 +101,111 @@ def test_global_alpha_schedule_matches_reference_formula():
     a = replicas.global_progress_alpha(0.05, 500_000, 5, 1_000_000)
     assert a == pytest.approx(0.05 * (1 - 500000 / 5000001), rel=1e-6)
     assert replicas.global_progress_alpha(0.05, 6_000_000, 5, 1_000_000) == pytest.approx(0.05 * 1e-4, rel=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PhasedReplicaSync -- what bench.py --gpus N falls back to when the library's own communicator is not available, and
+# what the one-GPU tests drive -- over gloo with a stand-in for the trainer that restates the library's exchange kernels
+# (k_xchg_delta / k_xchg_touched / k_xchg_apply, w2b_kernels_misc.hip) on CPU tensors: the ORCHESTRATION is what is
+# tested here (order of the phases, the chunks, the row counts of mode 2, the global word count).
+class _FakeTrainer:
+    def __init__(self, model, base, rows, dim, chunk, words):
+        self.w, self.base = model, base.clone()            # base: the state all replicas agreed on at the last exchange
+        self.rows, self.dim, self.chunk, self.words = rows, dim, chunk, words
+        self.bufs, self.log, self.cnt, self.total = {}, [], None, None
+
+    def _span(self, c):
+        o = c * self.chunk
+        return o, min(self.chunk, self.w.numel() - o)
+
+    def exchange_begin(self):
+        self.log.append("begin")
+        self.cnt = None
+        return (self.w.numel() + self.chunk - 1) // self.chunk, self.words
+
+    def exchange_counts(self):
+        self.log.append("counts")
+        changed = (self.w.view(self.rows, self.dim) != self.base.view(self.rows, self.dim)).any(1)
+        self.cnt = changed.to(torch.float32)
+        self.bufs["cnt"] = self.cnt
+        return "cnt", self.rows
+
+    def exchange_delta(self, c):
+        self.log.append("delta%d" % c)
+        o, m = self._span(c)
+        self.d = (self.w[o:o + m] - self.base[o:o + m]).clone()
+        self.bufs[c] = self.d.clone()
+        return c, m
+
+    def exchange_apply(self, c, scale):
+        self.log.append("apply%d" % c)
+        o, m = self._span(c)
+        s = self.bufs[c] * scale
+        if self.cnt is not None:                      # contributor average (every row counts as saturated here)
+            per_elem = self.cnt.clamp(min=1).repeat_interleave(self.dim)[o:o + m]
+            s = s / per_elem
+        self.w[o:o + m] += s - self.d
+        self.base[o:o + m] += s
+
+    def exchange_end(self, total):
+        self.log.append("end")
+        self.total = total
+
+    def device_tensor(self, ptr, n):
+        assert self.bufs[ptr].numel() == n
+        return self.bufs[ptr]
+
+
+def _phased_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows, dim, chunk = 40, 8, 96                  # 320 floats in chunks of 96: a ragged last chunk
+        g = torch.Generator().manual_seed(0)
+        base = torch.randn(rows * dim, generator=g)
+        out = {}
+        for mode in (0, 1, 2):
+            model = base.clone()
+            mine = torch.zeros(rows, dim)
+            mine[rank * 10:rank * 10 + 15] = float(rank + 1)        # rows 10..14 are changed by both replicas
+            model += mine.view(-1)
+            t = _FakeTrainer(model, base, rows, dim, chunk, words=1000 * (rank + 1))
+            replicas.PhasedReplicaSync(dist, t, mode).sync()
+            out[mode] = (t.w.clone(), t.base.clone(), t.total, list(t.log))
+        q.put((rank, base, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_phased_replica_sync_over_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_phased_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda x: x[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows, dim = 40, 8
+    base = res[0][1]
+    deltas = []
+    for r in range(world):
+        d = torch.zeros(rows, dim)
+        d[r * 10:r * 10 + 15] = float(r + 1)
+        deltas.append(d.view(-1))
+    total = sum(deltas)
+    cnt = sum((d.view(rows, dim) != 0).any(1).float() for d in deltas).clamp(min=1).repeat_interleave(dim)
+    want = {0: base + total, 1: base + total / world, 2: base + total / cnt}
+    for rank, _, out in res:
+        for mode in (0, 1, 2):
+            w, b, words, log = out[mode]
+            assert torch.allclose(w, want[mode], atol=1e-6), (rank, mode)
+            # base is the state the replicas agree on; a replica's own rows are (base + d) + (S - d): equal up to fp32 rounding
+            assert torch.allclose(w, b, atol=1e-6) and torch.allclose(b, want[mode], atol=1e-6)
+            assert words == 1000 + 2000                                # the alpha schedule's global word count (ref :391)
+            phases = ["begin"] + (["counts"] if mode == 2 else []) + [x for c in range(4) for x in ("delta%d" % c, "apply%d" % c)] + ["end"]
+            assert log == phases
+    assert torch.equal(res[0][2][2][1], res[1][2][2][1])               # `base` is bit-identical across the ranks

@@ -125,7 +125,8 @@ class PhasedReplicaSync:
                 host = buf.cpu()
                 self.dist.all_reduce(host)
                 buf.copy_(host)
-            torch.cuda.synchronize(buf.device)
+            if buf.is_cuda:
+                torch.cuda.synchronize(buf.device)
 
 
 def global_progress_alpha(starting_alpha, words_done_all_ranks, iters, train_words):
