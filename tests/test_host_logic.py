@@ -269,6 +269,16 @@ def test_cli_warns_about_more_workers_than_the_corpus_supports(tmp_path):
     assert "warning" not in r.stderr
 
 
+def test_cli_rejects_packed_output_of_unpackable_bitlevels_before_training(tmp_path):
+    exe = os.path.join(ROOT, "word2bits")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    out = str(tmp_path / "o.vec")
+    for bl in ("0", "4"):
+        r = subprocess.run([exe, "-train", CORPUS, "-output", out, "-packed", out + ".w2bp", "-bitlevel", bl], capture_output=True, text=True)
+        assert r.returncode == 2 and "-packed needs -bitlevel 1 or 2" in r.stderr and "Starting epoch" not in r.stdout
+
+
 def test_bench_names_the_workload_it_runs():
     """round 2 labelled every shape 'BASELINE configs[1]'; the label is built from the arguments now"""
     import importlib.util

@@ -149,6 +149,10 @@ int main(int argc, char **argv) {
     printf("Words in train file: %lld\n", train_words);
   }
   if (o.output_file.empty()) return 0;                       // ref :527
+  if (!o.packed_file.empty() && w2b_packed_words_per_row(o.layer1_size, o.bitlevel) < 0) {
+    fprintf(stderr, "word2bits: -packed needs -bitlevel 1 or 2\n");       // said before the training, not after it
+    return 2;
+  }
 
   // A worker re-computes alpha only after more than 10000 of its own words (ref :379-393).  The reference has the same
   // property, but nobody starts it with hundreds of threads on a small file; a GPU invites exactly that.
