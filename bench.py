@@ -15,8 +15,9 @@ CBOW/negative-sampling update kernel over one batch of centre words:
 
 All inputs are resident in HBM before the timed region.  N>1: one process per GPU
 (torch.distributed.run), each rank trains its own shard (weak scaling) on its own replica and
-the replicas are combined every --sync-every steps by an RCCL all-reduce of [u||v] (delta-sum),
-inside the timed region.
+the replicas are combined every --sync-every steps by an RCCL all-reduce of [u||v] (--sync-mode,
+default 2: contributor average), inside the timed region.  `--gpus N` launched without a rendezvous
+starts the N ranks itself (torch.distributed.run); with a rendezvous of another size it exits 2.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
   roofline     -- algorithmic HBM bytes per launch / hipEvent-measured launch duration vs 8 TB/s
@@ -338,20 +339,90 @@ def other_shapes():
     return out
 
 
+# ------------------------------------------------------------------------------------------ ranks
+def ensure_ranks(args):
+    """`--gpus N` means N ranks, one per GPU -- or no line at all.
+
+    * launched bare (no WORLD_SIZE in the environment) with N > 1: this process re-executes itself under
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (what the driver does
+      itself for N > 1) and exits with that job's status;
+    * launched by a rendezvous whose WORLD_SIZE differs from --gpus: exit status 2, nothing printed on stdout -- a
+      line that says `n_gpus: 1` for a `--gpus 8` command (round 3: --gpus was parsed and never read) cannot happen.
+    Returns (world, rank, local_rank)."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is None:
+        if args.gpus <= 1:
+            return 1, 0, 0
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: --gpus %d without a rendezvous: starting %d ranks (%s)" % (args.gpus, args.gpus, " ".join(cmd[1:9])),
+              file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.call(cmd))
+    world = int(ws)
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the rendezvous has WORLD_SIZE=%d ranks; refusing to report a line for a job "
+              "that is not the one asked for" % (args.gpus, world), file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def dry_run(args, world, rank):
+    """W2B_BENCH_DRY=1 (test hook, CPU): everything of the N-rank protocol that needs no GPU -- rendezvous (gloo),
+    barrier + max-over-ranks timing of K empty steps, ONE line from rank 0 -- so that `bench.py --gpus 2`, launched
+    bare, can be checked to produce two ranks on a machine without a GPU.  The line says so and carries no value."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == world
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ranks_seen = 1
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        dt, ranks_seen = float(tt.item()), int(one.item())
+    if rank == 0:
+        print(json.dumps({"metric": "training words/sec at dim=%d bitlevel=%d neg=%d" % (args.dim, args.bitlevel, args.negative),
+                          "value": None, "unit": "words/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "dry_run": "W2B_BENCH_DRY=1: rendezvous and timing protocol only, no GPU work -- not a measurement",
+                          "ranks_seen": ranks_seen, "rccl_ranks": 0}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     if args.form == "eval":
         return run_eval_form(args)
+    world, rank, local_rank = ensure_ranks(args)
+    if os.environ.get("W2B_BENCH_DRY") == "1":
+        return dry_run(args, world, rank)
     import torch
     import torch.distributed as dist
     import word2bits_amd as w2b
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if world > torch.cuda.device_count() and os.environ.get("W2B_BENCH_SHARE_GPU") != "1":
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (one rank per GPU; W2B_BENCH_SHARE_GPU=1 is the "
+                         "smoke-test hook that lets ranks share devices)" % (world, torch.cuda.device_count()))
     # (test hook for 1-GPU boxes: W2B_BENCH_SHARE_GPU=1 puts every rank on the devices that exist and
     # W2B_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device -- the N > 1 control flow of this
     # file can then be smoke-tested; such a line says so in `config.replica_sync` and is not a measurement)
@@ -567,6 +638,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ranks of the collective that actually ran: RCCL's own count for the library communicator; the process group's
+    # size when torch.distributed carried the sum over RCCL; 0 when no RCCL collective was involved (1 GPU, gloo hook)
+    if world > 1 and torch_sync is None:
+        rccl_ranks = t.comm_count()
+    elif world > 1 and backend == "nccl":
+        rccl_ranks = dist.get_world_size()
+    else:
+        rccl_ranks = 0
     total_words = words_per_step * args.steps * world
     value = total_words / dt
     bpw = algorithmic_bytes_per_word(D, cw, K)
@@ -576,7 +655,7 @@ def main():
         "metric": "training words/sec at dim=%d bitlevel=%d neg=%d" % (D, args.bitlevel, K),
         "value": value, "unit": "words/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
         "config": {"workload": "%s: synthetic %dM-token %s stream, vocab=%d, bitlevel=%d, "
                                "size=%d, window=%d, negative=%d, sample=0; form=%s, %d centre words/step/GPU"
                                % (workload_name(args), args.tokens // 1_000_000, args.ids, V, args.bitlevel, D, W, K,

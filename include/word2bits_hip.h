@@ -239,6 +239,9 @@ int w2b_comm_unique_id(void *out128);                      /* rank 0 creates, ot
  * creates no communicator (w2b_sync_replicas is then a no-op); with an id a communicator of size 1 is created and the
  * whole exchange path runs (a way to exercise it on a one-GPU machine; the model stays bit-identical). */
 int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id128);
+/* ranks of the RCCL communicator this trainer exchanges over, asked of RCCL itself (ncclCommCount): 0 = no communicator.
+ * What bench.py prints as `rccl_ranks`, so that a line claiming N GPUs can be checked against the collective that ran. */
+int w2b_comm_count(w2b_trainer *t, int32_t *nranks_out);
 /* mode 0: delta-sum (a = 1);  mode 1: average of the deltas (a = 1/R);  mode 2 (what ./word2bits -gpus N uses): delta-sum,
  * except that SATURATED rows -- rows that have been updated more than a few dozen times in every replica since the last
  * exchange, so that each replica's delta is already most of the way -- move by the MEAN of the deltas of the c replicas

@@ -196,8 +196,10 @@ def test_bench_two_ranks_control_flow(gpu):
     import sys
     from w2b_testlib import ROOT
     env = dict(os.environ, W2B_BENCH_BACKEND="gloo", W2B_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+    # launched BARE: bench.py itself starts the two ranks (round 4; the driver's own torch.distributed.run launch is the
+    # same code path from the rendezvous on)
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--tokens", "8000000", "--vocab", "50000", "--dim", "200", "--cpu-baseline", "none",
            "--also-relaxed", "0", "--also-legs", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
@@ -209,3 +211,4 @@ def test_bench_two_ranks_control_flow(gpu):
     assert d["config"]["exchanges_in_timed_region"] >= 1
     assert "SMOKE TEST" in d["config"]["replica_sync"]
     assert d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["rccl_ranks"] == 0                     # gloo hook: no RCCL collective ran, and the line says so

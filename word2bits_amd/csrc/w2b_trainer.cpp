@@ -1129,6 +1129,16 @@ extern "C" int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const
   return W2B_OK;
 }
 
+extern "C" int w2b_comm_count(w2b_trainer *t, int32_t *nranks_out) {
+  if (!t || !nranks_out) return fail(W2B_EINVAL, "w2b_comm_count: null argument");
+  *nranks_out = 0;
+  if (!t->comm) return W2B_OK;
+  int n = 0;
+  NCCLCHK(ncclCommCount(t->comm, &n));
+  *nranks_out = n;
+  return W2B_OK;
+}
+
 // ---- the exchange in phases (include/word2bits_hip.h).  Chunk c lives on exchange stream c % 2 with its own staging
 // buffers, so consecutive chunks overlap: while the collective of one chunk runs, the delta of the next is computed
 // and the sum of the previous one is applied.

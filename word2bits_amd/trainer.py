@@ -308,6 +308,12 @@ class Trainer:
         buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
         check(lib().w2b_comm_init(self._h, int(nranks), int(rank), buf))
 
+    def comm_count(self):
+        """ranks of the library's RCCL communicator as RCCL reports them (0: none)"""
+        n = C.c_int32(0)
+        check(lib().w2b_comm_count(self._h, C.byref(n)))
+        return n.value
+
     def sync_replicas(self, mode=0):
         check(lib().w2b_sync_replicas(self._h, int(mode)))
 
