@@ -136,7 +136,17 @@ typedef struct w2b_tuning {
   /* sentence-resident kernel: the most frequent context words (the rows that would be hot rows of u) are merged with
    * memory at the latest after this many steps in a worker's window, and stay resident; 0 = only when they leave */
   int32_t window_refresh;
-  int32_t reserved[4];
+  /* round 4 (carved out of the reserved fields: struct_size is unchanged, and 0 keeps meaning "the library decides") */
+  int32_t atomic_rank_u;   /* rows of u (context words) updated with atomic adds: 0 = as atomic_rank (default), > 0 = rows 1..N,
+                            * -1 = none.  The reference's own update of a context row is `u[c] += e[c]` on the CURRENT memory
+                            * value (ref :500-502): an add of a gradient computed a whole centre word earlier, never a lost one. */
+  int32_t hot_late;        /* plain worker / tuple kernels: 1 = hot target rows (the rows with per-XCD copies) are loaded after
+                            * the chunk's other dot products and get a reduction round of their own, so that they are open for
+                            * ~1 us instead of ~10 us; -1 = off; 0 = the library decides */
+  int32_t fresh_rank_u;    /* plain worker / tuple kernels: context rows 1..N are read again right before their update (phase C)
+                            * instead of taken from the LDS stash of phase A, so that the update lands on the row's CURRENT value
+                            * as the reference's `u[c] += e[c]` does (ref :500-502); 0 = the library decides, -1 = none */
+  int32_t reserved[1];
 } w2b_tuning;
 int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out);
 int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in);

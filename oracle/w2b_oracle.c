@@ -8,7 +8,7 @@
  * arithmetic, memory-buffer reader instead of stdio) but arithmetically
  * identical operation-by-operation so that, compiled WITHOUT fused
  * multiply-add contraction, it reproduces the reference binary's output
- * bit-for-bit at -threads 1 (pinned by tests/test_oracle_vs_ref.py against
+ * bit-for-bit at -threads 1 (pinned by tests/test_oracle_golden.py against
  * oracle/_ref/word2bits_nofma, and by the fixtures under tests/golden/).
  *
  * Parity status: PINNED (see above).  Build: oracle/Makefile (-ffp-contract=off).

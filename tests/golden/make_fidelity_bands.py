@@ -15,6 +15,8 @@ jobs (any subset, --jobs a,b,c):
   text8size   17 M Zipf tokens over 70 K words, bitlevel 1, size 200, negative 24, -iter 3
   planted     planted-analogy corpus, bitlevel 1 size 200 and bitlevel 2 size 400, -iter 5, scored by the unmodified
               evaluator
+  heldout_k5, heldout_zipf12   (round 4) the held-out regimes of w2b_testlib.HELDOUT: V=100 K, size 300, window 5,
+              negative 5, -sample 0; and Zipf exponent 1.2 at the configs[2] shape (bitlevel 2, size 400, negative 24)
 Each job takes "threads x runs" pairs: --headline 64x3,256x2 ...; runs of one thread count that fit side by side on the
 host's hardware threads (threads * runs <= cpu_count) are started concurrently.
 """
@@ -29,7 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from planted import make_planted, parse_accuracy                                      # noqa: E402
-from w2b_testlib import write_headline_corpus, write_zipf_text_corpus                 # noqa: E402
+from w2b_testlib import write_headline_corpus, write_zipf_text_corpus, write_heldout_corpus, HELDOUT   # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
 
@@ -81,6 +83,7 @@ def main():
     ap.add_argument("--headline-zipf-tokens", type=int, default=20_000_000)
     ap.add_argument("--text8size", default="64x2,256x2")
     ap.add_argument("--planted", default="8x3,64x3,512x3")
+    ap.add_argument("--heldout", default="64x2,256x2", help="threads x runs for the held-out regimes (jobs heldout_k5, heldout_zipf12)")
     ap.add_argument("--tmp", default="/tmp/w2b_bands")
     a = ap.parse_args()
     os.makedirs(a.tmp, exist_ok=True)
@@ -118,6 +121,17 @@ def main():
             flush()
         res["jobs"]["text8size"] = job
         os.remove(corpus)
+    for name in HELDOUT:                  # round 4: regimes no knob was ever swept on (w2b_testlib.HELDOUT)
+        if name in jobs:
+            corpus = write_heldout_corpus(os.path.join(a.tmp, name + ".txt"), name)
+            fl = HELDOUT[name]["flags"]
+            flags = sum((["-" + k, str(v)] for k, v in fl.items()), []) + ["-min-count", "5", "-binary", "1"]
+            job = {"corpus": "write_heldout_corpus(%r): %r" % (name, HELDOUT[name]["corpus"]), "flags": fl, "runs": []}
+            res["jobs"][name] = job
+            for th, runs in spec(a.heldout):
+                job["runs"] += run_many(corpus, flags, th, runs, a.tmp)
+                flush()
+            os.remove(corpus)
     if "headline" in jobs:
         corpus = write_headline_corpus(os.path.join(a.tmp, "headline.txt"), n_zipf=a.headline_zipf_tokens)
         fl = dict(bitlevel=1, size=800, window=8, negative=24, iter=1, sample=0)

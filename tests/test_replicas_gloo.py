@@ -171,8 +171,10 @@ def _phased_worker(rank, world, port, q):
             model += mine.view(-1)
             t = _FakeTrainer(model, base, rows, dim, chunk, words=1000 * (rank + 1))
             replicas.PhasedReplicaSync(dist, t, mode).sync()
-            out[mode] = (t.w.clone(), t.base.clone(), t.total, list(t.log))
-        q.put((rank, base, out))
+            out[mode] = (t.w.numpy().copy(), t.base.numpy().copy(), t.total, list(t.log))
+        # numpy arrays travel by value; torch tensors would travel as file descriptors served by THIS process, which may
+        # have exited by the time the parent unpickles them (FileNotFoundError on the resource-sharer socket: a flaky test)
+        q.put((rank, base.numpy().copy(), out))
     finally:
         dist.destroy_process_group()
 
@@ -190,6 +192,8 @@ def test_phased_replica_sync_over_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     rows, dim = 40, 8
+    res = [(r, torch.from_numpy(b), {m: (torch.from_numpy(w), torch.from_numpy(bb), tot, log) for m, (w, bb, tot, log) in o.items()})
+           for r, b, o in res]
     base = res[0][1]
     deltas = []
     for r in range(world):

@@ -283,16 +283,37 @@ def write_disjoint_shard_corpus(path, n_shards=4, sentences=60, vocab_per_shard=
     return path
 
 
-def write_zipf_text_corpus(path, vocab=70000, n_tokens=17_000_000, seed=0, line=1000):
+# Held-out regimes of the Hogwild fidelity gates (round 4): shapes and distributions that no knob of the library was ever
+# swept on -- the rules that pick hot rows / lossless rows from the word counts must carry over to them unchanged.
+HELDOUT = {
+    # a mid-sized vocabulary, short window, few negatives, one bit, no sub-sampling (every word kept by -min-count 5)
+    "heldout_k5": dict(corpus=dict(vocab=100_000, n_tokens=8_000_000, s=1.0, every=5, seed=41),
+                       flags=dict(bitlevel=1, size=300, window=5, negative=5, iter=1, sample=0)),
+    # a steeper distribution (Zipf exponent 1.2) at the BASELINE configs[2] shape, the reference's default sub-sampling
+    "heldout_zipf12": dict(corpus=dict(vocab=70_000, n_tokens=6_000_000, s=1.2, every=0, seed=42),
+                           flags=dict(bitlevel=2, size=400, window=8, negative=24, iter=2)),
+}
+
+
+def write_heldout_corpus(path, name):
+    c = HELDOUT[name]["corpus"]
+    return write_zipf_text_corpus(path, vocab=c["vocab"], n_tokens=c["n_tokens"], seed=c["seed"], s=c["s"], every=c["every"])
+
+
+def write_zipf_text_corpus(path, vocab=70000, n_tokens=17_000_000, seed=0, line=1000, s=1.0, every=0):
     """A text8-SIZED stand-in (text8 itself is not available offline): n_tokens Zipf(1) draws over `vocab` words
     'w<id>', one line of `line` tokens each (text8 is a single line; the reference cuts sentences at 1000 tokens
     anyway, ref :410).  Deterministic for a given numpy version; used by the fidelity tests and by the script that
     records what the unmodified reference does on the same file (tests/golden/make_fidelity_bands.py)."""
     rng = np.random.default_rng(seed)
-    ids = zipf_ids(rng, vocab, n_tokens)
+    ids = zipf_ids(rng, vocab, n_tokens, s)
+    if every:                          # (s, every: the held-out regimes; the defaults write the round-3 file byte for byte)
+        base = np.repeat(np.arange(1, vocab, dtype=np.int64), every)
+        rng.shuffle(base)
+        ids = np.concatenate([base, ids])
     words = np.array([b"w%d" % i for i in range(vocab)], dtype=object)
     with open(path, "wb") as f:
-        for o in range(0, n_tokens, line):
+        for o in range(0, len(ids), line):
             f.write(b" ".join(words[ids[o:o + line]]))
             f.write(b"\n")
     return path

@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(512) k_probe(float *tab, unsigned nrows, int d
   if (acc == 0x12345678u) sink[0] = acc + pad[0];
 }
 
+static int g_reps = 3;          // launches per configuration (calib mode: 1, so that dispatch order == print order)
 template <int SHAPE, int LAUX, int SAUX, int T, bool PF>
 static void run(const char *name, float *tab, unsigned nrows, int dim, int wg_per_cu, unsigned *sink, int what = 0) {
   const int threads = (SHAPE == 2) ? 256 : 448;
@@ -114,7 +115,7 @@ static void run(const char *name, float *tab, unsigned nrows, int dim, int wg_pe
   CK(hipFuncSetAttribute((const void *)k_probe<SHAPE, LAUX, SAUX, T, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   float best = 1e30f;
-  for (int rep = 0; rep < 3; rep++) {
+  for (int rep = 0; rep < g_reps; rep++) {
     CK(hipEventRecord(a));
     hipLaunchKernelGGL((k_probe<SHAPE, LAUX, SAUX, T, PF>), dim3(grid), dim3(threads), lds, 0, tab, nrows, dim, iters, sink, what);
     CK(hipEventRecord(b));
@@ -125,13 +126,33 @@ static void run(const char *name, float *tab, unsigned nrows, int dim, int wg_pe
   const double bytes = (what ? 1.0 : 2.0) * grid * (double)iters * T * dim * 4;
   printf("%-34s T=%2d pf=%d wg/cu=%d: %8.3f ms  %6.2f TB/s (%s)\n", name, T, (int)PF, wg_per_cu, best, bytes / best / 1e9,
          what == 0 ? "read+write" : (what == 1 ? "reads only" : "writes only"));
+  if (g_reps == 1)            // calib mode: known bytes of this dispatch, for tools/pmc_calib.py
+    printf("CALIB %s | read_bytes %.0f | write_bytes %.0f\n", name, what == 2 ? 0.0 : (double)grid * iters * T * dim * 4,
+           what == 1 ? 0.0 : (double)grid * iters * T * dim * 4);
   fflush(stdout);
 }
 
-int main() {
+int main(int argc, char **argv) {
   const unsigned nrows = 400000; const int dim = 800;
   float *tab; unsigned *sink;
   CK(hipMalloc(&tab, (size_t)nrows * dim * 4)); CK(hipMemset(tab, 0, (size_t)nrows * dim * 4)); CK(hipMalloc(&sink, 64));
+  if (argc > 1 && argv[1][0] == 'c') {
+    // `row_probe calib` under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`: ONE launch per configuration with a known
+    // number of row bytes read and written (16-byte lanes, random 3200-byte rows of a 1.28 GB table: the access shape of the
+    // training kernels), for each cache policy the kernels use -- plain, sc1 (coherent rows), nt (per-XCD hot-row copies).
+    // tools/pmc_calib.py joins the CALIB lines with the counter CSV (dispatch order) into calibration factors.
+    g_reps = 1;
+    run<2, 0, 0, 12, false>("plain reads", tab, nrows, dim, 2, sink, 1);
+    run<2, 0, 0, 12, false>("plain writes", tab, nrows, dim, 2, sink, 2);
+    run<2, 0, 0, 12, false>("plain read+write", tab, nrows, dim, 2, sink, 0);
+    run<2, 16, 16, 12, false>("sc1 reads", tab, nrows, dim, 2, sink, 1);
+    run<2, 16, 16, 12, false>("sc1 writes", tab, nrows, dim, 2, sink, 2);
+    run<2, 16, 16, 12, false>("sc1 read+write", tab, nrows, dim, 2, sink, 0);
+    run<2, 2, 2, 12, false>("nt reads", tab, nrows, dim, 2, sink, 1);
+    run<2, 2, 2, 12, false>("nt writes", tab, nrows, dim, 2, sink, 2);
+    run<2, 2, 2, 12, false>("nt read+write", tab, nrows, dim, 2, sink, 0);
+    return 0;
+  }
 #define ROW(SH, LA, SA, T, W, NAME) run<SH, LA, SA, T, false>(NAME, tab, nrows, dim, W, sink); run<SH, LA, SA, T, true>(NAME, tab, nrows, dim, W, sink);
   for (int pass = 0; pass < 1; pass++) {
     ROW(0, 0, 0, 12, 2, "8B/lane plain+plain");

@@ -28,9 +28,14 @@
 #ifndef W2B_T
 #define W2B_T 13   // most target rows kept in registers per chunk (LDS sizing); see TFor below
 #endif
-// target rows per chunk of the plain kernels: 13 (negative=24 -> 25 targets = 13 + 12) without the loss
-// bookkeeping, 9 (9 + 9 + 7) with it -- the widest chunk that stays within 128 VGPRs without spilling
-template <bool LOSS> struct TFor { static constexpr int value = LOSS ? 9 : W2B_T; };
+// target rows per chunk of the plain kernels: 13 (negative=24 -> 25 targets = 13 + 12), the widest chunk that stays
+// within 128 VGPRs without spilling -- with and without the loss bookkeeping (round 4: the log-sigmoid terms are
+// booked from the f values parked in LDS after phase C, when the chunk's registers are free, and the reg * sum q^2
+// terms share one accumulator per thread; rounds 1-3 ran the loss-computing instantiation with 9-row chunks)
+#ifndef W2B_T_LOSS
+#define W2B_T_LOSS W2B_T
+#endif
+template <bool LOSS> struct TFor { static constexpr int value = LOSS ? W2B_T_LOSS : W2B_T; };
 #ifndef W2B_CA
 #define W2B_CA 8   // context rows loaded per sub-chunk
 #endif
@@ -205,9 +210,10 @@ struct WordLds {
   int *ctx;     // [maxc]  context rows of u, window order (ref :431-436)
   int *umult;   // [maxc]  multiplicity at the first occurrence of a row, 0 at later duplicates
   int *tgt;     // [maxt]  target rows of v: [0] = centre word (label 1), then kept negatives (label 0)
-  int *prev;    // [maxt]  index of the previous occurrence of the same target row, or -1
+  int *prev;    // [maxt]  index of the previous occurrence of the same target row, or -1 (prep_lists only; process_word
+                //         parks the dot products f of the targets here for the loss bookkeeping)
   int *cend;    // [maxt]  end index of every target chunk (a chunk is cut at W2B_T rows or at a repeated row)
-  float *red;   // [2][W2B_T][W2B_MAXW] cross-wave partial dot products (double buffered)
+  float *red;   // [3][W2B_T][W2B_MAXW] cross-wave partial dot products (double buffered) + the late round of the hot rows
   float *stash; // [W2B_STASH][blockDim][VEC] raw u columns of the first context rows, private to the
                 // owning thread: phase C updates them without a second trip to memory
   float *xprod; // exact mode only: [W2B_T][W2B_EXACT_COLS + 1] products of the current column block
@@ -221,7 +227,7 @@ __device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int neg
   L.stash = reinterpret_cast<float *>(base);
   base += W2B_STASH * blockDim.x * vec;
   L.red = reinterpret_cast<float *>(base);
-  int *p = base + 2 * W2B_T * W2B_MAXW;
+  int *p = base + 3 * W2B_T * W2B_MAXW;
   L.ctx = p; p += maxc;
   L.umult = p; p += maxc;
   L.tgt = p; p += maxt;
@@ -301,7 +307,10 @@ __device__ __forceinline__ void add_col(float *tab, long long row, int dim, int 
     soff = 0;
   }
 #pragma unroll
-  for (int e = 0; e < VEC; e++) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(d.e[e], r, (col0 + e) * 4, soff, 0);
+  // aux 16 = sc1: agent scope, like every other coherent row access (the adds of workers on different XCDs meet at the
+  // memory side, and they are ordered against the sc1 loads / stores of the non-atomic rows' accesses; round 3 issued
+  // them without scope bits -- tools/atomic_probe.hip checks both forms for lost adds)
+  for (int e = 0; e < VEC; e++) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(d.e[e], r, (col0 + e) * 4, soff, 16);
 }
 
 // ------------------------------------------------------------------------------------ XCD-local copies of the hot rows
@@ -412,7 +421,7 @@ __device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot 
 // X: this XCD's copies of the hottest rows (nu = nv = 0: none; VEC == 4 only): a row k <= nu of u / k <= nv of v is read
 // and written at its copy instead of its master address.  Passed by reference, so that its fields stay in registers.
 // P.atomic_rank: the other rows among 1..atomic_rank are updated with atomic adds at their master address.
-template <int QM, int VEC, bool LOSS, int MM>
+template <int QM, int VEC, bool LOSS, int MM, bool LATE = false>
 __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &L, const QParam &qp,
                                              const int cw, const int nt, const float alpha,
                                              double &loss_acc, const XHot &X) {
@@ -438,10 +447,10 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     return load_col<VEC, MM>(P.u, row, dim, col0, P.tab_bytes);
   };
   // row <- val (= old + d): a store (hot rows: to this XCD's copy), or an atomic add of d for rows 1..atomic_rank
-  const int atomic_rank = P.atomic_rank;
+  const int atomic_rank = P.atomic_rank, atomic_rank_u = P.atomic_rank_u;
   auto up_u = [&](int row, const Col<VEC> &val, const Col<VEC> &d) {
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) { xhot_st(X.cu, row - 1, nhu, dim, col0, val); return; } }
-    if (row <= atomic_rank) add_col<VEC>(P.u, row, dim, col0, d, P.tab_bytes);
+    if (row <= atomic_rank_u) add_col<VEC>(P.u, row, dim, col0, d, P.tab_bytes);
     else store_col<VEC, MM>(P.u, row, dim, col0, val, P.tab_bytes);
   };
   auto ld_v = [&](int row) -> Col<VEC> {
@@ -453,15 +462,25 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     if (row <= atomic_rank) add_col<VEC>(P.v, row, dim, col0, d, P.tab_bytes);
     else store_col<VEC, MM>(P.v, row, dim, col0, val, P.tab_bytes);
   };
+  // Late round (P.hot_late, hot rows of v only): a hot target row is NOT loaded with its chunk -- ~10 us before its store,
+  // while the other workers of the XCD keep updating the same copy -- but after the chunk's other dot products are under
+  // way, and gets a reduction round of its own: open for about a microsecond.  The error accumulation and the stores
+  // stay in target order, so a single worker computes bit for bit what it computes without the late round.
+  // (LATE is an instantiation of its own: compiled into the common kernel, the extra round cost it 30 spilled VGPRs)
+  const bool late = LATE && (VEC == 4) && nhv > 0;
+  unsigned latemask = 0;                                        // wave-uniform: chunk slots that hold a hot row
   // one chunk of target rows
   auto load_targets = [&](bool zero) {
+    latemask = 0;
 #pragma unroll
     for (int i = 0; i < TC; i++) {
-      if (zero) {
+      const bool is_late = late && start + i < end && (unsigned)(rows[i] - 1) < (unsigned)nhv;
+      if (is_late) latemask |= 1u << i;
+      if (zero || is_late) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
       }
-      if (active && start + i < end) x[i] = ld_v(rows[i]);
+      if (active && start + i < end && !is_late) x[i] = ld_v(rows[i]);
     }
   };
   // issue the first chunk of target-row loads before the context phase so both gathers overlap
@@ -469,7 +488,9 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
 
   // ---- phase A: context_avg = (1/cw) * sum_j quantize(u[ctx_j])   (ref :431-449)
   Col<VEC> avg;
-  float regsq = 0.f;
+  float regsq = 0.f;                       // LOSS with reg != 0: this thread's sum of q^2 over the window rows AND the target rows
+  const bool reg_on = P.reg != 0.f;
+  float *fsave = reinterpret_cast<float *>(L.prev);
 #pragma unroll
   for (int e = 0; e < VEC; e++) avg.e[e] = 0.f;
   for (int j0 = 0; j0 < cw; j0 += W2B_CA) {
@@ -488,7 +509,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
         for (int e = 0; e < VEC; e++) {
           const float q = quant<QM>(r[jj].e[e], qp);
           avg.e[e] += q;
-          if (LOSS) regsq += q * q;
+          if (LOSS && reg_on) regsq += q * q;
         }
       }
   }
@@ -505,22 +526,27 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
   int par = 0;
   for (;;) {
     const int n = end - start;
-    float p[TC], p2[TC];
+    float p[TC];
 #pragma unroll
     for (int i = 0; i < TC; i++) {
-      float t[VEC], s2 = 0.f;
+      float t[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; e++) {
         const float q = quant<QM>(x[i].e[e], qp);
         t[e] = avg.e[e] * q;                                    // ref :466 (re-associated as a binary tree)
-        if (LOSS) s2 += q * q;
       }
-      // pairwise: the same tree over the elements as the 8-byte-column kernel (w2b_kernels_workers2.hip)
+      // pairwise tree over the elements of a column
       const float s = (VEC == 4) ? (t[0] + t[1 % VEC]) + (t[2 % VEC] + t[3 % VEC]) : ((VEC == 2) ? t[0] + t[1 % VEC] : t[0]);
       p[i] = active ? s : 0.f;
-      p2[i] = active ? s2 : 0.f;
     }
     float *red = L.red + par * (TC * W2B_MAXW);
+    if constexpr (VEC == 4 && LATE) {
+      if (latemask) {                                           // the hot rows of this chunk: loads in flight during the reduction below
+#pragma unroll
+        for (int i = 0; i < TC; i++)
+          if (((latemask >> i) & 1u) && active) x[i] = xhot_ld(X.cv, rows[i] - 1, nhv, dim, col0);
+      }
+    }
     if (MM == W2B_MM_EXACT) {
       // ref :461-467 in the reference's own order: f = 0; for c: f += context_avg[c] * quantize(v[c]) -- every
       // product rounded, then added to the running sum.  The products of a block of columns go to LDS, lane i of
@@ -569,22 +595,33 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
       else if (f < -6.f) g = label * alpha;
       else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
       gl = g;
-      if (LOSS && wave == 0) {                                  // ref :480-483
-        const float dp = (label != 0.f) ? f : -f;
-        float sg;
-        if (dp > 6.f) sg = 1.f;
-        else if (dp < -6.f) sg = 1e-9f;
-        else sg = 1.f / (1.f + expf(-dp));
-        loss_acc += (double)logf(sg);
-      }
+      if (LOSS && wave == 0) fsave[start + lane] = f;           // the log-sigmoid term of ref :480-483 is booked after phase C
     }
-    if (LOSS && P.reg != 0.f) {                                 // reg * sum q^2 of every target row
+    if (LATE && latemask) {
+      float *red3 = L.red + 2 * (TC * W2B_MAXW);
 #pragma unroll
-      for (int i = 0; i < TC; i++)
-        if (i < n) {
-          const float s2 = wave_sum(p2[i]);
-          if (lane == 0) loss_acc -= (double)(P.reg * s2);
+      for (int i = 0; i < TC; i++) {
+        if ((latemask >> i) & 1u) {
+          float t[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; e++) t[e] = avg.e[e] * quant<QM>(x[i].e[e], qp);
+          const float sl = (VEC == 4) ? (t[0] + t[1 % VEC]) + (t[2 % VEC] + t[3 % VEC]) : ((VEC == 2) ? t[0] + t[1 % VEC] : t[0]);
+          const float ws = wave_sum(active ? sl : 0.f);
+          if (lane == 0) red3[i * W2B_MAXW + wave] = ws;
         }
+      }
+      __syncthreads();
+      if (lane < n && ((latemask >> lane) & 1u)) {
+        float f = 0.f;
+        for (int w = 0; w < nwaves; w++) f += red3[lane * W2B_MAXW + w];
+        const float label = (start + lane == 0) ? 1.f : 0.f;
+        float g;
+        if (f > 6.f) g = (label - 1.f) * alpha;
+        else if (f < -6.f) g = label * alpha;
+        else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
+        gl = g;
+        if (LOSS && wave == 0) fsave[start + lane] = f;
+      }
     }
     // error accumulation + row update, in target order (ref :486-491)
 #pragma unroll
@@ -599,7 +636,9 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
             // opaque copy: re-derive the quantized value here instead of keeping VEC extra registers per
             // row alive since the dot product (halves the register footprint of a chunk)
             if (QM != 0) asm volatile("" : "+v"(xv));
-            err.e[e] += g * quant<QM>(xv, qp);
+            const float q = quant<QM>(xv, qp);
+            if (LOSS && reg_on) regsq += q * q;                 // reg * sum q^2 of every target row (ref :463,:468-471)
+            err.e[e] += g * q;
             dl.e[e] = g * avg.e[e] - ar2 * xv;
             x[i].e[e] = xv + dl.e[e];
           }
@@ -622,7 +661,10 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     for (int jj = 0; jj < W2B_CA; jj++)
       if (active && j0 + jj < cw && L.umult[j0 + jj] > 0) {
         const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
-        if (j0 + jj < W2B_STASH) {
+        // rows 1..fresh_rank_u are read AGAIN here instead of taken from the stash: the reference's update is
+        // `u[c] += e[c]` on the current memory value (ref :500-502); the stashed value is a whole centre word (~30 us) old,
+        // and storing stash + e would erase what every other worker added to a frequent row in between
+        if (j0 + jj < W2B_STASH && crow > P.fresh_rank_u) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) r[jj].e[e] = L.stash[((j0 + jj) * blockDim.x + tid) * VEC + e];
         } else {
@@ -635,7 +677,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
         const int m = L.umult[j0 + jj];
         if (m > 0) {
           const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
-          const bool by_add = crow <= atomic_rank && !(VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu);
+          const bool by_add = crow <= atomic_rank_u && !(VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu);
           Col<VEC> dl;
           for (int k = 0; k < m; k++) {      // a row that occurs m times in the window is updated m times
 #pragma unroll
@@ -649,9 +691,24 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
         }
       }
   }
-  if (LOSS && P.reg != 0.f) {
-    const float s = wave_sum(regsq);
-    if (lane == 0) loss_acc -= (double)(P.reg * s);             // ref :437-445 (summed over the window)
+  if (LOSS) {
+    // ref :480-483 for all targets of this centre word, now that the chunk registers are free: lane j of wavefront 0
+    // takes target j (f parked in LDS by the same wavefront; in-order LDS + the barriers in between)
+    if (wave == 0) {
+      for (int j = lane; j < nt; j += 64) {
+        const float f = fsave[j];
+        const float dp = (j == 0) ? f : -f;                     // target 0 is the centre word (label 1)
+        float sg;
+        if (dp > 6.f) sg = 1.f;
+        else if (dp < -6.f) sg = 1e-9f;
+        else sg = 1.f / (1.f + expf(-dp));
+        loss_acc += (double)logf(sg);
+      }
+    }
+    if (reg_on) {
+      const float s = wave_sum(active ? regsq : 0.f);
+      if (lane == 0) loss_acc -= (double)(P.reg * s);           // ref :437-445 and :463-471: window rows + target rows
+    }
   }
   __syncthreads();
 }

@@ -5,7 +5,7 @@
 namespace {
 // ------------------------------------------------------------------------------------ form (i): workers
 
-template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM>
+template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM, bool LATE = false>
 __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES : 1)) k_train_workers(const W2bParams P, const long long max_positions) {
   extern __shared__ int smem[];
   WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     if constexpr (VEC == 1 && MAXTHREADS == 1024) wide = P.wide != 0;
     if (cw > 0) {
       if (wide) { if constexpr (VEC == 1 && MAXTHREADS == 1024) process_word_wide<QM, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc); }
-      else process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, XH);
+      else process_word<QM, VEC, LOSS, MM, LATE>(P, L, qp, cw, nt, alpha, loss_acc, XH);
     } else __syncthreads();
     if (VEC == 4 && hot && ++since_merge >= P.hot_period) {
       since_merge = 0;
@@ -171,6 +171,13 @@ hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool 
 #define W2B_LAUNCH_W(VEC, LOSS) \
     do { if (threads <= 256) hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 256, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); \
          else hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 1024, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); } while (0)
+    if constexpr (MM == 0) {          // hot target rows in a late round of their own (w2b_tuning.hot_late): 16-byte columns, coherent rows
+      if (p.hot_late && vec == 4 && threads <= 256 && p.xhot && p.xhot_v > 0) {
+        if (loss) hipLaunchKernelGGL((k_train_workers<QM, 4, true, 256, 0, true>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions);
+        else hipLaunchKernelGGL((k_train_workers<QM, 4, false, 256, 0, true>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions);
+        return hipGetLastError();
+      }
+    }
     if (vec == 4) { if (loss) W2B_LAUNCH_W(4, true); else W2B_LAUNCH_W(4, false); }
     else { if (loss) W2B_LAUNCH_W(1, true); else W2B_LAUNCH_W(1, false); }
 #undef W2B_LAUNCH_W

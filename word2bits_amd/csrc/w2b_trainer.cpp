@@ -217,6 +217,9 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.uavg_rank = 0;
   p.win_refresh = t->tune.window_refresh;
   p.atomic_rank = 0;
+  p.atomic_rank_u = 0;
+  p.hot_late = 0;
+  p.fresh_rank_u = 0;
   (void)w2b_block_threads(t->cfg.layer1_size, nullptr, &p.wide);   // rows longer than a workgroup has columns
   p.wide_scratch = t->wide_scratch;
   p.starting_alpha = t->cfg.alpha;
@@ -353,6 +356,9 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
 #endif
   if (in->atomic_rank < -1 || in->atomic_cap < 0) return fail(W2B_EINVAL, "w2b_set_tuning: atomic_rank >= -1, atomic_cap >= 0");
   if (in->window_refresh < 0) return fail(W2B_EINVAL, "w2b_set_tuning: window_refresh must be >= 0");
+  if (in->atomic_rank_u < -1) return fail(W2B_EINVAL, "w2b_set_tuning: atomic_rank_u >= -1");
+  if (in->fresh_rank_u < -1) return fail(W2B_EINVAL, "w2b_set_tuning: fresh_rank_u >= -1");
+  if (in->hot_late < -1 || in->hot_late > 1) return fail(W2B_EINVAL, "w2b_set_tuning: hot_late must be -1, 0 or 1");
   if (in->hot_weight_permille < 1 || in->hot_weight_permille > 1000)
     return fail(W2B_EINVAL, "w2b_set_tuning: hot_weight_permille must be 1..1000");
   for (int r : in->reserved) if (r != 0) return fail(W2B_EINVAL, "w2b_set_tuning: reserved fields must be zero");
@@ -803,6 +809,10 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   p.xhot_u = nu;
   p.xhot_v = nv;
   p.atomic_rank = atomic_plan(t, workers);
+  p.atomic_rank_u = t->tune.atomic_rank_u > 0 ? (t->tune.atomic_rank_u < t->cfg.vocab_size - 1 ? t->tune.atomic_rank_u : (int)(t->cfg.vocab_size - 1))
+                                              : (t->tune.atomic_rank_u < 0 ? 0 : p.atomic_rank);
+  p.hot_late = t->tune.hot_late > 0 ? 1 : 0;
+  p.fresh_rank_u = t->tune.fresh_rank_u > 0 ? t->tune.fresh_rank_u : 0;
   if (!with_u) {          // sentence-resident kernel: its context rows live in LDS; the most frequent ones (the rows that
     int un = 0, vn = 0;   // would be hot rows of u) are merged by consensus and refreshed (w2b_kernels_resident.hip)
     xhot_plan(t, workers, true, &un, &vn);
