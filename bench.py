@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--zipf-shift", type=int, default=0,
                     help="experiment: Zipf weights 1/(rank + N) instead of 1/rank (a Zipf stream without its N hottest words)")
     ap.add_argument("--sync-every", type=int, default=16)
+    ap.add_argument("--sync-hot-mb", type=int, default=64,
+                    help="N>1: after every step that has no full exchange, the hot tier -- at most this many MB of leading rows "
+                         "per table (w2b_sync_hot_rows; 0 = off), as ./word2bits -gpus N does")
     ap.add_argument("--sync-mode", type=int, default=2,
                     help="0 delta-sum, 1 average, 2 contributor average (what ./word2bits -gpus N uses)")
     ap.add_argument("--sync-impl", choices=["lib", "torch"], default="lib",
@@ -595,7 +598,17 @@ def main():
 
     n_syncs = [0]
 
-    def exchange():
+    n_hot = [0]
+
+    def exchange(hot=False):
+        if hot:                 # the leading rows only (a few MB), rule of mode 2 over the short interval
+            horizon = args.sync_every * words_per_step
+            if torch_sync is not None:
+                torch_sync.sync_hot(horizon, args.sync_hot_mb << 20)
+            else:
+                t.sync_hot_rows(horizon, args.sync_hot_mb << 20)
+            n_hot[0] += 1
+            return
         if torch_sync is not None:
             torch_sync.sync()
         else:
@@ -611,6 +624,8 @@ def main():
                 done = i + 1 - args.warmup
                 if done % args.sync_every == 0 or i + 1 == n1:
                     exchange()
+                elif args.sync_hot_mb > 0:
+                    exchange(hot=True)
 
     run(0, args.warmup, False)
     if world > 1:
@@ -627,7 +642,10 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0 and torch_sync is None:
             raise SystemExit("library exchange failed after its communicator was created")
-        n_syncs[0] = 0
+        if args.sync_hot_mb > 0:
+            exchange(hot=True)                     # (first use of the hot tier stays out of the timed region as well)
+        t.synchronize()
+        n_syncs[0] = n_hot[0] = 0
         t.sync_stats()
     t.synchronize()
     t.timing_enable(True)
@@ -675,7 +693,7 @@ def main():
                                     "agent scope (sc1): Hogwild coherent across the 8 XCD L2s",
                    "replica_sync": ("%s every %d steps, mode %d (0 delta-sum, 1 average, 2 contributor average)" %
                                     (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl,
-                   "exchanges_in_timed_region": n_syncs[0],
+                   "exchanges_in_timed_region": n_syncs[0], "hot_tier_exchanges_in_timed_region": n_hot[0],
                    "worker_kernel": (dict(zip(("sentence_resident", "radius", "column_bytes", "workers_per_cu",
                                                "hot_rows_with_xcd_copies"), kinfo)) if kinfo else None),
                    "tuning": tuning_used,
@@ -710,7 +728,10 @@ def main():
     if world > 1:
         result["replica_exchange"] = {
             "every_steps": args.sync_every, "mode": ["delta-sum", "average", "contributor average"][args.sync_mode],
-            "implementation": sync_impl, "exchanges": n_syncs[0],
+            "implementation": sync_impl, "exchanges": n_syncs[0], "hot_tier_exchanges": n_hot[0],
+            "hot_tier": ("after every other step: at most %d MB of leading rows per table, %s rows of u / v at this shape"
+                         % (args.sync_hot_mb, list(t.exchange_hot_rows(args.sync_every * words_per_step, args.sync_hot_mb << 20)))
+                         if args.sync_hot_mb > 0 else "off"),
             "bytes": 8 * V * D, "bytes_all_reduced_per_exchange": 8 * V * D,
             "device_ms": (sync_ms / sync_n) if sync_n else None,
             "device_ms_per_exchange": (sync_ms / sync_n) if sync_n else None,

@@ -260,6 +260,17 @@ int w2b_comm_count(w2b_trainer *t, int32_t *nranks_out);
  * by R as well).  The more often the replicas exchange, the fewer rows are saturated.  Measured in
  * tests/test_gpu_exchange.py.  Asynchronous (see above). */
 int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
+/* HOT TIER (round 4).  What costs a replicated run its epoch loss is how long the FREQUENT rows stay apart, not the
+ * rare ones: a row that receives hundreds of updates per replica between two exchanges ends up as the mean of R models
+ * that each saw 1/R of the data.  w2b_sync_hot_rows exchanges only the leading rows of both tables -- the rows that would
+ * be saturated over `horizon_words` centre words per replica (the interval of the full exchanges), at most budget_bytes of
+ * rows per table, a few MB where a full exchange is GBs -- with the rule of mode 2 evaluated over the SHORT interval since
+ * the previous exchange: rows still saturated move by the mean of their contributors, the others by the sum.  Meant to be
+ * called after every launch, with w2b_sync_replicas(mode 2) every N launches for the tail.  The next training launch
+ * waits for it (it moves exactly the rows the per-XCD hot-row copies are folded into); a full exchange stays asynchronous. */
+int w2b_sync_hot_rows(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes);
+/* rows 1..*rows_u of u and 1..*rows_v of v that w2b_sync_hot_rows / w2b_exchange_begin_hot would exchange */
+int w2b_exchange_hot_rows(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes, int32_t *rows_u, int32_t *rows_v);
 /* exchanges since the last call and their summed device time (begin of the first chunk -> end of the last; waits for
  * the exchanges in flight); resets both */
 int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
@@ -276,6 +287,9 @@ int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
  * Chunks c and c + 1 use different staging buffers and streams, so a host may pipeline them. */
 int w2b_exchange_init(w2b_trainer *t);
 int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count /* or NULL */);
+/* the hot tier of w2b_sync_hot_rows in phases: the chunks that follow are the leading rows of u and of v */
+int w2b_exchange_begin_hot(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes, int64_t *n_chunks,
+                           int64_t *local_word_count /* or NULL */);
 int w2b_exchange_counts(w2b_trainer *t, void **buf_dev, int64_t *elems);
 int w2b_exchange_delta(w2b_trainer *t, int64_t chunk, void **buf_dev, int64_t *elems);
 int w2b_exchange_apply(w2b_trainer *t, int64_t chunk, float scale);

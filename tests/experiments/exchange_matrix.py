@@ -1,0 +1,42 @@
+"""Measurement, not a test: training effect of the replica exchange on ONE GPU (R replicas in this process, the collective
+supplied through the phase API -- tests/test_gpu_exchange.py run_replicas) over launch length x exchange scheme.
+  python tests/experiments/exchange_matrix.py [--positions 1024,256,64] [--replicas 2,4]
+Schemes per (R, positions): none (end of epoch only) | full every launch (mode 2) | two-tier: hot tier (B MB per table) after
+every launch + full every E launches.  Printed: epoch loss and its deviation from the single replica at the same positions."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import word2bits_amd as w2b
+from w2b_testlib import write_zipf_text_corpus
+from test_gpu_exchange import run_replicas
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--positions", default="1024,256,64")
+ap.add_argument("--replicas", default="2,4")
+ap.add_argument("--tiers", default="8:4,8:16,32:16", help="E:B pairs: full exchange every E launches, hot tier of B MB per table")
+a = ap.parse_args()
+path = write_zipf_text_corpus("/tmp/w2b_xm_t8.txt")
+corpus = w2b.Corpus(path, 5)
+flags = dict(bitlevel=1, size=200, window=8, negative=24)
+probe = w2b.Trainer(2, 200, 8, 24, 1, num_threads=1, train_words=corpus.train_words)
+workers = probe.suggested_threads(); probe.close()
+workers -= workers % 4
+for positions in [int(x) for x in a.positions.split(",")]:
+    t0 = time.time()
+    one, launches = run_replicas(corpus, 1, workers, 1, positions, flags)
+    print("XM positions=%d workers=%d launches/epoch=%d: 1 replica loss %.0f  [%.1f s]" % (positions, workers, launches, one, time.time() - t0), flush=True)
+    for R in [int(x) for x in a.replicas.split(",")]:
+        schemes = [("none", dict(sync_every=0)), ("full every launch", dict(sync_every=1))]
+        for eb in a.tiers.split(","):
+            E, B = [int(x) for x in eb.split(":")]
+            schemes.append(("two-tier E=%d B=%dMB" % (E, B), dict(sync_every=E, hot_mb=B)))
+            schemes.append(("full every %d only" % E, dict(sync_every=E)))
+        seen = set()
+        for name, kw in schemes:
+            if name in seen:
+                continue
+            seen.add(name)
+            t0 = time.time()
+            loss, _ = run_replicas(corpus, R, workers, positions=positions, flags=flags, mode=2, **kw)
+            print("XM positions=%-5d R=%d %-26s loss %.0f (%+.2f %% vs 1 replica)  [%.1f s]" % (positions, R, name, loss, 100 * (loss - one) / abs(one), time.time() - t0), flush=True)
+corpus.close(); os.remove(path)

@@ -158,14 +158,17 @@ __global__ void k_xhot_fold(const W2bParams P) {
   const int r = blockIdx.x;
   const bool is_u = r < nu;
   const int k = is_u ? r : r - nu;
-  w2b_f4 *master = reinterpret_cast<w2b_f4 *>((is_u ? P.u : P.v) + (long long)(k + 1) * dim);
+  // the master row is read and written at agent scope (sc1), like every other access to it: a replica exchange may be
+  // applying the other replicas' contribution to the same row on its own stream (k_xchg_apply), and a plain access could
+  // work on a stale L2 line of this XCD
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)((is_u ? P.u : P.v) + (long long)(k + 1) * dim), 0, dim * 4, 0x27000);
   const long long per_xcd = 2ll * (nu + nv) * dim + (long long)(nu + nv) * W2B_MAXW,      // copies, entries, merge locks
                   copy_off = (long long)(is_u ? k : nu + k) * dim, entry_off = copy_off + (long long)(nu + nv) * dim;
   if (threadIdx.x < W2B_MAXW)                      // (no merge is in progress between launches)
     for (int x = 0; x < W2B_NXCD; x++)
       reinterpret_cast<unsigned *>(P.xhot + x * per_xcd + 2ll * (nu + nv) * dim)[(is_u ? k : nu + k) * W2B_MAXW + threadIdx.x] = 0u;
   for (int c = threadIdx.x; c < dim / 4; c += blockDim.x) {
-    w2b_f4 m = master[c];
+    w2b_f4 m = xchg_ld_sc1(rm, c);
     for (int x = 0; x < W2B_NXCD; x++) {
       const w2b_f4 cv = reinterpret_cast<const w2b_f4 *>(P.xhot + x * per_xcd + copy_off)[c];
       const w2b_f4 ev = reinterpret_cast<const w2b_f4 *>(P.xhot + x * per_xcd + entry_off)[c];
@@ -176,7 +179,7 @@ __global__ void k_xhot_fold(const W2bParams P) {
         m[i] = me ? cv[i] : (ce ? m[i] : m[i] + P.xhot_w * (cv[i] - m[i]));
       }
     }
-    master[c] = m;
+    xchg_st_sc1(rm, c, m);
     for (int x = 0; x < W2B_NXCD; x++) {
       reinterpret_cast<w2b_f4 *>(P.xhot + x * per_xcd + copy_off)[c] = m;
       reinterpret_cast<w2b_f4 *>(P.xhot + x * per_xcd + entry_off)[c] = m;

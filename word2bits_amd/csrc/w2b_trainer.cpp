@@ -90,6 +90,13 @@ struct w2b_trainer {
   // replica exchange (see "multi-GPU" below): two exchange streams, chunk staging buffers, events
   hipStream_t xs[2] = {nullptr, nullptr};
   float *xd[2] = {nullptr, nullptr}, *xsum[2] = {nullptr, nullptr};   // per slot: own delta / sum over the replicas
+  struct XRange { long long off, len; };    // floats of [u || v]
+  std::vector<XRange> x_ranges;             // the chunks of the exchange in progress (full: the whole model; hot tier: two prefixes)
+  bool x_hot = false, x_open = false;       // the exchange in progress is a hot-tier one / has begun and not ended
+  bool x_fence_next_launch = false;         // the next training launch waits for the exchange in flight (hot tier)
+  int x_hot_u = 0, x_hot_v = 0;             // rows 0..x_hot_* of u / v are the hot tier of the exchange in progress
+  long long x_words_full = 0;               // centre words since the previous FULL exchange
+  hipEvent_t x_evd[2] = {nullptr, nullptr}, x_evs[2] = {nullptr, nullptr}, x_evc = nullptr;   // delta / sum of a slot complete; counts summed
   float *xcnt = nullptr;                    // [2 * vocab_size]: replicas that changed each row (contributor-average mode)
   bool x_use_cnt = false;                   // the exchange in progress damps the saturated rows' sums by xcnt
   int x_sat_u = 0, x_sat_v = 0;             // rows 1..x_sat_* of u / v count as saturated in the exchange in progress
@@ -300,6 +307,9 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
   return W2B_OK;
 }
 
+static int xchg_fence(w2b_trainer *t);      // the training stream waits for a replica exchange in flight (below)
+static void xchg_teardown(w2b_trainer *t);  // streams, events and buffers of the replica exchange
+
 extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
@@ -319,10 +329,8 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   if (t->poll_host) (void)hipHostFree(t->poll_host);
   for (hipStream_t q : t->xs) if (q) (void)hipStreamSynchronize(q);
   for (hipEvent_t e : t->x_ev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : t->x_done) if (e) (void)hipEventDestroy(e);
-  if (t->x_train) (void)hipEventDestroy(t->x_train);
-  for (hipStream_t q : t->xs) if (q) (void)hipStreamDestroy(q);
-  void *ptrs[] = {t->xcnt, t->xd[0], t->xd[1], t->xsum[0], t->xsum[1], t->uv, t->base, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->xhot, t->wide_scratch, t->corpus_owned, t->workers, t->shared,
+  xchg_teardown(t);
+  void *ptrs[] = {t->uv, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->xhot, t->wide_scratch, t->corpus_owned, t->workers, t->shared,
                   t->jump_a, t->jump_c, t->st_center, t->st_off, t->st_ctx, t->st_neg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -330,7 +338,6 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   delete t;
 }
 
-static int xchg_fence(w2b_trainer *t);      // the training stream waits for a replica exchange in flight (below)
 
 // --------------------------------------------------------------------------------- tuning knobs
 extern "C" int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out) {
@@ -911,12 +918,14 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
       t->entry_floats = need;
     }
   }
+  if (t->x_fence_next_launch) if (int rc = xchg_fence(t)) return rc;   // a hot-tier exchange in flight (see xchg_end)
   W2bParams p = make_params(t);
   // per-XCD copies of the hottest rows: v only for the sentence-resident kernel (its context rows live in LDS)
   if (int rc = xhot_prepare(t, p, t->cfg.num_threads, radius < 0)) return rc;
   if (int rc = wide_prepare(t, p, t->cfg.num_threads)) return rc;
 
   t->x_words += (long long)max_positions * t->cfg.num_threads;
+  t->x_words_full += (long long)max_positions * t->cfg.num_threads;
   HIPCHK(timing_begin(t));
   if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream, t->debug));
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
@@ -1076,7 +1085,33 @@ extern "C" int w2b_comm_unique_id(void *out128) {
   return W2B_OK;
 }
 
-// Buffers, streams and events of the replica exchange (first use).
+// Buffers, streams and events of the replica exchange (first use).  xs[0] is the ELEMENTWISE stream (delta / apply /
+// touched kernels, the begin / end events), xs[1] the COLLECTIVE stream: RCCL serialises the collectives of one
+// communicator anyway, so one stream carries all of them, and the elementwise kernels of chunk c + 1 run while the
+// collective of chunk c is on the links (round 3 alternated whole chunks between two streams and claimed an overlap of
+// the two collectives that RCCL does not give).
+static void xchg_teardown(w2b_trainer *t) {
+  for (int k = 0; k < 2; k++) {
+    if (t->xs[k]) (void)hipStreamSynchronize(t->xs[k]);
+    if (t->xd[k]) (void)hipFree(t->xd[k]);
+    if (t->xsum[k]) (void)hipFree(t->xsum[k]);
+    if (t->x_done[k]) (void)hipEventDestroy(t->x_done[k]);
+    if (t->x_evd[k]) (void)hipEventDestroy(t->x_evd[k]);
+    if (t->x_evs[k]) (void)hipEventDestroy(t->x_evs[k]);
+    if (t->xs[k]) (void)hipStreamDestroy(t->xs[k]);
+    t->xd[k] = t->xsum[k] = nullptr;
+    t->x_done[k] = t->x_evd[k] = t->x_evs[k] = nullptr;
+    t->xs[k] = nullptr;
+  }
+  if (t->x_train) (void)hipEventDestroy(t->x_train);
+  if (t->x_evc) (void)hipEventDestroy(t->x_evc);
+  t->x_train = t->x_evc = nullptr;
+  if (t->xcnt) (void)hipFree(t->xcnt);
+  if (t->base) (void)hipFree(t->base);
+  t->xcnt = nullptr;
+  t->base = nullptr;
+}
+
 static int xchg_setup(w2b_trainer *t) {
   if (t->base) return W2B_OK;
   const long long n = 2 * t->table_elems;
@@ -1089,20 +1124,18 @@ static int xchg_setup(w2b_trainer *t) {
     if (e == hipSuccess) e = hipMalloc(&t->xsum[k], sizeof(float) * t->xchunk);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->xs[k], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_done[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_evd[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_evs[k], hipEventDisableTiming);
   }
   if (e == hipSuccess && !t->wca_buf) e = hipMalloc(&t->wca_buf, 2 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc(&t->xcnt, sizeof(float) * 2 * t->cfg.vocab_size);
+  if (e == hipSuccess) e = hipMemsetAsync(t->xcnt, 0, sizeof(float) * 2 * t->cfg.vocab_size, t->stream);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_train, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_evc, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemcpyAsync(t->base, t->uv, sizeof(float) * n, hipMemcpyDeviceToDevice, t->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
   if (e != hipSuccess) {
-    for (int k = 0; k < 2; k++) {
-      if (t->xd[k]) (void)hipFree(t->xd[k]);
-      if (t->xsum[k]) (void)hipFree(t->xsum[k]);
-      t->xd[k] = t->xsum[k] = nullptr;
-    }
-    if (t->base) (void)hipFree(t->base);
-    t->base = nullptr;
+    xchg_teardown(t);                          // everything or nothing: a retry starts from scratch
     return fail(W2B_EHIP, std::string("replica exchange setup: ") + hipGetErrorString(e));
   }
   return W2B_OK;
@@ -1113,6 +1146,7 @@ static int xchg_fence(w2b_trainer *t) {
   if (!t->x_pending) return W2B_OK;
   for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->stream, t->x_done[k], 0));
   t->x_pending = false;
+  t->x_fence_next_launch = false;
   t->xhot_master_changed = true;
   return W2B_OK;
 }
@@ -1149,69 +1183,29 @@ extern "C" int w2b_comm_count(w2b_trainer *t, int32_t *nranks_out) {
   return W2B_OK;
 }
 
-// ---- the exchange in phases (include/word2bits_hip.h).  Chunk c lives on exchange stream c % 2 with its own staging
-// buffers, so consecutive chunks overlap: while the collective of one chunk runs, the delta of the next is computed
-// and the sum of the previous one is applied.
-static long long xchg_chunks(const w2b_trainer *t) { return (2 * t->table_elems + t->xchunk - 1) / t->xchunk; }
+// ---- one exchange = a list of RANGES of [u || v], each at most one staging buffer long.  A FULL exchange covers the whole
+// model in chunks; a HOT-TIER exchange (w2b_sync_hot_rows) covers the leading rows of both tables only.
+static long long xchg_chunks(const w2b_trainer *t) { return (long long)t->x_ranges.size(); }
+
+static void xchg_add_range(w2b_trainer *t, long long off, long long len) {
+  for (long long o = 0; o < len; o += t->xchunk) {
+    const long long m = len - o < t->xchunk ? len - o : t->xchunk;
+    t->x_ranges.push_back({off + o, m});
+  }
+}
 
 extern "C" int w2b_exchange_init(w2b_trainer *t) {
   NEED(t);
   return xchg_setup(t);
 }
 
-static int xchg_begin(w2b_trainer *t) {
-  if (!t->base) return fail(W2B_ESTATE, "replica exchange: w2b_comm_init / w2b_exchange_init first (while all replicas "
-                                        "still hold the same model)");
-  while (t->x_ev.size() >= 512) {            // nobody reads the timings (w2b_sync_stats): keep the list bounded
-    HIPCHK(hipEventSynchronize(t->x_ev[1]));
-    (void)hipEventDestroy(t->x_ev[0]);
-    (void)hipEventDestroy(t->x_ev[1]);
-    t->x_ev.erase(t->x_ev.begin(), t->x_ev.begin() + 2);
-  }
-  // the exchange sees every launch issued so far (and nothing forces the launches issued later to wait for it)
-  HIPCHK(hipEventRecord(t->x_train, t->stream));
-  for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->xs[k], t->x_train, 0));
-  hipEvent_t a, b;
-  HIPCHK(hipEventCreate(&a));
-  HIPCHK(hipEventCreate(&b));
-  t->x_ev.push_back(a);
-  t->x_ev.push_back(b);
-  HIPCHK(hipEventRecord(a, t->xs[0]));
-  return W2B_OK;
-}
-static int xchg_delta(w2b_trainer *t, long long c) {
-  const long long n = 2 * t->table_elems, o = c * t->xchunk, m = (n - o < t->xchunk) ? n - o : t->xchunk;
-  const int k = (int)(c & 1);
-  HIPCHK(w2b_launch_xchg_delta(t->uv + o, t->base + o, t->xd[k], t->xsum[k], m, t->xs[k]));
-  return W2B_OK;
-}
-static int xchg_apply(w2b_trainer *t, long long c, float scale) {
-  const long long n = 2 * t->table_elems, o = c * t->xchunk, m = (n - o < t->xchunk) ? n - o : t->xchunk;
-  const int k = (int)(c & 1);
-  HIPCHK(w2b_launch_xchg_apply(t->uv + o, t->base + o, t->xd[k], t->xsum[k], scale, m, t->x_use_cnt ? t->xcnt : nullptr, o,
-                               t->cfg.layer1_size, t->cfg.vocab_size, t->x_sat_u, t->x_sat_v, t->xs[k]));
-  return W2B_OK;
-}
-static int xchg_end(w2b_trainer *t) {
-  t->x_words = 0;
-  // x_ev.back() = the end of this exchange: stream 0 waits for stream 1's last operation first
-  HIPCHK(hipEventRecord(t->x_done[1], t->xs[1]));
-  HIPCHK(hipStreamWaitEvent(t->xs[0], t->x_done[1], 0));
-  HIPCHK(hipEventRecord(t->x_ev.back(), t->xs[0]));
-  HIPCHK(hipEventRecord(t->x_done[0], t->xs[0]));
-  t->x_pending = true;
-  t->sync_count++;
-  t->sync_bytes += 2 * t->table_elems * (long long)sizeof(float);
-  return W2B_OK;
-}
-
-// Mode 2 of the exchange: which rows are SATURATED -- have been updated so often in this replica since the last exchange
-// (`words` centre words ago) that the replica's delta is no longer a small step.  A row that is a target (v) / a context
-// row (u) of `rate` centre words has received rate x words updates; at alpha = 0.05 a few dozen updates move a row most
-// of the way, so W2B_SAT_UPDATES = 32 of them make it saturated.  The vocabulary is sorted by count: a prefix per table.
+// Which rows are SATURATED -- have been updated so often in this replica over `words` centre words that the replica's
+// delta is no longer a small step.  A row that is a target (v) / a context row (u) of `rate` centre words has received
+// rate x words updates; at alpha = 0.05 a few dozen updates move a row most of the way, so W2B_SAT_UPDATES = 32 of them
+// make it saturated.  The vocabulary is sorted by count: a prefix per table.
 static const double W2B_SAT_UPDATES = 32.0;
-static void xchg_saturated(w2b_trainer *t, long long words) {
-  t->x_sat_u = t->x_sat_v = 0;
+static void xchg_saturated_prefix(const w2b_trainer *t, long long words, int *sat_u, int *sat_v) {
+  *sat_u = *sat_v = 0;
   const long long V = t->cfg.vocab_size;
   if (t->counts.empty() || t->counts_tot <= 0 || words <= 0) return;
   auto prefix = [&](bool is_v) -> int {
@@ -1225,65 +1219,210 @@ static void xchg_saturated(w2b_trainer *t, long long words) {
     }
     return (int)lo;
   };
-  t->x_sat_u = prefix(false);
-  t->x_sat_v = prefix(true);
+  *sat_u = prefix(false);
+  *sat_v = prefix(true);
+}
+
+// Rows of the hot tier: the rows that would be saturated over `horizon_words` (the centre words a replica trains between
+// two FULL exchanges), at most budget_bytes of rows per table.
+static void xchg_hot_plan(const w2b_trainer *t, long long horizon_words, long long budget_bytes, int *hu, int *hv) {
+  xchg_saturated_prefix(t, horizon_words, hu, hv);
+  const long long row_bytes = (long long)t->cfg.layer1_size * (long long)sizeof(float);
+  long long cap = budget_bytes > 0 ? budget_bytes / row_bytes : 0;
+  if (cap > t->cfg.vocab_size - 1) cap = t->cfg.vocab_size - 1;
+  if (*hu > cap) *hu = (int)cap;
+  if (*hv > cap) *hv = (int)cap;
+}
+
+static void xchg_abort(w2b_trainer *t) {       // an exchange that failed between begin and end: forget its (begin, end) events
+  if (t->x_open && t->x_ev.size() >= 2) {
+    (void)hipEventDestroy(t->x_ev.back()); t->x_ev.pop_back();
+    (void)hipEventDestroy(t->x_ev.back()); t->x_ev.pop_back();
+  }
+  t->x_open = false;
+}
+
+// hot_u / hot_v >= 0: a hot-tier exchange of rows 0..hot_u of u and 0..hot_v of v; -1: the whole model
+static int xchg_begin(w2b_trainer *t, int hot_u, int hot_v) {
+  if (!t->base) return fail(W2B_ESTATE, "replica exchange: w2b_comm_init / w2b_exchange_init first (while all replicas "
+                                        "still hold the same model)");
+  if (t->x_open) return fail(W2B_ESTATE, "replica exchange: the previous exchange was not ended (w2b_exchange_end)");
+  while (t->x_ev.size() >= 512) {            // nobody reads the timings (w2b_sync_stats): keep the list bounded
+    HIPCHK(hipEventSynchronize(t->x_ev[1]));
+    (void)hipEventDestroy(t->x_ev[0]);
+    (void)hipEventDestroy(t->x_ev[1]);
+    t->x_ev.erase(t->x_ev.begin(), t->x_ev.begin() + 2);
+  }
+  // the exchange sees every launch issued so far (and nothing forces the launches issued later to wait for a FULL exchange)
+  HIPCHK(hipEventRecord(t->x_train, t->stream));
+  for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->xs[k], t->x_train, 0));
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  t->x_ev.push_back(a);
+  t->x_ev.push_back(b);
+  t->x_open = true;
+  HIPCHK(hipEventRecord(a, t->xs[0]));
+  t->x_ranges.clear();
+  t->x_hot = hot_u >= 0;
+  const long long TE = t->table_elems, D = t->cfg.layer1_size;
+  if (t->x_hot) {
+    auto prefix = [&](long long rows) { long long m = ((rows + 1) * D + 3) & ~3ll; return m < TE ? m : TE; };
+    t->x_hot_u = hot_u;
+    t->x_hot_v = hot_v;
+    xchg_add_range(t, 0, prefix(hot_u));
+    xchg_add_range(t, TE, prefix(hot_v));
+    xchg_saturated_prefix(t, t->x_words, &t->x_sat_u, &t->x_sat_v);       // over the words since the last exchange of any kind
+  } else {
+    xchg_add_range(t, 0, 2 * TE);
+    xchg_saturated_prefix(t, t->x_words_full, &t->x_sat_u, &t->x_sat_v);  // over the words since the last FULL exchange
+  }
+  return W2B_OK;
+}
+static int xchg_delta(w2b_trainer *t, long long c) {
+  const auto &r = t->x_ranges[(size_t)c];
+  const int k = (int)(c & 1);
+  HIPCHK(w2b_launch_xchg_delta(t->uv + r.off, t->base + r.off, t->xd[k], t->xsum[k], r.len, t->xs[0]));
+  return W2B_OK;
+}
+static int xchg_apply(w2b_trainer *t, long long c, float scale) {
+  const auto &r = t->x_ranges[(size_t)c];
+  const int k = (int)(c & 1);
+  HIPCHK(w2b_launch_xchg_apply(t->uv + r.off, t->base + r.off, t->xd[k], t->xsum[k], scale, r.len, t->x_use_cnt ? t->xcnt : nullptr,
+                               r.off, t->cfg.layer1_size, t->cfg.vocab_size, t->x_sat_u, t->x_sat_v, t->xs[0]));
+  return W2B_OK;
+}
+// per row of [u || v]: has this replica changed it since the last exchange?  A hot-tier exchange looks at its rows only.
+static int xchg_touched(w2b_trainer *t, hipStream_t s) {
+  const long long V = t->cfg.vocab_size, D = t->cfg.layer1_size;
+  if (!t->x_hot) return w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, 2 * V, (int)D, s) == hipSuccess ? W2B_OK : fail(W2B_EHIP, "k_xchg_touched");
+  hipError_t e = w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, t->x_hot_u + 1, (int)D, s);
+  if (e == hipSuccess) e = w2b_launch_xchg_touched(t->uv + t->table_elems, t->base + t->table_elems, t->xcnt + V, t->x_hot_v + 1, (int)D, s);
+  return e == hipSuccess ? W2B_OK : fail(W2B_EHIP, "k_xchg_touched");
+}
+static int xchg_end(w2b_trainer *t) {
+  if (!t->x_hot) t->x_words_full = 0;
+  t->x_words = 0;
+  // x_ev.back() = the end of this exchange: the elementwise stream waits for the collective stream's last operation first
+  HIPCHK(hipEventRecord(t->x_done[1], t->xs[1]));
+  HIPCHK(hipStreamWaitEvent(t->xs[0], t->x_done[1], 0));
+  HIPCHK(hipEventRecord(t->x_ev.back(), t->xs[0]));
+  HIPCHK(hipEventRecord(t->x_done[0], t->xs[0]));
+  t->x_open = false;
+  t->x_pending = true;
+  // a hot-tier exchange moves a few MB of exactly the rows the next launch's hot-row folds and merges work on: the next
+  // launch waits for it (a full exchange stays asynchronous)
+  if (t->x_hot) t->x_fence_next_launch = true;
+  t->sync_count++;
+  long long bytes = 0;
+  for (const auto &r : t->x_ranges) bytes += r.len * (long long)sizeof(float);
+  t->sync_bytes += bytes;
+  return W2B_OK;
+}
+
+// The library's own collective.  Software pipeline over the chunks: E = xs[0] (elementwise), C = xs[1] (collective)
+//      E: delta(0) delta(1) apply(0) delta(2) apply(1) ...          C: sum(0) sum(1) sum(2) ...
+// with events delta(c) -> sum(c) -> apply(c); slot c & 1 of the staging buffers is free again when apply(c) has been issued
+// on E before delta(c + 2).
+static int xchg_run_rccl(w2b_trainer *t, int32_t mode) {
+  hipStream_t E = t->xs[0], Cs = t->xs[1];
+  // progress first (16 bytes): every replica learns the global word count -- the alpha schedule (ref :391) is exact
+  // at every exchange and extrapolates in between (W2bShared::wca_others)
+  HIPCHK(w2b_launch_wca_pack(t->shared, t->wca_buf, Cs));
+  NCCLCHK(ncclAllReduce(t->wca_buf, t->wca_buf + 1, 1, ncclUint64, ncclSum, t->comm, Cs));
+  HIPCHK(w2b_launch_wca_unpack(t->shared, t->wca_buf, Cs));
+  const float scale = mode == 1 ? 1.f / (float)t->nranks : 1.f;
+  t->x_use_cnt = mode == 2;
+  if (mode == 2) {          // who has trained which row since the last exchange (2 V floats), before the first apply
+    if (int rc = xchg_touched(t, Cs)) return rc;
+    NCCLCHK(ncclAllReduce(t->xcnt, t->xcnt, (size_t)(2 * t->cfg.vocab_size), ncclFloat, ncclSum, t->comm, Cs));
+    HIPCHK(hipEventRecord(t->x_evc, Cs));
+    HIPCHK(hipStreamWaitEvent(E, t->x_evc, 0));
+  }
+  const long long nc = xchg_chunks(t);
+  auto issue_delta_sum = [&](long long c) -> int {
+    const int k = (int)(c & 1);
+    if (int rc = xchg_delta(t, c)) return rc;
+    HIPCHK(hipEventRecord(t->x_evd[k], E));
+    HIPCHK(hipStreamWaitEvent(Cs, t->x_evd[k], 0));
+    NCCLCHK(ncclAllReduce(t->xsum[k], t->xsum[k], (size_t)t->x_ranges[(size_t)c].len, ncclFloat, ncclSum, t->comm, Cs));
+    HIPCHK(hipEventRecord(t->x_evs[k], Cs));
+    return W2B_OK;
+  };
+  if (nc > 0) if (int rc = issue_delta_sum(0)) return rc;
+  for (long long c = 0; c < nc; c++) {
+    if (c + 1 < nc) if (int rc = issue_delta_sum(c + 1)) return rc;
+    HIPCHK(hipStreamWaitEvent(E, t->x_evs[c & 1], 0));
+    if (int rc = xchg_apply(t, c, scale)) return rc;
+  }
+  return W2B_OK;
 }
 
 extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
   NEED(t);
   if (!t->comm) return W2B_OK;             // a single replica without a communicator: nothing to exchange
   if (mode < 0 || mode > 2) return fail(W2B_EINVAL, "w2b_sync_replicas: unknown mode");
-  if (int rc = xchg_begin(t)) return rc;
-  // progress first (16 bytes): every replica learns the global word count -- the alpha schedule (ref :391) is exact
-  // at every exchange and extrapolates in between (W2bShared::wca_others)
-  HIPCHK(w2b_launch_wca_pack(t->shared, t->wca_buf, t->xs[0]));
-  NCCLCHK(ncclAllReduce(t->wca_buf, t->wca_buf + 1, 1, ncclUint64, ncclSum, t->comm, t->xs[0]));
-  HIPCHK(w2b_launch_wca_unpack(t->shared, t->wca_buf, t->xs[0]));
-  const float scale = mode == 1 ? 1.f / (float)t->nranks : 1.f;
-  t->x_use_cnt = mode == 2;
-  if (mode == 2) {          // who has trained which row since the last exchange (2 V floats), before the first apply
-    xchg_saturated(t, t->x_words);
-    HIPCHK(w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, 2 * t->cfg.vocab_size, t->cfg.layer1_size, t->xs[0]));
-    NCCLCHK(ncclAllReduce(t->xcnt, t->xcnt, (size_t)(2 * t->cfg.vocab_size), ncclFloat, ncclSum, t->comm, t->xs[0]));
-    HIPCHK(hipEventRecord(t->x_done[0], t->xs[0]));
-    HIPCHK(hipStreamWaitEvent(t->xs[1], t->x_done[0], 0));
-  }
-  const long long nc = xchg_chunks(t), n = 2 * t->table_elems;
-  for (long long c = 0; c < nc; c++) {
-    const long long o = c * t->xchunk, m = (n - o < t->xchunk) ? n - o : t->xchunk;
-    const int k = (int)(c & 1);
-    if (int rc = xchg_delta(t, c)) return rc;
-    NCCLCHK(ncclAllReduce(t->xsum[k], t->xsum[k], (size_t)m, ncclFloat, ncclSum, t->comm, t->xs[k]));
-    if (int rc = xchg_apply(t, c, scale)) return rc;
-  }
+  if (int rc = xchg_begin(t, -1, -1)) return rc;
+  if (int rc = xchg_run_rccl(t, mode)) { xchg_abort(t); return rc; }
+  return xchg_end(t);
+}
+
+extern "C" int w2b_sync_hot_rows(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes) {
+  NEED(t);
+  if (!t->comm) return W2B_OK;
+  if (horizon_words <= 0 || budget_bytes <= 0) return fail(W2B_EINVAL, "w2b_sync_hot_rows: horizon_words and budget_bytes must be positive");
+  int hu = 0, hv = 0;
+  xchg_hot_plan(t, horizon_words, budget_bytes, &hu, &hv);
+  if (int rc = xchg_begin(t, hu, hv)) return rc;
+  if (int rc = xchg_run_rccl(t, 2)) { xchg_abort(t); return rc; }
   return xchg_end(t);
 }
 
 // ---- the same exchange for a host that brings its own collective (MPI, torch.distributed over gloo / RCCL, ...):
-//   w2b_exchange_begin -> for every chunk: w2b_exchange_delta, <sum *buf over the replicas, in place>, w2b_exchange_apply
-//   -> w2b_exchange_end.  The buffer handed out is device memory; the library's kernels run on its exchange streams, so
-// w2b_exchange_delta returns after the delta is complete (the host's collective may use any stream or the CPU) and
-// w2b_exchange_apply expects the sum to be complete when it is called.
-extern "C" int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count) {
-  NEED(t);
-  if (int rc = xchg_begin(t)) return rc;
+//   w2b_exchange_begin[_hot] -> (w2b_exchange_counts, <sum over the replicas>) -> for every chunk: w2b_exchange_delta,
+//   <sum *buf over the replicas, in place>, w2b_exchange_apply -> w2b_exchange_end.  The buffer handed out is device
+// memory; the library's kernels run on its elementwise exchange stream, so w2b_exchange_delta returns after the delta is
+// complete (the host's collective may use any stream or the CPU) and w2b_exchange_apply expects the sum to be complete
+// when it is called.
+static int xchg_begin_host(w2b_trainer *t, int hu, int hv, int64_t *n_chunks, int64_t *local_word_count) {
+  if (int rc = xchg_begin(t, hu, hv)) return rc;
   t->x_use_cnt = false;
   if (n_chunks) *n_chunks = xchg_chunks(t);
   if (local_word_count) {
-    HIPCHK(w2b_launch_wca_pack(t->shared, t->wca_buf, t->xs[0]));
+    hipError_t e = w2b_launch_wca_pack(t->shared, t->wca_buf, t->xs[0]);
     unsigned long long v = 0;
-    HIPCHK(hipMemcpyAsync(&v, t->wca_buf, sizeof v, hipMemcpyDeviceToHost, t->xs[0]));
-    HIPCHK(hipStreamSynchronize(t->xs[0]));
+    if (e == hipSuccess) e = hipMemcpyAsync(&v, t->wca_buf, sizeof v, hipMemcpyDeviceToHost, t->xs[0]);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->xs[0]);
+    if (e != hipSuccess) { xchg_abort(t); return fail(W2B_EHIP, std::string("w2b_exchange_begin: ") + hipGetErrorString(e)); }
     *local_word_count = (int64_t)v;
   }
-  xchg_saturated(t, t->x_words);                  // (used when the host asks for w2b_exchange_counts: mode 2)
+  return W2B_OK;
+}
+extern "C" int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count) {
+  NEED(t);
+  return xchg_begin_host(t, -1, -1, n_chunks, local_word_count);
+}
+extern "C" int w2b_exchange_begin_hot(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes, int64_t *n_chunks,
+                                      int64_t *local_word_count) {
+  NEED(t);
+  if (horizon_words <= 0 || budget_bytes <= 0) return fail(W2B_EINVAL, "w2b_exchange_begin_hot: horizon_words and budget_bytes must be positive");
+  int hu = 0, hv = 0;
+  xchg_hot_plan(t, horizon_words, budget_bytes, &hu, &hv);
+  return xchg_begin_host(t, hu, hv, n_chunks, local_word_count);
+}
+extern "C" int w2b_exchange_hot_rows(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes, int32_t *rows_u, int32_t *rows_v) {
+  if (!t) return fail(W2B_EINVAL, "null trainer");
+  int hu = 0, hv = 0;
+  xchg_hot_plan(t, horizon_words, budget_bytes, &hu, &hv);
+  if (rows_u) *rows_u = hu;
+  if (rows_v) *rows_v = hv;
   return W2B_OK;
 }
 extern "C" int w2b_exchange_counts(w2b_trainer *t, void **buf_dev, int64_t *elems) {
   NEED(t);
-  if (!t->base || t->x_ev.empty()) return fail(W2B_ESTATE, "w2b_exchange_counts: w2b_exchange_begin first");
+  if (!t->base || !t->x_open) return fail(W2B_ESTATE, "w2b_exchange_counts: w2b_exchange_begin first");
   if (!buf_dev || !elems) return fail(W2B_EINVAL, "w2b_exchange_counts: null argument");
-  HIPCHK(w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, 2 * t->cfg.vocab_size, t->cfg.layer1_size, t->xs[0]));
+  if (int rc = xchg_touched(t, t->xs[0])) return rc;
   HIPCHK(hipStreamSynchronize(t->xs[0]));
   t->x_use_cnt = true;
   *buf_dev = t->xcnt;
@@ -1293,24 +1432,23 @@ extern "C" int w2b_exchange_counts(w2b_trainer *t, void **buf_dev, int64_t *elem
 
 extern "C" int w2b_exchange_delta(w2b_trainer *t, int64_t chunk, void **buf_dev, int64_t *elems) {
   NEED(t);
-  if (!t->base || t->x_ev.empty()) return fail(W2B_ESTATE, "w2b_exchange_delta: w2b_exchange_begin first");
+  if (!t->base || !t->x_open) return fail(W2B_ESTATE, "w2b_exchange_delta: w2b_exchange_begin first");
   if (chunk < 0 || chunk >= xchg_chunks(t) || !buf_dev || !elems) return fail(W2B_EINVAL, "w2b_exchange_delta: bad argument");
   if (int rc = xchg_delta(t, chunk)) return rc;
-  HIPCHK(hipStreamSynchronize(t->xs[chunk & 1]));
-  const long long n = 2 * t->table_elems, o = chunk * t->xchunk;
+  HIPCHK(hipStreamSynchronize(t->xs[0]));
   *buf_dev = t->xsum[chunk & 1];
-  *elems = (n - o < t->xchunk) ? n - o : t->xchunk;
+  *elems = t->x_ranges[(size_t)chunk].len;
   return W2B_OK;
 }
 extern "C" int w2b_exchange_apply(w2b_trainer *t, int64_t chunk, float scale) {
   NEED(t);
-  if (!t->base || t->x_ev.empty()) return fail(W2B_ESTATE, "w2b_exchange_apply: w2b_exchange_begin first");
+  if (!t->base || !t->x_open) return fail(W2B_ESTATE, "w2b_exchange_apply: w2b_exchange_begin first");
   if (chunk < 0 || chunk >= xchg_chunks(t)) return fail(W2B_EINVAL, "w2b_exchange_apply: bad chunk");
   return xchg_apply(t, chunk, scale);
 }
 extern "C" int w2b_exchange_end(w2b_trainer *t, int64_t word_count_all_replicas) {
   NEED(t);
-  if (!t->base || t->x_ev.empty()) return fail(W2B_ESTATE, "w2b_exchange_end: w2b_exchange_begin first");
+  if (!t->base || !t->x_open) return fail(W2B_ESTATE, "w2b_exchange_end: w2b_exchange_begin first");
   if (word_count_all_replicas >= 0) {        // the alpha schedule runs on the global count (ref :391)
     unsigned long long v = (unsigned long long)word_count_all_replicas;
     HIPCHK(hipMemcpyAsync(t->wca_buf + 1, &v, sizeof v, hipMemcpyHostToDevice, t->xs[0]));
@@ -1325,6 +1463,7 @@ extern "C" int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device
   HIPCHK(hipSetDevice(t->device));
   if (exchanges) *exchanges = t->sync_count;
   double ms = 0;
+  if (t->x_open) return fail(W2B_ESTATE, "w2b_sync_stats: an exchange is in progress (w2b_exchange_end first)");
   for (size_t i = 0; i + 1 < t->x_ev.size(); i += 2) {      // begin -> end of every exchange, read after the fact
     HIPCHK(hipEventSynchronize(t->x_ev[i + 1]));
     float m = 0;

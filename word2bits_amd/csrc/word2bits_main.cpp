@@ -6,7 +6,7 @@
 // happens: the corpus is tokenised once on the host (word2bits_corpus.h) and every epoch is a
 // sequence of GPU launches in which each of the -threads Hogwild workers is one workgroup.
 // GPU-only additions use new flag names: -gpus, -sync-every, -positions, -device, -table-size, -relaxed,
-// -window-cache, -exact, -eval, -hot-rows, -hot-period, -row-desc, -atomic-rank, -atomic-cap.
+// -window-cache, -exact, -eval, -hot-rows, -hot-period, -row-desc, -atomic-rank, -atomic-cap, -sync-hot-mb, ...
 #include <pthread.h>
 #include <unistd.h>
 
@@ -33,6 +33,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int gpus = 1, device = 0;
   long long sync_every = 8;            // -gpus > 1: launches between two replica exchanges
   long long positions = 4096;          // sentence positions per worker per launch
+  long long sync_hot_mb = 64;          // -gpus > 1: MB of leading rows per table exchanged after EVERY launch (0 = off; w2b_sync_hot_rows)
   long long table_size = W2B_UNIGRAM_TABLE_SIZE;
   int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
   int window_cache = -1;               // -1 automatic, 0 plain worker kernel, 1 sentence-resident kernel
@@ -80,6 +81,62 @@ struct Replica {                        // one GPU
   w2b_trainer *t = nullptr;
 };
 
+// -gpus N in one process: the collectives of the N communicators must be issued concurrently, one host thread per
+// replica.  The threads live as long as the run (round 3 created and joined N threads per exchange) and take one
+// command at a time: 1 = full exchange (w2b_sync_replicas mode 2), 2 = hot tier (w2b_sync_hot_rows), 0 = exit.
+struct ExchangeCrew {
+  struct Slot { pthread_t th; w2b_trainer *t; ExchangeCrew *crew; };
+  std::vector<Slot> slots;
+  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+  pthread_cond_t cv = PTHREAD_COND_INITIALIZER, done_cv = PTHREAD_COND_INITIALIZER;
+  long long generation = 0, horizon = 0, budget = 0;
+  int command = 0, remaining = 0;
+  static void *run(void *p) {
+    Slot *s = (Slot *)p;
+    ExchangeCrew *c = s->crew;
+    long long seen = 0;
+    for (;;) {
+      pthread_mutex_lock(&c->mu);
+      while (c->generation == seen) pthread_cond_wait(&c->cv, &c->mu);
+      seen = c->generation;
+      const int cmd = c->command;
+      const long long horizon = c->horizon, budget = c->budget;
+      pthread_mutex_unlock(&c->mu);
+      if (cmd == 0) return nullptr;
+      if (cmd == 1) CK(w2b_sync_replicas(s->t, 2));
+      else CK(w2b_sync_hot_rows(s->t, horizon, budget));
+      pthread_mutex_lock(&c->mu);
+      if (--c->remaining == 0) pthread_cond_signal(&c->done_cv);
+      pthread_mutex_unlock(&c->mu);
+    }
+  }
+  void start(std::vector<Replica> &reps) {
+    slots.resize(reps.size());
+    for (size_t g = 0; g < reps.size(); g++) {
+      slots[g].t = reps[g].t;
+      slots[g].crew = this;
+      pthread_create(&slots[g].th, nullptr, run, &slots[g]);
+    }
+  }
+  void issue(int cmd, long long horizon_words = 0, long long budget_bytes = 0) {   // returns when every replica has issued its exchange
+    pthread_mutex_lock(&mu);
+    command = cmd;
+    horizon = horizon_words;
+    budget = budget_bytes;
+    remaining = cmd == 0 ? 0 : (int)slots.size();
+    generation++;
+    pthread_cond_broadcast(&cv);
+    while (remaining > 0) pthread_cond_wait(&done_cv, &mu);
+    pthread_mutex_unlock(&mu);
+  }
+  void stop() {
+    if (slots.empty()) return;
+    issue(0);
+    for (auto &s : slots) pthread_join(s.th, nullptr);
+    slots.clear();
+  }
+};
+
 void save(const Options &o, const w2b_corpus *c, w2b_trainer *t, const std::string &path) {
   const long long V = w2b_corpus_vocab_size(c), D = o.layer1_size;
   if (o.classes != 0) {                 // ref :542,562: nothing but the fopen/fclose happens
@@ -123,6 +180,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-device", argc, argv)) > 0) o.device = atoi(argv[i + 1]);
   if ((i = arg_pos("-sync-every", argc, argv)) > 0) o.sync_every = atoll(argv[i + 1]);
   if ((i = arg_pos("-positions", argc, argv)) > 0) o.positions = atoll(argv[i + 1]);
+  if ((i = arg_pos("-sync-hot-mb", argc, argv)) > 0) o.sync_hot_mb = atoll(argv[i + 1]);
   if ((i = arg_pos("-table-size", argc, argv)) > 0) o.table_size = atoll(argv[i + 1]);
   if ((i = arg_pos("-relaxed", argc, argv)) > 0) o.relaxed = atoi(argv[i + 1]);
   if ((i = arg_pos("-window-cache", argc, argv)) > 0) o.window_cache = atoi(argv[i + 1]);
@@ -304,6 +362,8 @@ int main(int argc, char **argv) {
     if (o.gpus > 1) for (int g = 0; g < o.gpus; g++) pthread_join(th[g], nullptr);
   }
 
+  ExchangeCrew crew;
+  if (o.gpus > 1) crew.start(reps);
   const auto t_start = std::chrono::steady_clock::now();
   for (int iteration = 0; iteration < o.iter; iteration++) {
     printf("Starting epoch: %d\n", iteration);                // ref :533
@@ -334,14 +394,14 @@ int main(int argc, char **argv) {
         epoch_loss += l;
       }
       launches++;
-      if (o.gpus > 1 && (finished || launches % (o.sync_every > 0 ? o.sync_every : 1) == 0)) {
-        // replicas: periodic all-reduce of the deltas of [u||v] over RCCL, every row's sum shared among the replicas that
-        // trained it (w2b_sync_replicas mode 2), and always at the end of an epoch
-        std::vector<pthread_t> th(o.gpus);
-        // (one host thread per replica: the collectives of one process's communicators must be issued concurrently)
-        auto sync = [](void *p) -> void * { CK(w2b_sync_replicas((w2b_trainer *)p, 2)); return nullptr; };
-        for (int g = 0; g < o.gpus; g++) pthread_create(&th[g], nullptr, sync, reps[g].t);
-        for (int g = 0; g < o.gpus; g++) pthread_join(th[g], nullptr);
+      if (o.gpus > 1) {
+        // replicas: two tiers.  Every sync_every launches (and always at the end of an epoch) an all-reduce of the deltas of
+        // the whole [u||v] over RCCL, every row's sum shared among the replicas that trained it (w2b_sync_replicas mode 2,
+        // asynchronous); after every other launch only the leading rows of both tables -- the rows that would be saturated
+        // over such an interval, at most -sync-hot-mb MB per table (w2b_sync_hot_rows).
+        const long long every = o.sync_every > 0 ? o.sync_every : 1;
+        if (finished || launches % every == 0) crew.issue(1);
+        else if (o.sync_hot_mb > 0) crew.issue(2, every * o.positions * per_gpu, o.sync_hot_mb << 20);
       }
       if (o.debug_mode > 1) {                                 // progress line, ref :384-387
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
@@ -366,6 +426,7 @@ int main(int argc, char **argv) {
       save(o, corpus, reps[0].t, name);
     }
   }
+  crew.stop();
   save(o, corpus, reps[0].t, o.output_file);                  // ref :560-576
   if (!o.packed_file.empty() && o.classes == 0) {
     // the same vectors at 1 (2) bits per value instead of 32: packed on the device, 1/32 (1/16) of the bytes cross the bus
