@@ -74,6 +74,8 @@ def parse():
                          "[u||v] buffer")
     ap.add_argument("--cpu-baseline", choices=["reference", "port", "none"], default="reference")
     ap.add_argument("--cpu-tokens", type=int, default=6_000_000)
+    ap.add_argument("--cpu-1thread-seconds", type=float, default=20.0, help="sample length of the -threads 1 reference leg")
+    ap.add_argument("--cpu-cfg0", type=int, default=1, help="1: also time BASELINE configs[0] (the reference's own CPU case, -threads 1)")
     ap.add_argument("--also-relaxed", type=int, default=1,
                     help="N=1 only: after the headline (coherent) run, time the same steps with relaxed row "
                          "coherence and report it as an extra object")
@@ -85,7 +87,9 @@ def parse():
                     help="N=1, default workload only: after the headline, run the other measured shapes (form (ii) tuples, "
                          "BASELINE configs[4] shape at bitlevel 1 and 0, configs[0] / configs[2] row lengths) as short "
                          "sub-runs of this script and report each with its own value, roofline fraction and kernel")
-    ap.add_argument("--loss", type=int, default=0, help="1: headline run with the loss bookkeeping on")
+    ap.add_argument("--loss", type=int, default=1,
+                    help="1 (default): the headline runs with the loss bookkeeping on -- the instantiation ./word2bits runs (it "
+                         "always prints 'Epoch Loss', ref :539); 0: without it")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--window-cache", type=int, default=-1,
                     help="worker form: -1 = automatic, 1 = sentence-resident kernel (context window rows stay in "
@@ -148,17 +152,80 @@ def draw_ids(torch, cdf, n, gen):
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline_reference(args):
-    """Time the UNMODIFIED reference program (training phase only) on this host.
-    Corpus per BASELINE.md section 4 / SURVEY Appendix C.8: every vocabulary word 5x (so that
-    -min-count 5 keeps V rows), then a Zipf(1) stream; newline every 1000 tokens."""
-    import re
-    import select
-    import subprocess
+class RefProbe:
+    """The UNMODIFIED reference program (oracle/_ref/word2bits_stock) on this host, watched through its stdout (stdbuf -o0:
+    unbuffered, so the marker lines arrive when they are printed; no pty needed): 'Starting epoch: 0' -> 'Epoch Loss:' is
+    the training phase (never "total minus -iter 0"), and the progress line's percentage gives the words done
+    at any moment for a bounded sample of a run that would take too long."""
+
+    def __init__(self, path, flags, threads, sample_seconds=None, timeout=600):
+        import threading
+        self.exe = os.path.join(ROOT, "oracle", "_ref", "word2bits_stock")
+        self.threads, self.sample_seconds, self.timeout = threads, sample_seconds, timeout
+        self.t_launch = time.time()
+        self.t_start = self.t_end = self.words = None
+        self.progress = []                        # (seconds since 'Starting epoch', percent)
+        cmd = ["stdbuf", "-o0", self.exe, "-train", path, "-output", "/dev/null", "-threads", str(threads)] + flags
+        self.p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, bufsize=0)
+        self.th = threading.Thread(target=self._watch, daemon=True)
+        self.th.start()
+
+    def _watch(self):
+        import re
+        import select
+        fd = self.p.stdout.fileno()
+        buf = b""
+        deadline = time.time() + self.timeout
+        while time.time() < deadline:
+            r, _, _ = select.select([fd], [], [], 0.5)
+            now = time.time()
+            if r:
+                chunk = os.read(fd, 65536)
+                if not chunk:
+                    break
+                buf += chunk
+                if self.words is None:
+                    m = re.search(rb"Words in train file: (\d+)", buf)
+                    if m:
+                        self.words = int(m.group(1))
+                if self.t_start is None and b"Starting epoch: 0" in buf:
+                    self.t_start = now
+                if self.t_start is not None:
+                    m = re.findall(rb"Progress: ([\d.]+)%", buf[-400:])
+                    if m:
+                        self.progress.append((now - self.t_start, float(m[-1])))
+                if b"Epoch Loss:" in buf:
+                    self.t_end = now
+                    break
+                if len(buf) > (1 << 20):
+                    buf = buf[-4096:]
+            elif self.p.poll() is not None:
+                break
+            if self.sample_seconds and self.t_start is not None and now - self.t_start >= self.sample_seconds:
+                break
+        self.p.kill()                            # the save loop that follows is not part of the metric
+        self.p.wait()
+
+    def result(self):
+        self.th.join(self.timeout + 5)
+        if self.t_start is None or not self.words:
+            return None
+        startup = self.t_start - self.t_launch
+        if self.t_end is not None:               # a whole epoch
+            return {"words_per_s": self.words / (self.t_end - self.t_start), "train_s": self.t_end - self.t_start,
+                    "startup_s": startup, "words": self.words, "whole_epoch": True}
+        pr = [(t, p) for t, p in self.progress if t >= 1.0]
+        if len(pr) < 2 or pr[-1][0] - pr[0][0] < 2.0:
+            return None
+        dw = (pr[-1][1] - pr[0][1]) / 100.0 * (self.words + 1)     # Progress = wca / (iter * train_words + 1), ref :385
+        return {"words_per_s": dw / (pr[-1][0] - pr[0][0]), "train_s": pr[-1][0] - pr[0][0], "startup_s": startup,
+                "words": int(dw), "whole_epoch": False}
+
+
+def write_cpu_corpus(args):
+    """Corpus per BASELINE.md section 4 / SURVEY Appendix C.8: every vocabulary word 5x (so that -min-count 5 keeps V
+    rows), then a Zipf(1) stream; newline every 1000 tokens."""
     import tempfile
-    exe = os.path.join(ROOT, "oracle", "_ref", "word2bits_stock")
-    if not os.path.exists(exe):
-        return None
     V, nz = args.vocab, args.cpu_tokens
     rng = np.random.default_rng(1234)
     base = np.repeat(np.arange(1, V, dtype=np.int64), 5)
@@ -170,59 +237,59 @@ def cpu_baseline_reference(args):
     ids = np.concatenate([base, z])
     tmpdir = tempfile.mkdtemp(prefix="w2b_cpu_")
     path = os.path.join(tmpdir, "corpus.txt")
-    toks = np.char.add("w", ids.astype(str))
-    with open(path, "w") as f:
-        for o in range(0, len(toks), 1000):
-            f.write(" ".join(toks[o:o + 1000]))
-            f.write("\n")
-    cores = os.cpu_count() or 1
-    cmd = [exe, "-train", path, "-output", "/dev/null", "-bitlevel", str(args.bitlevel), "-size", str(args.dim),
-           "-window", str(args.window), "-negative", str(args.negative), "-iter", "1", "-sample", "0",
-           "-binary", "1", "-min-count", "5", "-threads", str(cores)]
-    # stdbuf -o0 (LD_PRELOAD libstdbuf) makes the program's stdout unbuffered, so the two marker lines
-    # arrive when they are printed; no pty is needed (the GPU box has none to give)
-    p = subprocess.Popen(["stdbuf", "-o0"] + cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, bufsize=0)
-    fd = p.stdout.fileno()
-    t_start = t_end = None
-    words = None
-    buf = b""
-    deadline = time.time() + 600
-    while time.time() < deadline:
-        r, _, _ = select.select([fd], [], [], 1.0)
-        if r:
-            chunk = os.read(fd, 65536)
-            if not chunk:
-                break
-            now = time.time()
-            buf += chunk
-            if t_start is None and b"Starting epoch: 0" in buf:
-                t_start = now
-            m = re.search(rb"Words in train file: (\d+)", buf)
-            if m:
-                words = int(m.group(1))
-            if t_end is None and b"Epoch Loss:" in buf:
-                t_end = now
-                break
-            if len(buf) > (1 << 20):
-                buf = buf[-4096:]
-        elif p.poll() is not None:
-            break
-    p.kill()                                 # the save loop that follows is not part of the metric
-    p.wait()
-    try:
-        os.remove(path)
-        os.rmdir(tmpdir)
-    except OSError:
-        pass
-    if t_start is None or t_end is None or not words:
+    words = np.array([b"w%d" % i for i in range(V)], dtype=object)
+    with open(path, "wb") as f:
+        for o in range(0, len(ids), 1000):
+            f.write(b" ".join(words[ids[o:o + 1000]]))
+            f.write(b"\n")
+    return path
+
+
+def ref_flags(args):
+    return ["-bitlevel", str(args.bitlevel), "-size", str(args.dim), "-window", str(args.window), "-negative",
+            str(args.negative), "-iter", "1", "-sample", "0", "-binary", "1", "-min-count", "5"]
+
+
+def cpu_baseline_reference(args, path):
+    """the headline shape on ALL host threads, training phase of a whole epoch over the bounded corpus"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "word2bits_stock")):
         return None
-    return {"value": words / (t_end - t_start), "unit": "words/s", "cores": cores, "kind": "reference",
+    cores = os.cpu_count() or 1
+    r = RefProbe(path, ref_flags(args), cores).result()
+    if not r:
+        return None
+    return {"value": r["words_per_s"], "unit": "words/s", "cores": cores, "kind": "reference",
             "sample": "unmodified reference CPU program (oracle/_ref/word2bits_stock: -O3 -march=x86-64-v3, "
                       "FMA contraction on), %d tokens = every one of %d words 5x + %d Zipf(1) tokens, V=%d "
                       "D=%d w=%d K=%d bitlevel=%d -sample 0 -threads %d; training phase only "
-                      "('Starting epoch' -> 'Epoch Loss'), %.1f s"
-                      % (words, V - 1, nz, V, args.dim, args.window, args.negative, args.bitlevel, cores,
-                         t_end - t_start)}
+                      "('Starting epoch' -> 'Epoch Loss'), %.1f s (start-up before it: %.1f s)"
+                      % (r["words"], args.vocab - 1, args.cpu_tokens, args.vocab, args.dim, args.window, args.negative,
+                         args.bitlevel, cores, r["train_s"], r["startup_s"])}
+
+
+def cpu_baseline_cfg0():
+    """BASELINE configs[0] literally (the reference's own CPU-runnable case): bitlevel 1, size 200, window 8, negative 24,
+    iter 1, -threads 1 -- on the planted-analogy corpus (text8 is not available offline; 645 K words)."""
+    import tempfile
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "word2bits_stock")):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from planted import make_planted
+    d = tempfile.mkdtemp(prefix="w2b_cfg0_")
+    corpus, questions = os.path.join(d, "planted.txt"), os.path.join(d, "q.txt")
+    make_planted(corpus, questions, repeats=120)
+    r = RefProbe(corpus, ["-bitlevel", "1", "-size", "200", "-window", "8", "-negative", "24", "-iter", "1", "-binary", "1",
+                          "-min-count", "5"], 1, timeout=300).result()
+    for f in (corpus, questions):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    if not r:
+        return None
+    return {"value": r["words_per_s"], "unit": "words/s", "cores": 1, "kind": "reference",
+            "sample": "BASELINE configs[0]: ./word2bits -bitlevel 1 -size 200 -window 8 -negative 24 -iter 1 -threads 1 (default "
+                      "-sample) on the planted-analogy corpus standing in for text8: %d words, whole epoch %.1f s" % (r["words"], r["train_s"])}
 
 
 def cpu_baseline_port(args):
@@ -467,7 +534,7 @@ def main():
     if workers <= 0:          # ask the library how many workgroups of the worker kernel are resident at once
         probe = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=1, device=local_rank, sample=0.0,
                             train_words=train_words * world,
-                            relaxed_coherence=bool(args.relaxed), window_cache=wcache, compute_loss=False)
+                            relaxed_coherence=bool(args.relaxed), window_cache=wcache, compute_loss=bool(args.loss))
         probe.set_vocab_counts(counts, 0)         # which kernel runs (and how many workers fill the device) depends on the counts
         workers = probe.suggested_threads()
         probe.close()
@@ -658,6 +725,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    per_launch = np.sort(t.timing_launches())
     kernel_ms, launches = t.timing_read()
     sync_n, sync_ms = t.sync_stats() if world > 1 else (0, 0.0)
     if world > 1:
@@ -703,7 +771,10 @@ def main():
                      "kernel": "k_train_tuples" if args.form == "tuples" else
                                ("k_train_resident" if kinfo and kinfo[0] else "k_train_workers"),
                      "algorithmic_bytes_per_word": bpw, "avg_launch_ms": avg_launch_s * 1e3,
-                     "launches": launches},
+                     "launches": launches,
+                     "launch_ms_min_median_max": ([float(per_launch[0]), float(np.median(per_launch)), float(per_launch[-1])]
+                                                  if len(per_launch) else None),
+                     "loss_bookkeeping": bool(args.loss)},
     }
     result["roofline"]["algorithmic_bytes_per_launch"] = words_per_step * bpw
     # HBM bytes per launch from the counters: collected by tools/gpu_profile_session.sh with rocprofv3 --pmc (separate
@@ -758,11 +829,22 @@ def main():
         return {"value": wps * args.steps / rdt, "unit": "words/s", "ms_per_step": rdt / args.steps * 1e3,
                 "roofline_frac": wps * bpw / ((rms / 1e3) / max(1, rl)) / HBM_PEAK}
 
-    if world == 1 and args.also_legs and args.form == "worker" and not args.relaxed and not args.loss:
-        # the path ./word2bits runs (it always prints "Epoch Loss", ref :539): the LOSS instantiation of the same kernel
-        leg = timed_leg(make_trainer(False, loss=True), words_per_step)
-        leg["note"] = "same steps with compute_loss = 1 (log-sigmoid terms booked by the producer wavefront)"
-        result["with_loss_bookkeeping"] = leg
+    ref1 = cpu_path = None
+    if rank == 0 and world == 1 and args.cpu_baseline == "reference" and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "word2bits_stock")):
+        # the CPU legs use one bounded corpus; the ONE-thread run of the reference (BASELINE.md section 4 asks for -threads 1
+        # and -threads $(nproc)) starts now and runs on one host core next to the GPU legs below; the all-threads run and
+        # the configs[0] run follow when the GPU is done, alone on the host
+        try:
+            cpu_path = write_cpu_corpus(args)
+            ref1 = RefProbe(cpu_path, ref_flags(args), 1, sample_seconds=args.cpu_1thread_seconds)
+        except Exception:
+            ref1 = None
+    if world == 1 and args.also_legs and args.form == "worker" and not args.relaxed:
+        # the other instantiation of the same kernel: ./word2bits always books the loss (it prints "Epoch Loss", ref :539),
+        # so the headline does too; a host that does not want the number can switch it off (compute_loss = 0)
+        leg = timed_leg(make_trainer(False, loss=not args.loss), words_per_step)
+        leg["note"] = "same steps with compute_loss = %d" % (not args.loss)
+        result["without_loss_bookkeeping" if args.loss else "with_loss_bookkeeping"] = leg
         if args.bitlevel != 2:
             leg = timed_leg(make_trainer(False, bitlevel=2), words_per_step)
             leg["note"] = "same steps at bitlevel 2 (BASELINE configs[2] quantizer)"
@@ -795,19 +877,43 @@ def main():
             "note": "plain cached row accesses: hot rows are private per XCD L2 within a launch (not the default)"}
         t2.close()
     if (world == 1 and args.also_shapes and workload_name(args) == "BASELINE configs[1]" and args.form == "worker"
-            and not args.relaxed and not args.loss and not tune):
+            and not args.relaxed and args.loss and not tune):
         result["other_shapes"] = other_shapes()
     if rank == 0:
         cb = None
         if world == 1 and args.cpu_baseline != "none":
             try:
-                cb = cpu_baseline_reference(args) if args.cpu_baseline == "reference" else None
+                if ref1 is not None:
+                    r1 = ref1.result()
+                    result["cpu_baseline_1thread"] = None if not r1 else {
+                        "value": r1["words_per_s"], "unit": "words/s", "cores": 1, "kind": "reference",
+                        "sample": "the same program and corpus with -threads 1: %d words in %.1f s after 'Starting epoch' (progress "
+                                  "line, ref :384-387), then stopped; it ran on one host core beside the GPU legs" % (r1["words"], r1["train_s"])}
+                if args.cpu_baseline == "reference" and cpu_path:
+                    cb = cpu_baseline_reference(args, cpu_path)
                 if cb is None:
                     cb = cpu_baseline_port(args)
+                if args.cpu_baseline == "reference" and args.cpu_cfg0:
+                    result["cpu_baseline_configs0"] = cpu_baseline_cfg0()
             except Exception as e:            # the GPU number must still be reported
                 cb = {"value": None, "unit": "words/s", "cores": os.cpu_count(), "kind": "port",
                       "sample": "failed: %r" % (e,)}
+            finally:
+                if cpu_path:
+                    try:
+                        os.remove(cpu_path)
+                        os.rmdir(os.path.dirname(cpu_path))
+                    except OSError:
+                        pass
         result["cpu_baseline"] = cb
+        # end-to-end wall times of ./word2bits and the reference program on one file (tools/e2e_compare.py, run in the
+        # round's profile session and committed): quoted, not re-measured here (the reference takes minutes)
+        e2e = os.path.join(ROOT, "profiles", "r04_e2e.json")
+        if world == 1 and os.path.exists(e2e) and workload_name(args).startswith("BASELINE configs[1]"):
+            try:
+                result["e2e"] = dict(json.load(open(e2e)), source="profiles/r04_e2e.json")
+            except Exception:
+                pass
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

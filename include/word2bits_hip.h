@@ -234,6 +234,8 @@ int w2b_synchronize(w2b_trainer *t);
 /* hipEvent timing of the training kernels launched since the last reset (sum over launches). */
 int w2b_timing_enable(w2b_trainer *t, int32_t on);
 int w2b_timing_read(w2b_trainer *t, double *kernel_ms, int64_t *launches); /* syncs, then resets */
+/* the same launches one by one: ms_out[0..min(capacity, *launches)) (syncs; does not reset) -- min / median / max per launch */
+int w2b_timing_launches(w2b_trainer *t, double *ms_out, int64_t capacity, int64_t *launches);
 
 /* ---- multi-GPU: one process per GPU, replicas + periodic all-reduce over RCCL ----------------
  * Replaces the shared-memory Hogwild of ref :535-536 across devices.  Every replica keeps `base`, the

@@ -30,7 +30,8 @@ dev = torch.device("cuda", 0)
 V, D, W, K = a.vocab, a.dim, a.window, a.negative
 gen = torch.Generator(device=dev); gen.manual_seed(1000)
 w = 1.0 / torch.arange(1, V, dtype=torch.float64, device=dev)
-cdf = torch.cumsum(w, 0); cdf /= cdf[-1]
+cdf = torch.cumsum(w, 0)
+cdf = cdf / cdf[-1]
 stream = torch.empty(a.tokens, dtype=torch.int32, device=dev)
 for o in range(0, a.tokens, 1 << 24):
     m = min(1 << 24, a.tokens - o)

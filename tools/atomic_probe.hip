@@ -102,7 +102,7 @@ static void tput(const char *name, float *tab, unsigned nrows, unsigned hot, int
     if (ms < best) best = ms;
   }
   const double rows = (double)grid * iters * rpi;
-  printf("%-44s rows %-8s: %8.3f ms  %7.1f M row-updates/s  %6.2f TB/s of row bytes\n", name, hot ? "hot set" : "uniform", best,
+  printf("%-44s rows %-8s (%u): %8.3f ms  %7.1f M row-updates/s  %6.2f TB/s of row bytes\n", name, hot ? "hot set" : "uniform", hot, best,
          rows / best / 1e3, rows * dim * 4 / best / 1e9);
   fflush(stdout);
 }
@@ -138,7 +138,7 @@ int main() {
   check("aux=16 + sc1 readers");
   // ---- (2) throughput
   CK(hipMemset(tab, 0, (size_t)nrows * dim * 4));
-  for (unsigned hot : {0u, 4096u, 256u}) {
+  for (unsigned hot : {0u, 256u, 8u, 1u}) {      // uniform rows; then ever smaller sets: how many adds per second does ONE row take?
     tput<2, 16>("sc1 16-byte stores (no add; baseline)", tab, nrows, hot, dim);
     tput<0, 0>("atomic add, strided lanes, aux=0", tab, nrows, hot, dim);
     tput<0, 16>("atomic add, strided lanes, sc1", tab, nrows, hot, dim);

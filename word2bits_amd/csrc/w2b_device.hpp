@@ -313,6 +313,39 @@ __device__ __forceinline__ void add_col(float *tab, long long row, int dim, int 
   for (int e = 0; e < VEC; e++) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(d.e[e], r, (col0 + e) * 4, soff, 16);
 }
 
+// The same add for 16-byte columns with the wavefront's 256 deltas TRANSPOSED first, so that instruction e adds the
+// dwords [64 e, 64 e + 64) of the wavefront's 1 KiB segment -- two whole cache lines per instruction instead of eight
+// lines with 8 dwords each.  The memory side pays per line an instruction touches: tools/atomic_probe.hip measures 97 M
+// row-updates/s for the per-lane layout above and 397 M/s for this one (16-byte stores of the same rows: 1350 M/s).  The
+// transpose is 16 ds_bpermute (crossbar only, no LDS memory) + 12 selects.  ALL 64 lanes of the wavefront must call it
+// (inactive lanes pass zeros); dest lane l of instruction e takes element l & 3 of lane 16 e + (l >> 2).
+template <int TB = -1>
+__device__ __forceinline__ void add_col_contig(float *tab, long long row, int dim, const Col<4> &d, unsigned tab_bytes) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int urow = __builtin_amdgcn_readfirstlane((int)row);
+  __amdgpu_buffer_rsrc_t r;
+  int soff;
+  if (TB == 0 || (TB < 0 && tab_bytes)) {
+    r = __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, (int)tab_bytes, 0x27000);
+    soff = urow * dim * 4;
+  } else {
+    r = __builtin_amdgcn_make_buffer_rsrc((void *)(tab + urow * (long long)dim), 0, dim * 4, 0x27000);
+    soff = 0;
+  }
+  const int sel = lane & 3;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int src = (16 * e + (lane >> 2)) << 2;
+    const float p0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.e[0])));
+    const float p1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.e[1])));
+    const float p2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.e[2])));
+    const float p3 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.e[3])));
+    const float v = sel == 0 ? p0 : (sel == 1 ? p1 : (sel == 2 ? p2 : p3));
+    const int c = wave * 256 + e * 64 + lane;
+    if (c < dim) (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, r, c * 4, soff, 16);
+  }
+}
+
 // ------------------------------------------------------------------------------------ XCD-local copies of the hot rows
 // With coherent (agent-scope) rows every access to a row goes to its memory line, and the few most frequent rows of
 // u (context words) and v (targets) queue there: a 3200-byte row sustains ~7 M read-modify-writes per second, against
@@ -628,8 +661,10 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     for (int i = 0; i < TC; i++) {
       if (i < n) {
         const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
+        Col<VEC> dl;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) dl.e[e] = 0.f;
         if (active) {
-          Col<VEC> dl;
 #pragma unroll
           for (int e = 0; e < VEC; e++) {
             float xv = x[i].e[e];
@@ -642,6 +677,12 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
             dl.e[e] = g * avg.e[e] - ar2 * xv;
             x[i].e[e] = xv + dl.e[e];
           }
+        }
+        // (wave-uniform choice: rows[i] lives in SGPRs) a frequent row below the hot ones gets its delta as an atomic add --
+        // all lanes take part in the transpose of the 16-byte-column form
+        if (VEC == 4 && rows[i] <= atomic_rank && !((unsigned)(rows[i] - 1) < (unsigned)nhv)) {
+          if constexpr (VEC == 4) add_col_contig<>(P.v, rows[i], dim, dl, P.tab_bytes);
+        } else if (active) {
           up_v(rows[i], x[i], dl);
         }
       }
@@ -673,21 +714,28 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
       }
 #pragma unroll
     for (int jj = 0; jj < W2B_CA; jj++)
-      if (active && j0 + jj < cw) {
+      if (j0 + jj < cw) {                    // (wave-uniform: the atomic form needs every lane of the wavefront)
         const int m = L.umult[j0 + jj];
         if (m > 0) {
           const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
           const bool by_add = crow <= atomic_rank_u && !(VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu);
           Col<VEC> dl;
-          for (int k = 0; k < m; k++) {      // a row that occurs m times in the window is updated m times
 #pragma unroll
-            for (int e = 0; e < VEC; e++) {
-              dl.e[e] = err.e[e] - ar2 * r[jj].e[e];
-              r[jj].e[e] = r[jj].e[e] + dl.e[e];
+          for (int e = 0; e < VEC; e++) dl.e[e] = 0.f;
+          for (int k = 0; k < m; k++) {      // a row that occurs m times in the window is updated m times
+            if (active) {
+#pragma unroll
+              for (int e = 0; e < VEC; e++) {
+                dl.e[e] = err.e[e] - ar2 * r[jj].e[e];
+                r[jj].e[e] = r[jj].e[e] + dl.e[e];
+              }
             }
-            if (by_add && k + 1 < m) up_u(crow, r[jj], dl);    // (every one of the m updates is an add of its own)
+            if (by_add) {                    // (every one of the m updates is an add of its own)
+              if constexpr (VEC == 4) add_col_contig<>(P.u, crow, dim, dl, P.tab_bytes);
+              else if (active) add_col<VEC>(P.u, crow, dim, col0, dl, P.tab_bytes);
+            }
           }
-          up_u(crow, r[jj], dl);
+          if (!by_add && active) up_u(crow, r[jj], dl);
         }
       }
   }

@@ -266,8 +266,12 @@ __device__ __forceinline__ void retire_finish(const Rows<MM> &A, const Win2 &L, 
 }
 
 // ---- rows leaving the window (sentence boundaries: many at once)
+// keep0: entry 0 of the list is a REFRESH (Step2::refresh: the row stays resident) that happens to coincide with several
+// admissions, so that the step takes this generic path: the merged value must become the slot's value, entry and checksum
+// exactly as on the steady-state path (round 3 passed keep = false here: the row was then always treated as touched by
+// others at its real retirement)
 template <int MM>
-__device__ __forceinline__ void window_retire(const Rows<MM> &A, const Win2 &L, int n_ret, int wave) {
+__device__ __forceinline__ void window_retire(const Rows<MM> &A, const Win2 &L, int n_ret, int lane, int wave, bool keep0) {
   for (int i0 = 0; i0 < n_ret; i0 += W2B_RCH) {
     Col4 rw[W2B_RCH], g[W2B_RCH];
 #pragma unroll
@@ -282,7 +286,7 @@ __device__ __forceinline__ void window_retire(const Rows<MM> &A, const Win2 &L, 
     for (int i = 0; i < W2B_RCH; i++)
       if (i0 + i < n_ret) {
         const int s = L.s->ret_slot[i0 + i];
-        retire_finish<MM>(A, L, L.s->ret_row[i0 + i], L.s->ret_gen[i0 + i], s, L.w->csum[s][wave], g[i], rw[i], false, 0, wave);
+        retire_finish<MM>(A, L, L.s->ret_row[i0 + i], L.s->ret_gen[i0 + i], s, L.w->csum[s][wave], g[i], rw[i], keep0 && i0 + i == 0, lane, wave);
       }
   }
 }
@@ -751,7 +755,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
             apre_row = (nr >= 0 && !(deferred && nr == d_row) && !is_uc) ? nr : -1;
             if (apre_row >= 0 && active) apre = A.ld_u(apre_row);
           } else {
-            if (n_ret) window_retire<MM>(A, I, n_ret, wave);
+            if (n_ret) window_retire<MM>(A, I, n_ret, lane, wave, I.s->st.refresh != 0);
             if (n_adm) window_admit<MM>(A, I, n_adm, lane, wave);
             apre_row = -1;
           }

@@ -614,6 +614,20 @@ extern "C" int w2b_timing_read(w2b_trainer *t, double *kernel_ms, int64_t *launc
   return W2B_OK;
 }
 
+// per-launch durations of the same events (does NOT reset: w2b_timing_read does)
+extern "C" int w2b_timing_launches(w2b_trainer *t, double *ms_out, int64_t capacity, int64_t *launches) {
+  NEED(t);
+  HIPCHK(hipStreamSynchronize(t->stream));
+  const int64_t n = (int64_t)(t->ev.size() / 2);
+  if (launches) *launches = n;
+  for (int64_t i = 0; i < n && i < capacity && ms_out; i++) {
+    float m = 0;
+    HIPCHK(hipEventElapsedTime(&m, t->ev[(size_t)(2 * i)], t->ev[(size_t)(2 * i + 1)]));
+    ms_out[i] = m;
+  }
+  return W2B_OK;
+}
+
 extern "C" int w2b_synchronize(w2b_trainer *t) {
   NEED(t);
   if (int rc = xchg_fence(t)) return rc;
@@ -727,6 +741,21 @@ static int worker_plan(const w2b_trainer *t) {
     if (competitive && share > W2B_PLAIN_CTX_SHARE) return -1;
   }
   return w2b_resident_plan(t->cfg.layer1_size, t->cfg.window, t->cfg.negative);
+}
+
+static int atomic_plan(const w2b_trainer *t, long long workers);
+// worker_plan() + what w2b_train_step additionally has to respect: atomic row updates (small flat vocabularies) exist in
+// only some forms of the sentence-resident kernel; the others run the plain kernel.  ONE decision for w2b_train_step,
+// w2b_worker_kernel_info and w2b_suggested_threads (round 3 decided it in w2b_train_step alone, so the other two could
+// report the sentence-resident kernel while the plain one ran).
+static int effective_radius(const w2b_trainer *t, long long workers) {
+  int radius = worker_plan(t);
+  if (radius >= 0) {
+    W2bParams probe = make_params(t);
+    probe.atomic_rank = atomic_plan(t, workers);
+    if (probe.atomic_rank > 0 && !w2b_resident_atomic_ok(probe, radius)) radius = -1;
+  }
+  return radius;
 }
 
 // How many leading rows of u / v get per-XCD copies for a launch with `workers` concurrent workers / workgroups.
@@ -861,7 +890,8 @@ extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
   NEED(t);
   if (!out) return fail(W2B_EINVAL, "w2b_suggested_threads: null");
   const W2bParams p = make_params(t);
-  const int radius = worker_plan(t);
+  // (judged for a full device: the atomic plan depends on the number of workers, which is what is being asked for)
+  const int radius = effective_radius(t, 2ll * t->num_cus > t->cfg.num_threads ? 2ll * t->num_cus : t->cfg.num_threads);
   const int per_cu = radius >= 0 ? w2b_resident_per_cu(p, radius, t->cfg.compute_loss != 0)
                                  : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
   long long n = (long long)per_cu * t->num_cus;
@@ -882,7 +912,7 @@ extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t
                                       int32_t *workgroups_per_cu, int32_t *hot_rows) {
   NEED(t);
   const W2bParams p = make_params(t);
-  const int r = worker_plan(t);
+  const int r = effective_radius(t, t->cfg.num_threads);
   int hu = 0, hot = 0;
   xhot_plan(t, t->cfg.num_threads, r < 0, &hu, &hot);
   if (resident) *resident = r >= 0;
@@ -901,12 +931,7 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   NEED(t);
   if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_train_step: corpus/shards not set");
   if (max_positions <= 0) return fail(W2B_EINVAL, "w2b_train_step: max_positions must be positive");
-  int radius = worker_plan(t);
-  if (radius >= 0) {       // atomic row updates (small flat vocabularies): only some forms of the sentence-resident kernel have them
-    W2bParams probe = make_params(t);
-    probe.atomic_rank = atomic_plan(t, t->cfg.num_threads);
-    if (probe.atomic_rank > 0 && !w2b_resident_atomic_ok(probe, radius)) radius = -1;
-  }
+  const int radius = effective_radius(t, t->cfg.num_threads);
   if (radius >= 0) {                       // scratch rows of the sentence-resident kernel (grown on demand)
     const size_t need = (size_t)t->cfg.num_threads * (size_t)w2b_resident_scratch_rows(radius) * t->cfg.layer1_size;
     if (need > t->entry_floats) {

@@ -40,6 +40,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int exact = 0;                       // 1: serial dot product in the reference's order (bit parity at -threads 1)
   std::string eval_file;               // -eval FILE: questions to score on the GPU after the final save (-binary 1)
   int hot_rows = -1;                   // -hot-rows N: leading rows of v (and u) with per-XCD copies; -1 = from the counts
+  int hot_rows_u = -1, hot_rows_v = -1; // -hot-rows-u / -hot-rows-v N: the same for one table only
   int hot_cap = -1;                    // -hot-cap N: most rows the automatic choice takes (-1 = default)
   int hot_period = 0;                  // -hot-period N: centre words between two merge events of a worker (0 = default)
   int atomic_rank = -2;                // -atomic-rank N: rows 1..N are updated with atomic adds (-1 automatic; default: library's)
@@ -188,6 +189,8 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-eval", argc, argv)) > 0) o.eval_file = argv[i + 1];
   if ((i = arg_pos("-packed", argc, argv)) > 0) o.packed_file = argv[i + 1];
   if ((i = arg_pos("-hot-rows", argc, argv)) > 0) o.hot_rows = atoi(argv[i + 1]);
+  if ((i = arg_pos("-hot-rows-u", argc, argv)) > 0) o.hot_rows_u = atoi(argv[i + 1]);
+  if ((i = arg_pos("-hot-rows-v", argc, argv)) > 0) o.hot_rows_v = atoi(argv[i + 1]);
   if ((i = arg_pos("-hot-period", argc, argv)) > 0) o.hot_period = atoi(argv[i + 1]);
   if ((i = arg_pos("-hot-cap", argc, argv)) > 0) o.hot_cap = atoi(argv[i + 1]);
   if ((i = arg_pos("-row-desc", argc, argv)) > 0) o.row_desc = atoi(argv[i + 1]);
@@ -298,10 +301,12 @@ int main(int argc, char **argv) {
     cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
-    if (o.hot_rows >= 0 || o.hot_cap >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0 || o.atomic_rank_u != 0 || o.hot_late != 0 || o.fresh_rank_u != 0) {
+    if (o.hot_rows >= 0 || o.hot_rows_u >= 0 || o.hot_rows_v >= 0 || o.hot_cap >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0 || o.atomic_rank_u != 0 || o.hot_late != 0 || o.fresh_rank_u != 0) {
       w2b_tuning tn;
       CK(w2b_get_tuning(a->r->t, &tn));
       if (o.hot_rows >= 0) tn.hot_rows_v = tn.hot_rows_u = o.hot_rows;
+      if (o.hot_rows_u >= 0) tn.hot_rows_u = o.hot_rows_u;
+      if (o.hot_rows_v >= 0) tn.hot_rows_v = o.hot_rows_v;
       if (o.hot_period > 0) tn.hot_period = o.hot_period;
       if (o.hot_cap >= 0) tn.hot_cap = o.hot_cap;
       tn.force_row_desc = o.row_desc ? 1 : 0;

@@ -304,6 +304,15 @@ class Trainer:
         check(lib().w2b_timing_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def timing_launches(self):
+        """durations (ms) of the training launches since the last timing_read(), one by one"""
+        n = C.c_int64(0)
+        check(lib().w2b_timing_launches(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float64)
+        if n.value:
+            check(lib().w2b_timing_launches(self._h, out.ctypes.data_as(_lib.f64p), n.value, C.byref(n)))
+        return out
+
     def comm_init(self, nranks, rank, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
         check(lib().w2b_comm_init(self._h, int(nranks), int(rank), buf))
