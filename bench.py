@@ -105,7 +105,6 @@ def parse():
     ap.add_argument("--hot-weight", type=int, default=0, help="w2b_tuning.hot_weight_permille (0 = library default)")
     ap.add_argument("--atomic-rank-u", type=int, default=0, help="w2b_tuning.atomic_rank_u (0 = as atomic_rank, -1 = none)")
     ap.add_argument("--fresh-rank-u", type=int, default=0, help="w2b_tuning.fresh_rank_u (0 = library default, -1 = none)")
-    ap.add_argument("--hot-late", type=int, default=0, help="w2b_tuning.hot_late (0 = library default, 1 on, -1 off)")
     ap.add_argument("--window-refresh", type=int, default=-1, help="w2b_tuning.window_refresh (-1 = library default)")
     ap.add_argument("--eval-questions", type=int, default=19544, help="--form eval: questions (questions-words.txt)")
     ap.add_argument("--eval-kind", choices=["1bit", "fp"], default="1bit")
@@ -559,8 +558,6 @@ def main():
         tune["window_refresh"] = args.window_refresh
     if args.atomic_rank_u != 0:
         tune["atomic_rank_u"] = args.atomic_rank_u
-    if args.hot_late != 0:
-        tune["hot_late"] = args.hot_late
     if args.fresh_rank_u != 0:
         tune["fresh_rank_u"] = args.fresh_rank_u
 

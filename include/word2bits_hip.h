@@ -140,13 +140,10 @@ typedef struct w2b_tuning {
   int32_t atomic_rank_u;   /* rows of u (context words) updated with atomic adds: 0 = as atomic_rank (default), > 0 = rows 1..N,
                             * -1 = none.  The reference's own update of a context row is `u[c] += e[c]` on the CURRENT memory
                             * value (ref :500-502): an add of a gradient computed a whole centre word earlier, never a lost one. */
-  int32_t hot_late;        /* plain worker / tuple kernels: 1 = hot target rows (the rows with per-XCD copies) are loaded after
-                            * the chunk's other dot products and get a reduction round of their own, so that they are open for
-                            * ~1 us instead of ~10 us; -1 = off; 0 = the library decides */
   int32_t fresh_rank_u;    /* plain worker / tuple kernels: context rows 1..N are read again right before their update (phase C)
                             * instead of taken from the LDS stash of phase A, so that the update lands on the row's CURRENT value
                             * as the reference's `u[c] += e[c]` does (ref :500-502); 0 = the library decides, -1 = none */
-  int32_t reserved[1];
+  int32_t reserved[2];
 } w2b_tuning;
 int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out);
 int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in);
@@ -205,7 +202,7 @@ int w2b_epoch_poll(w2b_trainer *t, int32_t lag, int32_t *finished, int64_t *word
 
 /* Number of Hogwild workers (-threads) that exactly fills this GPU for the configured shape: the workgroups
  * of the worker kernel that are resident at once (more workers run in rounds; fewer leave CUs idle) -- but, when
- * cfg.train_words is known, never more than train_words / 20000: a worker re-computes alpha only after >10000 of
+ * cfg.train_words is known, never more than train_words / 50000 (20000 until round 4): a worker re-computes alpha only after >10000 of
  * its own words (ref :379-393), so shorter shards would freeze the learning rate for the whole epoch. */
 int w2b_suggested_threads(w2b_trainer *t, int32_t *out);
 

@@ -249,10 +249,13 @@ def test_model_tensor_view_and_single_rank_sync_noop(gpu):
 
 def test_suggested_threads_fills_the_device(gpu):
     """w2b_suggested_threads = resident workgroups of the worker kernel that would run (per-CU occupancy
-    x CUs): 2 per CU for the sentence-resident kernel at D=800, 4 per CU for the plain one."""
+    x CUs): 2 per CU for the sentence-resident kernel at D=800, 4 per CU for the plain one (the automatic choice)."""
     import torch
     ncu = torch.cuda.get_device_properties(0).multi_processor_count        # 256 on an MI355X
-    a = w2b.Trainer(2, 800, 8, 24, 1, num_threads=1, compute_loss=False)                          # coherent: resident
+    a = w2b.Trainer(2, 800, 8, 24, 1, num_threads=1, compute_loss=False, window_cache=True)       # sentence-resident (explicit choice)
+    d = w2b.Trainer(2, 800, 8, 24, 1, num_threads=1, compute_loss=False)                          # automatic: the plain kernel (round 4)
+    assert not d.worker_kernel_info()[0] and d.suggested_threads() == 4 * ncu
+    d.close()
     b = w2b.Trainer(2, 800, 8, 24, 1, num_threads=1, compute_loss=False, relaxed_coherence=True)  # relaxed: plain
     c = w2b.Trainer(2, 800, 8, 24, 1, num_threads=1, compute_loss=True, relaxed_coherence=True)   # ... with the loss bookkeeping
     na, nb, nc = a.suggested_threads(), b.suggested_threads(), c.suggested_threads()

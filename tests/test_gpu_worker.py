@@ -247,3 +247,37 @@ def test_epoch_poll_one_launch_behind(gpu, window_cache):
         assert fin0 and fin2 and wca0 == wca2 == wca and alpha0 == alpha2
         assert loss0 == pytest.approx(loss2, rel=1e-9) and loss == pytest.approx(loss2, rel=1e-9) and loss2 < 0
     t.close()
+
+
+# ------------------------------------------------------------------ round 4: lossless rows / fresh rows / late round
+@pytest.mark.parametrize("knobs", [
+    dict(atomic_rank=149, atomic_rank_u=149),                 # every row's update an atomic add (transposed 16-byte-column form)
+    dict(atomic_rank=40, atomic_rank_u=-1),                   # v only, a prefix
+    dict(fresh_rank_u=149),                                   # context rows re-read before their update
+    dict(hot_rows_v=8, hot_rows_u=0, atomic_rank_u=149, hot_period=2),     # copies of hot target rows + lossless context rows
+    dict(hot_rows_v=8, hot_rows_u=4, fresh_rank_u=60, atomic_rank=60, atomic_rank_u=60, hot_period=4),
+])
+@pytest.mark.parametrize("D,bitlevel,loss", [(800, 1, True), (200, 2, False), (36, 0, True)])
+def test_single_worker_is_bit_identical_under_every_round4_knob(gpu, knobs, D, bitlevel, loss):
+    """One worker has nobody to race with: an atomic add of d lands as fl(x + d), a re-read row is the row it read -- so the plain kernel with any of the round-4 knobs must leave
+    the very bits it leaves without them (u, v, word count, alpha, epoch loss).  D = 36: partly filled wavefront."""
+    V, n = 150, 12000
+    rng = np.random.default_rng(21)
+    ids = token_stream(rng, V, n)
+    cn = counts_of(ids, V)
+    res = []
+    for kw in ({}, knobs):
+        t = w2b.Trainer(V, D, 8, 24, bitlevel, num_threads=1, iter=1, sample=0.0, train_words=int(cn.sum()),
+                        compute_loss=loss, window_cache=False, **kw)
+        t.init_net()
+        t.set_vocab_counts(cn, 50000)
+        t.set_corpus(ids)
+        t.set_shards(np.zeros(1, np.int64))
+        lg = t.train_epoch(positions_per_launch=611)
+        fin, wca, alpha, _ = t.epoch_status()
+        u, v = t.get_model()
+        res.append((u, v, wca, alpha, lg))
+        t.close()
+    (u0, v0, w0, a0, l0), (u1, v1, w1, a1, l1) = res
+    assert np.array_equal(u0.view(np.uint32), u1.view(np.uint32)) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32))
+    assert w0 == w1 and a0 == a1 and l0 == l1

@@ -213,7 +213,7 @@ struct WordLds {
   int *prev;    // [maxt]  index of the previous occurrence of the same target row, or -1 (prep_lists only; process_word
                 //         parks the dot products f of the targets here for the loss bookkeeping)
   int *cend;    // [maxt]  end index of every target chunk (a chunk is cut at W2B_T rows or at a repeated row)
-  float *red;   // [3][W2B_T][W2B_MAXW] cross-wave partial dot products (double buffered) + the late round of the hot rows
+  float *red;   // [2][W2B_T][W2B_MAXW] cross-wave partial dot products (double buffered)
   float *stash; // [W2B_STASH][blockDim][VEC] raw u columns of the first context rows, private to the
                 // owning thread: phase C updates them without a second trip to memory
   float *xprod; // exact mode only: [W2B_T][W2B_EXACT_COLS + 1] products of the current column block
@@ -227,7 +227,7 @@ __device__ __forceinline__ WordLds carve_word_lds(int *base, int window, int neg
   L.stash = reinterpret_cast<float *>(base);
   base += W2B_STASH * blockDim.x * vec;
   L.red = reinterpret_cast<float *>(base);
-  int *p = base + 3 * W2B_T * W2B_MAXW;
+  int *p = base + 2 * W2B_T * W2B_MAXW;
   L.ctx = p; p += maxc;
   L.umult = p; p += maxc;
   L.tgt = p; p += maxt;
@@ -454,7 +454,10 @@ __device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot 
 // X: this XCD's copies of the hottest rows (nu = nv = 0: none; VEC == 4 only): a row k <= nu of u / k <= nv of v is read
 // and written at its copy instead of its master address.  Passed by reference, so that its fields stay in registers.
 // P.atomic_rank: the other rows among 1..atomic_rank are updated with atomic adds at their master address.
-template <int QM, int VEC, bool LOSS, int MM, bool LATE = false>
+// ATOM (16-byte columns only): which tables have rows that are updated with atomic adds -- 0 none, 1 u (context rows, phase
+// C), 2 u and v.  Instantiations of their own, so that the transposes of the atomic form cost the others no registers
+// (compiled into one kernel they spilled 7 more VGPRs: 77.9 % -> 73.2 % of the roofline at the headline shape).
+template <int QM, int VEC, bool LOSS, int MM, int ATOM = 0>
 __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &L, const QParam &qp,
                                              const int cw, const int nt, const float alpha,
                                              double &loss_acc, const XHot &X) {
@@ -480,7 +483,8 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     return load_col<VEC, MM>(P.u, row, dim, col0, P.tab_bytes);
   };
   // row <- val (= old + d): a store (hot rows: to this XCD's copy), or an atomic add of d for rows 1..atomic_rank
-  const int atomic_rank = P.atomic_rank, atomic_rank_u = P.atomic_rank_u;
+  // (VEC == 4: only the ATOM instantiations look at the ranks; the 4-byte-column kernels decide at run time)
+  const int atomic_rank = (VEC == 4 && ATOM < 2) ? 0 : P.atomic_rank, atomic_rank_u = (VEC == 4 && ATOM < 1) ? 0 : P.atomic_rank_u;
   auto up_u = [&](int row, const Col<VEC> &val, const Col<VEC> &d) {
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) { xhot_st(X.cu, row - 1, nhu, dim, col0, val); return; } }
     if (row <= atomic_rank_u) add_col<VEC>(P.u, row, dim, col0, d, P.tab_bytes);
@@ -495,25 +499,15 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     if (row <= atomic_rank) add_col<VEC>(P.v, row, dim, col0, d, P.tab_bytes);
     else store_col<VEC, MM>(P.v, row, dim, col0, val, P.tab_bytes);
   };
-  // Late round (P.hot_late, hot rows of v only): a hot target row is NOT loaded with its chunk -- ~10 us before its store,
-  // while the other workers of the XCD keep updating the same copy -- but after the chunk's other dot products are under
-  // way, and gets a reduction round of its own: open for about a microsecond.  The error accumulation and the stores
-  // stay in target order, so a single worker computes bit for bit what it computes without the late round.
-  // (LATE is an instantiation of its own: compiled into the common kernel, the extra round cost it 30 spilled VGPRs)
-  const bool late = LATE && (VEC == 4) && nhv > 0;
-  unsigned latemask = 0;                                        // wave-uniform: chunk slots that hold a hot row
   // one chunk of target rows
   auto load_targets = [&](bool zero) {
-    latemask = 0;
 #pragma unroll
     for (int i = 0; i < TC; i++) {
-      const bool is_late = late && start + i < end && (unsigned)(rows[i] - 1) < (unsigned)nhv;
-      if (is_late) latemask |= 1u << i;
-      if (zero || is_late) {
+      if (zero) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) x[i].e[e] = 0.f;
       }
-      if (active && start + i < end && !is_late) x[i] = ld_v(rows[i]);
+      if (active && start + i < end) x[i] = ld_v(rows[i]);
     }
   };
   // issue the first chunk of target-row loads before the context phase so both gathers overlap
@@ -573,13 +567,6 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
       p[i] = active ? s : 0.f;
     }
     float *red = L.red + par * (TC * W2B_MAXW);
-    if constexpr (VEC == 4 && LATE) {
-      if (latemask) {                                           // the hot rows of this chunk: loads in flight during the reduction below
-#pragma unroll
-        for (int i = 0; i < TC; i++)
-          if (((latemask >> i) & 1u) && active) x[i] = xhot_ld(X.cv, rows[i] - 1, nhv, dim, col0);
-      }
-    }
     if (MM == W2B_MM_EXACT) {
       // ref :461-467 in the reference's own order: f = 0; for c: f += context_avg[c] * quantize(v[c]) -- every
       // product rounded, then added to the running sum.  The products of a block of columns go to LDS, lane i of
@@ -630,40 +617,19 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
       gl = g;
       if (LOSS && wave == 0) fsave[start + lane] = f;           // the log-sigmoid term of ref :480-483 is booked after phase C
     }
-    if (LATE && latemask) {
-      float *red3 = L.red + 2 * (TC * W2B_MAXW);
-#pragma unroll
-      for (int i = 0; i < TC; i++) {
-        if ((latemask >> i) & 1u) {
-          float t[VEC];
-#pragma unroll
-          for (int e = 0; e < VEC; e++) t[e] = avg.e[e] * quant<QM>(x[i].e[e], qp);
-          const float sl = (VEC == 4) ? (t[0] + t[1 % VEC]) + (t[2 % VEC] + t[3 % VEC]) : ((VEC == 2) ? t[0] + t[1 % VEC] : t[0]);
-          const float ws = wave_sum(active ? sl : 0.f);
-          if (lane == 0) red3[i * W2B_MAXW + wave] = ws;
-        }
-      }
-      __syncthreads();
-      if (lane < n && ((latemask >> lane) & 1u)) {
-        float f = 0.f;
-        for (int w = 0; w < nwaves; w++) f += red3[lane * W2B_MAXW + w];
-        const float label = (start + lane == 0) ? 1.f : 0.f;
-        float g;
-        if (f > 6.f) g = (label - 1.f) * alpha;
-        else if (f < -6.f) g = label * alpha;
-        else g = (label - P.exp_table[(int)((f + 6.f) * 83.f)]) * alpha;
-        gl = g;
-        if (LOSS && wave == 0) fsave[start + lane] = f;
-      }
-    }
     // error accumulation + row update, in target order (ref :486-491)
 #pragma unroll
     for (int i = 0; i < TC; i++) {
       if (i < n) {
         const float g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), i));
+        // (wave-uniform choice: rows[i] lives in SGPRs) a frequent row below the hot ones gets its delta as an atomic add;
+        // every lane of the wavefront takes part in the transpose of that form, idle lanes with zeros
+        const bool by_add = (VEC == 4 && ATOM >= 2) && rows[i] <= atomic_rank && !((unsigned)(rows[i] - 1) < (unsigned)nhv);
         Col<VEC> dl;
+        if constexpr (VEC == 4 && ATOM >= 2) {
 #pragma unroll
-        for (int e = 0; e < VEC; e++) dl.e[e] = 0.f;
+          for (int e = 0; e < VEC; e++) dl.e[e] = 0.f;
+        }
         if (active) {
 #pragma unroll
           for (int e = 0; e < VEC; e++) {
@@ -677,13 +643,10 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
             dl.e[e] = g * avg.e[e] - ar2 * xv;
             x[i].e[e] = xv + dl.e[e];
           }
+          if (!by_add) up_v(rows[i], x[i], dl);
         }
-        // (wave-uniform choice: rows[i] lives in SGPRs) a frequent row below the hot ones gets its delta as an atomic add --
-        // all lanes take part in the transpose of the 16-byte-column form
-        if (VEC == 4 && rows[i] <= atomic_rank && !((unsigned)(rows[i] - 1) < (unsigned)nhv)) {
-          if constexpr (VEC == 4) add_col_contig<>(P.v, rows[i], dim, dl, P.tab_bytes);
-        } else if (active) {
-          up_v(rows[i], x[i], dl);
+        if constexpr (VEC == 4 && ATOM >= 2) {
+          if (by_add) add_col_contig<>(P.v, rows[i], dim, dl, P.tab_bytes);
         }
       }
     }
@@ -713,31 +676,49 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
         }
       }
 #pragma unroll
-    for (int jj = 0; jj < W2B_CA; jj++)
-      if (j0 + jj < cw) {                    // (wave-uniform: the atomic form needs every lane of the wavefront)
-        const int m = L.umult[j0 + jj];
-        if (m > 0) {
-          const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
-          const bool by_add = crow <= atomic_rank_u && !(VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu);
-          Col<VEC> dl;
+    for (int jj = 0; jj < W2B_CA; jj++) {
+      if constexpr (VEC == 4 && ATOM >= 1) {
+        if (j0 + jj < cw) {                    // (wave-uniform: the atomic form needs every lane of the wavefront)
+          const int m = L.umult[j0 + jj];
+          if (m > 0) {
+            const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
+            const bool by_add = crow <= atomic_rank_u && !((unsigned)(crow - 1) < (unsigned)nhu);
+            Col<VEC> dl;
 #pragma unroll
-          for (int e = 0; e < VEC; e++) dl.e[e] = 0.f;
-          for (int k = 0; k < m; k++) {      // a row that occurs m times in the window is updated m times
-            if (active) {
+            for (int e = 0; e < VEC; e++) dl.e[e] = 0.f;
+            for (int k = 0; k < m; k++) {      // a row that occurs m times in the window is updated m times
+              if (active) {
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                  dl.e[e] = err.e[e] - ar2 * r[jj].e[e];
+                  r[jj].e[e] = r[jj].e[e] + dl.e[e];
+                }
+              }
+              if (by_add) add_col_contig<>(P.u, crow, dim, dl, P.tab_bytes);   // (every one of the m updates is an add of its own)
+            }
+            if (!by_add && active) up_u(crow, r[jj], dl);
+          }
+        }
+      } else {
+        if (active && j0 + jj < cw) {
+          const int m = L.umult[j0 + jj];
+          if (m > 0) {
+            const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
+            const bool by_add = crow <= atomic_rank_u && !(VEC == 4 && (unsigned)(crow - 1) < (unsigned)nhu);   // (4-byte columns)
+            Col<VEC> dl;
+            for (int k = 0; k < m; k++) {      // a row that occurs m times in the window is updated m times
 #pragma unroll
               for (int e = 0; e < VEC; e++) {
                 dl.e[e] = err.e[e] - ar2 * r[jj].e[e];
                 r[jj].e[e] = r[jj].e[e] + dl.e[e];
               }
+              if (by_add && k + 1 < m) up_u(crow, r[jj], dl);    // (every one of the m updates is an add of its own)
             }
-            if (by_add) {                    // (every one of the m updates is an add of its own)
-              if constexpr (VEC == 4) add_col_contig<>(P.u, crow, dim, dl, P.tab_bytes);
-              else if (active) add_col<VEC>(P.u, crow, dim, col0, dl, P.tab_bytes);
-            }
+            up_u(crow, r[jj], dl);
           }
-          if (!by_add && active) up_u(crow, r[jj], dl);
         }
       }
+    }
   }
   if (LOSS) {
     // ref :480-483 for all targets of this centre word, now that the chunk registers are free: lane j of wavefront 0

@@ -77,8 +77,6 @@ struct W2bParams {
   int atomic_rank_u;              // the same for u (plain worker / tuple kernels: the context rows' phase C)
   int fresh_rank_u;               // plain kernels, phase C: context rows 1..fresh_rank_u are re-read before their update instead of
                                   // taken from the LDS stash of phase A (the update lands on the current value, ref :500-502)
-  int hot_late;                   // plain kernels: hot target rows are loaded AFTER the chunk's other dot products and get a reduction
-                                  // round of their own, so that a hot row is open for ~1 us instead of the chunk's ~10 us
   int exact;                      // serial dot product in the reference's order (plain worker / tuple kernels)
   float starting_alpha, sample, reg;
 };

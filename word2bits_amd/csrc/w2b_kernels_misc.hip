@@ -215,7 +215,7 @@ size_t w2b_lds_bytes(int dim, int window, int negative, bool worker_form, bool e
   const int maxc = (2 * window + 1 + 3) & ~3, maxt = (negative + 1 + 3) & ~3;
   int vec;
   const int threads = w2b_block_threads(dim, &vec);
-  size_t ints = (size_t)W2B_STASH * threads * vec + 3 * W2B_T * W2B_MAXW + 2 * maxc + 3 * maxt;
+  size_t ints = (size_t)W2B_STASH * threads * vec + 2 * W2B_T * W2B_MAXW + 2 * maxc + 3 * maxt;
   if (worker_form) ints += ((W2B_MAX_SEN + 3) & ~3) + 4 + (sizeof(WorkerLds) + 3) / 4 + 4;
   else ints += 4;
   if (exact) ints += (size_t)W2B_T * (W2B_EXACT_COLS + 1) + 4;

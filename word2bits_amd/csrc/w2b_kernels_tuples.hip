@@ -3,7 +3,7 @@
 
 namespace {
 // ------------------------------------------------------------------------------------ form (ii): tuples
-template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM>
+template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM, int ATOM = 0>
 __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES : 1)) k_train_tuples(const W2bParams P, const long long n,
                                                       const int32_t *__restrict__ center,
                                                       const int32_t *__restrict__ ctx_off,
@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     if constexpr (VEC == 1 && MAXTHREADS == 1024) wide = P.wide != 0;
     if (cw > 0) {
       if (wide) { if constexpr (VEC == 1 && MAXTHREADS == 1024) process_word_wide<QM, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc); }
-      else process_word<QM, VEC, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc, XH);
+      else process_word<QM, VEC, LOSS, MM, ATOM>(P, L, qp, cw, nt, alpha, loss_acc, XH);
     } else __syncthreads();
     if (VEC == 4 && hot && ++since_merge >= P.hot_period) {
       since_merge = 0;
@@ -98,6 +98,21 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
     } while (0)
 #define W2B_LAUNCH_T(VEC, LOSS) \
     do { if (threads <= 256) W2B_LAUNCH_T2(VEC, LOSS, 256); else W2B_LAUNCH_T2(VEC, LOSS, 1024); } while (0)
+    if constexpr (MM == 0) {          // rows updated with atomic adds: the ATOM instantiations (16-byte columns, <= 256 threads)
+      const int atom = p.atomic_rank > 0 ? 2 : (p.atomic_rank_u > 0 ? 1 : 0);
+      if (atom && vec == 4 && threads <= 256) {
+#define W2B_LAUNCH_TA(LOSS, ATOM)                                                                            \
+        do {                                                                                                 \
+          auto kern = k_train_tuples<QM, 4, LOSS, 256, 0, ATOM>;                                             \
+          int g = grid > 0 ? grid : auto_grid(kern, threads, lds, num_cus, per_cu_override, n);              \
+          hipLaunchKernelGGL(kern, dim3(g), dim3(threads), lds, s, p, n, center, ctx_off, ctx, neg, alpha);  \
+        } while (0)
+        if (atom == 2) { if (loss) W2B_LAUNCH_TA(true, 2); else W2B_LAUNCH_TA(false, 2); }
+        else { if (loss) W2B_LAUNCH_TA(true, 1); else W2B_LAUNCH_TA(false, 1); }
+#undef W2B_LAUNCH_TA
+        return hipGetLastError();
+      }
+    }
     if (vec == 4) { if (loss) W2B_LAUNCH_T(4, true); else W2B_LAUNCH_T(4, false); }
     else { if (loss) W2B_LAUNCH_T(1, true); else W2B_LAUNCH_T(1, false); }
 #undef W2B_LAUNCH_T

@@ -5,7 +5,7 @@
 namespace {
 // ------------------------------------------------------------------------------------ form (i): workers
 
-template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM, bool LATE = false>
+template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM, int ATOM = 0>
 __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES : 1)) k_train_workers(const W2bParams P, const long long max_positions) {
   extern __shared__ int smem[];
   WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
@@ -36,6 +36,11 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
   if (!hot) { XH.nu = 0; XH.nv = 0; }
   int since_merge = 0, merge_cursor = (wid >> 3) * P.xhot_m;      // (workgroup b runs on XCD b % 8: take turns)
   const int W = P.window, K = P.negative;
+  // wavefront 0: the unigram-table entries of the NEXT position's first 64 negative draws, requested one position ahead
+  // (the draws depend on nothing but the LCG state, ref :455-457), so that their trip to the 400 MB table overlaps with
+  // this position's row traffic instead of standing between two positions while the other three wavefronts wait
+  int pf_t = 0;
+  unsigned long long pf_rng = ~0ull;                              // LCG state before the window draw the prefetch was made for
   for (long long it = 0; it < max_positions; ++it) {
     if (wave == 0) {
       unsigned long long rng = S->rng;
@@ -66,8 +71,13 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
         done = 1;
       } else {
         const int word = (sen_len > 0) ? s_sen[sen_pos] : 0;          // ref :424
+#ifdef W2B_NO_TABLE_PREFETCH
+        const bool pf_ok = false;
+#else
+        const bool pf_ok = (rng == pf_rng);
+#endif
         rng = rng * W2B_LCG_A + W2B_LCG_C;                            // ref :428-429
-        const int b = (int)(rng % (unsigned long long)W);
+        const int b = (int)fast_mod(rng, (unsigned long long)W, P.window_magic);
         const int hi = 2 * W + 1 - b;
         for (int a0 = b; a0 < hi; a0 += 64) {                         // ref :431-436
           const int a = a0 + lane;
@@ -85,7 +95,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
             int t = 0;
             if (d <= K) {
               const unsigned long long x = lcg_jump(P, rng, d);
-              t = P.table[(x >> 16) % (unsigned long long)P.table_size];
+              t = (d0 == 1 && pf_ok) ? pf_t : P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
               if (t == 0) t = (int)(x % (unsigned long long)(P.vocab_size - 1)) + 1;
               keep = (t != word);
             }
@@ -102,6 +112,16 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
         sen_pos++;                                                    // ref :505-509
         if (sen_pos >= sen_len) sen_len = 0;
       }
+#ifndef W2B_NO_TABLE_PREFETCH
+      if (!done && K > 0) {                                           // next position's table entries (valid if its LCG state is `rng`)
+        const unsigned long long r1 = rng * W2B_LCG_A + W2B_LCG_C;
+        pf_rng = rng;
+        if (lane < K) {
+          const unsigned long long x = lcg_jump(P, r1, lane + 1);
+          pf_t = P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
+        }
+      }
+#endif
       if (lane == 0) {
         S->rng = rng; S->cursor = cursor; S->wc = wc; S->last_wc = last_wc;
         S->sen_len = sen_len; S->sen_pos = sen_pos; S->override_ = ovr; S->eof = eof;
@@ -116,7 +136,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     if constexpr (VEC == 1 && MAXTHREADS == 1024) wide = P.wide != 0;
     if (cw > 0) {
       if (wide) { if constexpr (VEC == 1 && MAXTHREADS == 1024) process_word_wide<QM, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc); }
-      else process_word<QM, VEC, LOSS, MM, LATE>(P, L, qp, cw, nt, alpha, loss_acc, XH);
+      else process_word<QM, VEC, LOSS, MM, ATOM>(P, L, qp, cw, nt, alpha, loss_acc, XH);
     } else __syncthreads();
     if (VEC == 4 && hot && ++since_merge >= P.hot_period) {
       since_merge = 0;
@@ -171,10 +191,13 @@ hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool 
 #define W2B_LAUNCH_W(VEC, LOSS) \
     do { if (threads <= 256) hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 256, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); \
          else hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 1024, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); } while (0)
-    if constexpr (MM == 0) {          // hot target rows in a late round of their own (w2b_tuning.hot_late): 16-byte columns, coherent rows
-      if (p.hot_late && vec == 4 && threads <= 256 && p.xhot && p.xhot_v > 0) {
-        if (loss) hipLaunchKernelGGL((k_train_workers<QM, 4, true, 256, 0, true>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions);
-        else hipLaunchKernelGGL((k_train_workers<QM, 4, false, 256, 0, true>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions);
+    if constexpr (MM == 0) {          // rows updated with atomic adds (w2b_tuning.atomic_rank*): the ATOM instantiations (16-byte columns)
+      const int atom = p.atomic_rank > 0 ? 2 : (p.atomic_rank_u > 0 ? 1 : 0);
+      if (atom && vec == 4 && threads <= 256) {
+#define W2B_LAUNCH_A(LOSS, ATOM) hipLaunchKernelGGL((k_train_workers<QM, 4, LOSS, 256, 0, ATOM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions)
+        if (atom == 2) { if (loss) W2B_LAUNCH_A(true, 2); else W2B_LAUNCH_A(false, 2); }
+        else { if (loss) W2B_LAUNCH_A(true, 1); else W2B_LAUNCH_A(false, 1); }
+#undef W2B_LAUNCH_A
         return hipGetLastError();
       }
     }

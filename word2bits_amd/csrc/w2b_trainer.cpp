@@ -54,6 +54,7 @@ struct w2b_trainer {
   std::vector<double> ctx_share;        // [k]: share of the KEPT (sub-sampled) context positions that rows 1..k+1 hold
   std::vector<int64_t> counts;          // vocab[].cn as given to w2b_set_vocab_counts (sorted by count behind row 0)
   double counts_pw = 0, counts_tot = 0; // sum cn^0.75, sum cn
+  double counts_tot_kept = 0;           // sum of the expected KEPT occurrences (sub-sampling, ref :403-406)
   float *wide_scratch = nullptr;        // process_word_wide: [workgroups][2][dim]
   size_t wide_floats = 0;
   float *xhot = nullptr;        // [W2B_NXCD]{copies [nu + nv][dim], entries [nu + nv][dim], merge locks [nu + nv][W2B_MAXW]}
@@ -225,7 +226,6 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.win_refresh = t->tune.window_refresh;
   p.atomic_rank = 0;
   p.atomic_rank_u = 0;
-  p.hot_late = 0;
   p.fresh_rank_u = 0;
   (void)w2b_block_threads(t->cfg.layer1_size, nullptr, &p.wide);   // rows longer than a workgroup has columns
   p.wide_scratch = t->wide_scratch;
@@ -365,7 +365,6 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
   if (in->window_refresh < 0) return fail(W2B_EINVAL, "w2b_set_tuning: window_refresh must be >= 0");
   if (in->atomic_rank_u < -1) return fail(W2B_EINVAL, "w2b_set_tuning: atomic_rank_u >= -1");
   if (in->fresh_rank_u < -1) return fail(W2B_EINVAL, "w2b_set_tuning: fresh_rank_u >= -1");
-  if (in->hot_late < -1 || in->hot_late > 1) return fail(W2B_EINVAL, "w2b_set_tuning: hot_late must be -1, 0 or 1");
   if (in->hot_weight_permille < 1 || in->hot_weight_permille > 1000)
     return fail(W2B_EINVAL, "w2b_set_tuning: hot_weight_permille must be 1..1000");
   for (int r : in->reserved) if (r != 0) return fail(W2B_EINVAL, "w2b_set_tuning: reserved fields must be zero");
@@ -536,6 +535,7 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
     t->counts.assign(cn, cn + V);
     t->counts_pw = pw;
     t->counts_tot = tot;
+    t->counts_tot_kept = tot_kept;
     const int n = (int)(V - 1 < W2B_XHOT_MAX ? V - 1 : W2B_XHOT_MAX);
     t->rate_v.assign((size_t)(n > 0 ? n : 0), 0.0);
     t->rate_u.assign((size_t)(n > 0 ? n : 0), 0.0);
@@ -712,7 +712,7 @@ extern "C" int w2b_epoch_begin(w2b_trainer *t) {
 }
 
 static const double W2B_PLAIN_CTX_SHARE = 0.2;     // share of the context positions held by hot rows above which the plain kernel runs
-static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv);
+static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv, bool legacy_u);
 
 // Which worker kernel runs: plain_worker_kernel 0 = automatic (sentence-resident kernel for coherent rows when
 // the window fits in LDS; plain kernel for relaxed rows, where caching in L2 already absorbs the re-reads and
@@ -724,21 +724,17 @@ static int worker_plan(const w2b_trainer *t) {
   if (t->cfg.relaxed_coherence) return -1;              // the sentence-resident kernel exists for coherent rows only
   if (t->tune.mem_mode > 0) return -1;
   if (mode == 0) {
-    // Automatic: the sentence-resident kernel keeps every context row private to a worker while it is in the window.
-    // That is a gain when the window's words are mostly rare (a real corpus with sub-sampling: ref default -sample
-    // 1e-3); when a large part of all context positions are the few most frequent words (no sub-sampling: the
-    // synthetic benchmark stream), those rows would be resident in every worker nearly all the time.  Then the plain
-    // kernel, which reads and writes them at their XCD copies every step (XHot), is as fast and follows the
-    // reference's losses more closely.
-    int nu = 0, nv = 0;       // (judged for a full device, so that a probe trainer with one worker decides as the real one will)
-    const long long full = 2ll * t->num_cus;
-    xhot_plan(t, t->cfg.num_threads > full ? t->cfg.num_threads : full, true, &nu, &nv);
-    const double share = (nu > 0 && nu <= (int)t->ctx_share.size()) ? t->ctx_share[(size_t)nu - 1] : 0.0;
-    // ... where the plain kernel is competitive: long rows and at least as many target rows as two windows' worth of
-    // context rows (measured, Zipf ids without sub-sampling, plain vs sentence-resident, % of the HBM roofline: size 800
-    // negative 24: 71.2 vs 72.7; size 1000 negative 12: 75 vs 92; size 400: 61 vs 71; size 200: 42 vs 58)
-    const bool competitive = t->cfg.layer1_size >= 512 && t->cfg.negative >= 2 * (t->cfg.window + 1);
-    if (competitive && share > W2B_PLAIN_CTX_SHARE) return -1;
+    // Automatic = the plain kernel (round 4).  The sentence-resident kernel keeps every context row PRIVATE to a worker
+    // for as long as the row is in its window -- up to 2 x window + 1 positions, where the reference's thread holds a
+    // context row for one -- and publishes the worker's accumulated progress when the row leaves.  With hundreds of
+    // workers every frequent word is in dozens of windows at once, and the sum of those private progresses over-shoots.
+    // Rounds 2-3 chose it wherever it was faster and kept it inside the fidelity gates of the regimes they measured
+    // (text8-sized corpus: -1 ... -2.5 %) with a consensus rule for the most frequent context rows; on the first
+    // held-out regime (Zipf exponent 1.2 at the configs[2] shape, tests/w2b_testlib.py HELDOUT) that same default is
+    // 13 % off the reference's first-epoch loss at 256 workers (28 % without the consensus rule), the plain kernel
+    // 0.1-2 %.  It stays available as an explicit choice (plain_worker_kernel = 2, ./word2bits -window-cache 1): the
+    // faster kernel at short rows, with this caveat.
+    return -1;
   }
   return w2b_resident_plan(t->cfg.layer1_size, t->cfg.window, t->cfg.negative);
 }
@@ -766,7 +762,11 @@ static int effective_radius(const w2b_trainer *t, long long workers) {
 // 400 K-word Zipf vocabulary), none for 8 workers and none on flat distributions.  Only for 16-byte columns, coherent
 // rows, and not in the parity mode.
 static const double W2B_HOT_LOAD = 6400.0;
-static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv) {
+// u: round 4 -- the automatic choice gives the context rows NO copies (w2b_tuning.hot_rows_u = -1 -> 0): their updates are
+// atomic adds at the master rows instead (atomic_plan_u; the reference's `u[c] += e[c]`, ref :500-502), which one row
+// takes at 37 M per second (tools/atomic_probe.hip; row 1 of the headline stream needs 19 M).  legacy_u: the load rule of
+// round 3, which the sentence-resident kernel still uses to pick its consensus rows (uavg_rank).
+static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv, bool legacy_u) {
   *nu = *nv = 0;
   const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
   int wide = 0;
@@ -783,7 +783,7 @@ static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int 
     return (int)(n < vmax ? n : (vmax > 0 ? vmax : 0));
   };
   *nv = pick(t->tune.hot_rows_v, t->rate_v);
-  if (with_u) *nu = pick(t->tune.hot_rows_u, t->rate_u);
+  if (with_u) *nu = (t->tune.hot_rows_u < 0 && !legacy_u) ? 0 : pick(t->tune.hot_rows_u, t->rate_u);
 }
 
 // Rows 1..n (by count) whose updates are atomic adds at their master address (w2b_tuning.atomic_rank).  A load / modify /
@@ -820,6 +820,40 @@ static int atomic_plan(const w2b_trainer *t, long long workers) {
   return (int)(n < V - 1 ? n : V - 1);
 }
 
+// Context rows (u) updated with atomic adds.  The reference adds a centre word's accumulated error to every context row
+// with `u[c] += e[c]` on the row's CURRENT value (ref :500-502): nothing another thread added since the row was read for
+// the window average (ref :439) is lost -- the gradient is a whole centre word old, its application is not.  A GPU worker
+// that stores `value read in phase A + e` instead erases whatever the other workers added to the row during that centre
+// word.  How many others hold the row at that moment: workers x (uses of the row per centre word) -- a row is in a window
+// for the whole centre word, on the CPU as here, so this number is the reference's own at the same thread count.  Rows
+// for which it reaches W2B_ATOMIC_LOAD (a quarter of a worker) get the add; the vocabulary is sorted by count, so they
+// are a prefix.  Measured (profiles/r04_sessions/): the benchmarked regime at 64 / 256 / 1024 workers within 0.9 % of the
+// reference's epoch loss with lossless context rows and NO per-XCD copies, against +1.6 / +2.8 / +5.3 % with plain stores;
+// cost 1-2 % of the throughput in the transposed 16-byte-column form (add_col_contig).
+static int atomic_plan_u(const w2b_trainer *t, long long workers, int atomic_rank_v) {
+  const long long V = t->cfg.vocab_size;
+  if (t->tune.atomic_rank_u > 0) return (int)(t->tune.atomic_rank_u < V - 1 ? t->tune.atomic_rank_u : V - 1);
+  if (t->tune.atomic_rank_u < 0) return 0;
+  int wide = 0;
+  (void)w2b_block_threads(t->cfg.layer1_size, nullptr, &wide);
+  const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
+  if (t->cfg.exact_reduction || wide || mem_mode != 0) return atomic_rank_v;
+  if (t->tune.atomic_rank >= 0) return atomic_rank_v;            // an explicit atomic_rank speaks for both tables (round-3 meaning)
+  long long n = atomic_rank_v;
+  if (!t->counts.empty() && t->counts_tot_kept > 0) {
+    const double st = (double)t->cfg.sample * (double)t->cfg.train_words;
+    auto kept = [&](double c) { return (t->cfg.sample > 0 && st > 0) ? (c < sqrt(c * st) + st ? c : sqrt(c * st) + st) : c; };
+    long long lo = 0, hi = V - 1;                                 // largest row whose rate still reaches the threshold
+    while (lo < hi) {
+      const long long mid = (lo + hi + 1) / 2;
+      const double rate = (t->cfg.window + 1) * kept((double)t->counts[(size_t)mid]) / t->counts_tot_kept;
+      if ((double)workers * rate >= W2B_ATOMIC_LOAD) lo = mid; else hi = mid - 1;
+    }
+    if (lo > n) n = lo;
+  }
+  return (int)(n < V - 1 ? n : V - 1);
+}
+
 // scratch rows of process_word_wide for `workgroups` workgroups (grown on demand)
 static int wide_prepare(w2b_trainer *t, W2bParams &p, long long workgroups) {
   if (!p.wide) return W2B_OK;
@@ -840,18 +874,16 @@ static int wide_prepare(w2b_trainer *t, W2bParams &p, long long workgroups) {
 // layout changed or somebody wrote the master rows since the last launch.
 static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool with_u) {
   int nu = 0, nv = 0;
-  xhot_plan(t, workers, with_u, &nu, &nv);
+  xhot_plan(t, workers, with_u, &nu, &nv, false);
   p.xhot = nullptr;
   p.xhot_u = nu;
   p.xhot_v = nv;
   p.atomic_rank = atomic_plan(t, workers);
-  p.atomic_rank_u = t->tune.atomic_rank_u > 0 ? (t->tune.atomic_rank_u < t->cfg.vocab_size - 1 ? t->tune.atomic_rank_u : (int)(t->cfg.vocab_size - 1))
-                                              : (t->tune.atomic_rank_u < 0 ? 0 : p.atomic_rank);
-  p.hot_late = t->tune.hot_late > 0 ? 1 : 0;
+  p.atomic_rank_u = with_u ? atomic_plan_u(t, workers, p.atomic_rank) : 0;   // (the sentence-resident kernel keeps its context rows in LDS)
   p.fresh_rank_u = t->tune.fresh_rank_u > 0 ? t->tune.fresh_rank_u : 0;
   if (!with_u) {          // sentence-resident kernel: its context rows live in LDS; the most frequent ones (the rows that
     int un = 0, vn = 0;   // would be hot rows of u) are merged by consensus and refreshed (w2b_kernels_resident.hip)
-    xhot_plan(t, workers, true, &un, &vn);
+    xhot_plan(t, workers, true, &un, &vn, true);
     p.uavg_rank = un;
   }
   if (nu + nv == 0) return W2B_OK;
@@ -886,6 +918,11 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   return W2B_OK;
 }
 
+// Fewest words of an epoch a worker should have when the library picks the number of workers: alpha is re-computed per
+// worker only every 10000 of its own words (ref :379-393), so short shards coarsen the schedule.  20000 in rounds 2-3; the
+// text8-sized corpus then ran 850 workers and ended its later epochs 2 % off the reference whatever the row-update
+// scheme (256 workers: 0.5 %), i.e. the cap, not a race, was what the gate saw.
+static const long long W2B_WORDS_PER_WORKER_MIN = 50000;
 extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
   NEED(t);
   if (!out) return fail(W2B_EINVAL, "w2b_suggested_threads: null");
@@ -901,7 +938,7 @@ extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
   if (t->cfg.train_words > 0) {
     const long long total = t->cfg.total_threads > 0 && t->cfg.num_threads > 0
                                 ? (long long)t->cfg.total_threads / t->cfg.num_threads : 1;   // replicas
-    const long long cap = t->cfg.train_words / (20000 * (total > 0 ? total : 1));
+    const long long cap = t->cfg.train_words / (W2B_WORDS_PER_WORKER_MIN * (total > 0 ? total : 1));
     if (n > cap) n = cap > 1 ? cap : 1;
   }
   *out = (int32_t)n;
@@ -914,7 +951,7 @@ extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t
   const W2bParams p = make_params(t);
   const int r = effective_radius(t, t->cfg.num_threads);
   int hu = 0, hot = 0;
-  xhot_plan(t, t->cfg.num_threads, r < 0, &hu, &hot);
+  xhot_plan(t, t->cfg.num_threads, r < 0, &hu, &hot, false);
   if (resident) *resident = r >= 0;
   if (radius) *radius = r;
   if (hot_rows) *hot_rows = hot;
