@@ -393,7 +393,21 @@ def other_shapes():
         "cfg5_b0": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "0"],
         "d200": ["--vocab", "60238", "--dim", "200"],
         "d400_b2": ["--vocab", "60238", "--dim", "400", "--bitlevel", "2"],
+        # the sentence-resident kernel (context window rows stay in LDS): the faster kernel at these shapes, an explicit
+        # choice since round 4 (./word2bits -window-cache 1) because it keeps context rows private for up to 2 x window + 1
+        # positions and is up to 13 % off the reference's epoch loss on a held-out regime
+        "cfg5_b1_resident": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "1", "--window-cache", "1"],
+        "d200_resident": ["--vocab", "60238", "--dim", "200", "--window-cache", "1"],
+        "d400_b2_resident": ["--vocab", "60238", "--dim", "400", "--bitlevel", "2", "--window-cache", "1"],
     }
+    # tables of 48 / 96 MB live in the 256 MB Infinity Cache: HBM's 8 TB/s is not what bounds those legs.  The bound quoted
+    # beside it is what the memory system sustains for the same access shape (random rows, 16 bytes per lane, sc1 read +
+    # write) on a cache-sized table: tools/row_probe small, measured in the round's profile session
+    cache_bound = {}
+    try:
+        cache_bound = json.load(open(os.path.join(ROOT, "profiles", "r04_cache_bound.json")))
+    except Exception:
+        pass
     out = {}
     for name, extra in legs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--tokens", "30000000", "--steps", "10", "--warmup", "3",
@@ -406,6 +420,10 @@ def other_shapes():
                          "roofline_frac": d["roofline"]["frac"], "achieved_GBps": d["roofline"]["achieved"],
                          "kernel": d["roofline"]["kernel"], "avg_launch_ms": d["roofline"]["avg_launch_ms"],
                          "workload": d["config"]["workload"], "worker_kernel": d["config"].get("worker_kernel")}
+            cb = cache_bound.get(name.replace("_resident", ""))
+            if cb:
+                out[name]["cache_resident_bound_GBps"] = cb["GBps"]
+                out[name]["frac_of_cache_resident_bound"] = d["roofline"]["achieved"] / cb["GBps"]
         except Exception as e:                  # a leg must never take the headline down
             out[name] = {"value": None, "error": repr(e)[:200]}
     return out

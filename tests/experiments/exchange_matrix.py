@@ -6,6 +6,8 @@ every launch + full every E launches.  Printed: epoch loss and its deviation fro
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+torch.cuda.init()        # torch's bundled HIP runtime finds the GPU only when it initialises before the library's (tests/conftest.py)
 import word2bits_amd as w2b
 from w2b_testlib import write_zipf_text_corpus
 from test_gpu_exchange import run_replicas

@@ -46,17 +46,22 @@ def main():
     ref_threads = int(sys.argv[sys.argv.index("--ref-threads") + 1]) if "--ref-threads" in sys.argv else (os.cpu_count() or 1)
     tmp = "/tmp/w2b_e2e"
     os.makedirs(tmp, exist_ok=True)
-    corpus = write_headline_corpus(os.path.join(tmp, "headline.txt"))
+    corpus = write_headline_corpus(os.path.join(tmp, "headline_%d.txt" % os.getpid()))
     flags = ["-bitlevel", "1", "-size", "800", "-window", "8", "-negative", "24", "-iter", "1", "-sample", "0", "-binary", "1", "-min-count", "5"]
     res = {"file": "write_headline_corpus(vocab=400000, n_zipf=20000000): %d bytes, 22 M tokens" % os.path.getsize(corpus), "flags": " ".join(flags)}
-    res["word2bits_hip"] = phases([os.path.join(ROOT, "word2bits"), "-train", corpus, "-output", os.path.join(tmp, "hip.bin"), "-threads", "0"] + flags)
-    res["reference"] = phases([os.path.join(ROOT, "oracle", "_ref", "word2bits_stock"), "-train", corpus, "-output", os.path.join(tmp, "ref.bin"),
-                               "-threads", str(ref_threads)] + flags)
-    res["reference_threads"] = ref_threads
-    if res["word2bits_hip"] and res["reference"]:
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "both"     # hip | ref | both (two calls merge into out.json)
+    if os.path.exists(out):
+        res.update({k: v for k, v in json.load(open(out)).items() if k in ("word2bits_hip", "reference", "reference_threads")})
+    if only in ("hip", "both"):
+        res["word2bits_hip"] = phases([os.path.join(ROOT, "word2bits"), "-train", corpus, "-output", os.path.join(tmp, "hip.bin"), "-threads", "0"] + flags)
+    if only in ("ref", "both"):
+        res["reference"] = phases([os.path.join(ROOT, "oracle", "_ref", "word2bits_stock"), "-train", corpus, "-output", os.path.join(tmp, "ref.bin"),
+                                   "-threads", str(ref_threads)] + flags)
+        res["reference_threads"] = ref_threads
+    if res.get("word2bits_hip") and res.get("reference"):
         res["speedup_total"] = round(res["reference"]["total_s"] / res["word2bits_hip"]["total_s"], 1)
         res["speedup_train"] = round(res["reference"]["train_s"] / max(res["word2bits_hip"]["train_s"], 1e-3), 1)
-    for f in ("hip.bin", "ref.bin", "headline.txt"):
+    for f in ("hip.bin", "ref.bin", os.path.basename(corpus)):
         try:
             os.remove(os.path.join(tmp, f))
         except OSError:

@@ -37,15 +37,26 @@ def main():
     l = per_dispatch(l2, ksub) if l2 != "-" else {}
     fetch_kb, nf = f["FETCH_SIZE"]
     write_kb, nw = w["WRITE_SIZE"]
+    # calibration (round 4): tools/row_probe calib under the same two counters, known row bytes, for the cache policy the
+    # kernel's row accesses carry (sc1) -- profiles/r04_pmc_calibration.json; round 3 applied the guide's x2 / x1 unchecked
+    ff, wf, src = 2.0, 1.0, "x2 / x1 (MI355X_MICROARCH.md, uncalibrated for this access shape)"
+    import os
+    cal = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_pmc_calibration.json")
+    if os.path.exists(cal):
+        c = json.load(open(cal)).get("sc1", {})
+        if c.get("fetch_factor_in_read+write") and c.get("write_factor_in_read+write"):
+            ff, wf = c["fetch_factor_in_read+write"], c["write_factor_in_read+write"]
+            src = ("profiles/r04_pmc_calibration.json: row_probe calib, sc1 16-byte-lane random-row read+write with known bytes: "
+                   "FETCH_SIZE x %.4f, WRITE_SIZE x %.4f" % (ff, wf))
     res = {
         "kernel": ksub,
         "dispatches_sampled": {"FETCH_SIZE": nf, "WRITE_SIZE": nw},
         "FETCH_SIZE_KB_per_launch": fetch_kb,
         "WRITE_SIZE_KB_per_launch": write_kb,
-        "hbm_read_bytes_per_launch": fetch_kb * 1024 * 2,
-        "hbm_write_bytes_per_launch": write_kb * 1024,
-        "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
-        "fetch_correction": "x2 (gfx950 FETCH_SIZE half-count on 16-B/lane coalesced reads, MI355X_MICROARCH.md HBM section)",
+        "hbm_read_bytes_per_launch": fetch_kb * 1024 * ff,
+        "hbm_write_bytes_per_launch": write_kb * 1024 * wf,
+        "hbm_bytes_per_launch": fetch_kb * 1024 * ff + write_kb * 1024 * wf,
+        "counter_factors": src,
     }
     if l:
         hit, miss = l["TCC_HIT_sum"][0], l["TCC_MISS_sum"][0]
