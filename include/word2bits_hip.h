@@ -143,7 +143,10 @@ typedef struct w2b_tuning {
   int32_t fresh_rank_u;    /* plain worker / tuple kernels: context rows 1..N are read again right before their update (phase C)
                             * instead of taken from the LDS stash of phase A, so that the update lands on the row's CURRENT value
                             * as the reference's `u[c] += e[c]` does (ref :500-502); 0 = the library decides, -1 = none */
-  int32_t reserved[2];
+  int32_t exchange_sat_updates;  /* replica exchange, mode 2 / hot tier: a row counts as SATURATED (moves by the mean of its
+                                  * contributors' deltas instead of their sum) when every replica has updated it at least this
+                                  * often since the last exchange; 0 = the library's default */
+  int32_t reserved[1];
 } w2b_tuning;
 int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out);
 int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in);

@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--positions", default="1024,256,64")
 ap.add_argument("--replicas", default="2,4")
 ap.add_argument("--tiers", default="8:4,8:16,32:16", help="E:B pairs: full exchange every E launches, hot tier of B MB per table")
+ap.add_argument("--sat", default="0", help="w2b_tuning.exchange_sat_updates values to sweep (0 = library default)")
+ap.add_argument("--modes", default="2", help="exchange modes for the 'full every launch' scheme (0 delta-sum, 2 contributor mean)")
 a = ap.parse_args()
 path = write_zipf_text_corpus("/tmp/w2b_xm_t8.txt")
 corpus = w2b.Corpus(path, 5)
@@ -34,11 +36,20 @@ for positions in [int(x) for x in a.positions.split(",")]:
             schemes.append(("two-tier E=%d B=%dMB" % (E, B), dict(sync_every=E, hot_mb=B)))
             schemes.append(("full every %d only" % E, dict(sync_every=E)))
         seen = set()
-        for name, kw in schemes:
-            if name in seen:
-                continue
-            seen.add(name)
-            t0 = time.time()
-            loss, _ = run_replicas(corpus, R, workers, positions=positions, flags=flags, mode=2, **kw)
-            print("XM positions=%-5d R=%d %-26s loss %.0f (%+.2f %% vs 1 replica)  [%.1f s]" % (positions, R, name, loss, 100 * (loss - one) / abs(one), time.time() - t0), flush=True)
+        for sat in [int(x) for x in a.sat.split(",")]:
+            for name, kw in schemes:
+                for mode in ([int(x) for x in a.modes.split(",")] if name == "full every launch" else [2]):
+                    key = (name, mode, sat if name != "none" else 0)
+                    if key in seen:
+                        continue
+                    seen.add(key)
+                    t0 = time.time()
+                    tn = dict(exchange_sat_updates=sat) if sat else {}
+                    try:
+                        loss, _ = run_replicas(corpus, R, workers, positions=positions, flags=flags, mode=mode, **kw, **tn)
+                    except Exception as e:
+                        print("XM positions=%-5d R=%d %-26s mode %d sat %-5d FAILED %r" % (positions, R, name, mode, sat, e), flush=True)
+                        continue
+                    print("XM positions=%-5d R=%d %-26s mode %d sat %-5d loss %.0f (%+.2f %% vs 1 replica)  [%.1f s]" % (
+                        positions, R, name, mode, sat, loss, 100 * (loss - one) / abs(one), time.time() - t0), flush=True)
 corpus.close(); os.remove(path)

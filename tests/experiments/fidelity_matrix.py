@@ -62,18 +62,23 @@ def corpus_of(job):
         return write_headline_corpus(os.path.join(TMP, "hl.txt")), dict(bitlevel=1, size=800, window=8, negative=24, iter=1, sample=0)
     if job == "text8size":
         return write_zipf_text_corpus(os.path.join(TMP, "t8.txt")), dict(bitlevel=1, size=200, window=8, negative=24, iter=3)
+    if job.startswith("planted"):
+        from planted import make_planted
+        c = os.path.join(TMP, "planted.txt")
+        make_planted(c, os.path.join(TMP, "planted_q.txt"), repeats=120)
+        return c, B[job]["flags"]
     return write_heldout_corpus(os.path.join(TMP, job + ".txt"), job), HELDOUT[job]["flags"]
 
 
 out = open(a.out, "a") if a.out else None
 for job in a.jobs.split(","):
     c, fl = corpus_of(job)
-    for th in (64, 256):
+    for th in (8, 64, 256):
         m, s = band(job, th)
         if m is not None:
             print("%-14s reference %3d threads %s  (rel. std %s %%)" % (job, th, np.round(m / 1e3).tolist(), np.round(100 * s / np.abs(m), 2).tolist()))
     for th in [int(x) for x in a.threads.split(",")]:
-        ref_th = 64 if 0 < th <= 64 else 256
+        ref_th = (8 if 0 < th <= 8 else 64) if 0 < th <= 64 else 256
         m, _ = band(job, ref_th)
         for kern in KERNELS:
             for name, extra in ARMS:

@@ -215,7 +215,7 @@ def test_exchange_needs_init(gpu):
 
 
 # ---------------------------------------------------------------------------------------------- training effect
-def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=True, mode=2, hot_mb=0):
+def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=True, mode=2, hot_mb=0, **tuning):
     """one epoch over `corpus` with R replicas of workers_total / R workers each, exchanged every sync_every launches
     and at the end (sync_every 0: at the end only); hot_mb > 0: the hot tier (at most hot_mb MB of leading rows per table)
     after every other launch, as ./word2bits -gpus N does; returns the summed epoch loss"""
@@ -227,7 +227,7 @@ def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=
     for r in range(R):
         t = w2b.Trainer(corpus.vocab_size, flags["size"], flags["window"], flags["negative"], flags["bitlevel"],
                         num_threads=per, iter=1, train_words=corpus.train_words, compute_loss=True,
-                        worker_offset=r * per, total_threads=workers_total)
+                        worker_offset=r * per, total_threads=workers_total, **tuning)
         t.init_net()
         t.set_vocab_counts(corpus.counts(), 100_000_000)
         st = starts[r * per:(r + 1) * per]

@@ -3,19 +3,35 @@
 With several workers nothing is bit-reproducible -- not in the reference either -- so these tests hold `./word2bits`
 to what the UNMODIFIED reference program does with the SAME number of truly concurrent threads on the same corpus:
 `tests/golden/fidelity_bands.json`, recorded by tests/golden/make_fidelity_bands.py on the GPU box's HOST (2 x EPYC
-9575F, 256 hardware threads -- round 2's bands came from an 8-core container that time-slices 64 threads), 2-3 runs
-per thread count:
-  planted_*   planted-analogy corpus (564 K tokens), bitlevel 1 size 200 and BASELINE configs[2] shape (bitlevel 2, size
-              400, negative 24, iter 5), 8 / 64 / 512 threads, scored by the unmodified evaluator
-  text8size   17 M Zipf tokens over 70 K words, bitlevel 1 size 200 (BASELINE configs[0] shape), 3 epochs, 64 / 256 threads
-  headline    the BENCHMARKED regime, BASELINE configs[1]: V = 400 K, size 800, window 8, negative 24, bitlevel 1,
-              -sample 0, 22 M tokens (every word 5x + a 20 M-token Zipf(1) stream), 64 / 256 threads
+9575F, 256 hardware threads), 2-3 runs per thread count:
+  planted_*        planted-analogy corpus (564 K tokens), bitlevel 1 size 200 and BASELINE configs[2] shape (bitlevel 2, size
+                   400, negative 24, iter 5), 8 / 64 / 512 threads, scored by the unmodified evaluator
+  text8size        17 M Zipf tokens over 70 K words, bitlevel 1 size 200 (BASELINE configs[0] shape), 3 epochs, 64 / 256 threads
+  headline         the BENCHMARKED regime, BASELINE configs[1]: V = 400 K, size 800, window 8, negative 24, bitlevel 1,
+                   -sample 0, 22 M tokens (every word 5x + a 20 M-token Zipf(1) stream), 64 / 256 threads
+  heldout_k5       (round 4) HELD OUT -- no knob of the library was ever swept on it: V = 100 K, size 300, window 5, negative 5,
+                   bitlevel 1, -sample 0, 8.5 M tokens, 64 / 256 threads
+  heldout_zipf12   (round 4) HELD OUT: Zipf exponent 1.2 at the configs[2] shape (bitlevel 2, size 400, negative 24), default
+                   -sample, 2 epochs, 64 / 256 threads
 
-Every tolerance is  max(3 sigma of the reference's own runs at that thread count, FLOOR[regime])  per epoch -- the
-reference's run-to-run spread, not the product's measured value.  The reference is extremely repeatable (sigma 0.01-0.4 %
-of an epoch loss), so the floors decide; they are stated per regime below with what round 3 measured, and DESIGN.md
-section 6 has the full matrix (kernels x worker counts x hot-row / atomic / exchange knobs) they were read from.
-Accuracy is asserted inside the reference's band widened by max(5 points, 3 sigma).
+Every tolerance is  max(3 sigma of the reference's own runs at that thread count, FLOOR)  per epoch.  The reference is
+extremely repeatable (sigma 0.01-0.4 % of an epoch loss), so the floor decides: ONE floor for every regime since round 4,
+1.5 % (round 3 had 1.5 % / 3.5 % per regime, set just above what the product measured).  What the product does to stay
+inside it (profiles/r04_sessions/ has every matrix these numbers were read from):
+  * the automatic kernel is the plain one (the sentence-resident kernel keeps context rows private for up to 2 x window + 1
+    positions: -13 % on heldout_zipf12 at 256 workers; it is an explicit choice now and held to its own, looser bound below);
+  * below a full device no row has per-XCD copies -- every row is shared by all workers as in the reference -- and the
+    context rows are updated by lossless atomic adds (the reference's `u[c] += e[c]`, ref :500-502): measured
+    +0.3 / +0.9 / +1.5 % at 64 / 256 / 440 workers in the benchmarked regime (round 3's rules: -2.2 / -2.8 / -1.4 %), within
+    0.8 % everywhere on the two held-out regimes and the text8-sized corpus;
+  * on a full device (>= 3 workgroups per CU: `-threads 0` on a corpus of 50 M words and more) the hottest rows would queue
+    at their memory lines (13 M words/s instead of 28 M), so they get per-XCD copies kept together by consensus merges:
+    -0.1 ... +0.4 % in the benchmarked regime at 1024 workers -- a measured balance of two opposite errors (updates lost
+    inside an XCD, stale copies between XCDs), not a derived property, and asserted here on that regime only;
+  * `-threads 0` never picks fewer than 50 000 words per worker and epoch (20 000 until round 3: the text8-sized corpus then
+    ran 850 workers and its later epochs ended 2 % off whatever the row-update scheme -- the alpha schedule, re-computed per
+    worker every 10 000 words, was what the gate saw).
+Accuracy is asserted inside the reference's band widened by max(2 points, 3 sigma) (round 3: 5 points).
 The product's `./compute_accuracy` transcript must equal the unmodified evaluator's byte for byte on every trained file.
 text8 and questions-words.txt are not available offline; the planted corpus stands in for them."""
 import json
@@ -26,7 +42,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from w2b_testlib import GOLDEN, ROOT, ref_binary
+from w2b_testlib import GOLDEN, ROOT, ref_binary, HELDOUT
 from planted import make_planted, parse_accuracy
 
 pytestmark = pytest.mark.gpu
@@ -34,25 +50,11 @@ CLI = os.path.join(ROOT, "word2bits")
 EVAL = os.path.join(ROOT, "compute_accuracy")
 BANDS = json.load(open(os.path.join(GOLDEN, "fidelity_bands.json")))["jobs"]
 
-# Floors of the per-epoch loss tolerance (fraction of the reference's mean), by regime.  What they cover: a GPU worker
-# has a chunk of 13 rows in flight for ~10 us between load and store, dozens to hundreds of workers at once; the
-# reference's thread has ONE row open for ~0.1 us.  Updates that the reference applies one after the other are here
-# computed from the same stale row and then either lost (plain stores), averaged (hot rows) or
-# summed (atomic rows) -- none of which is the reference's sequence.  Measured in round 3 (profiles/r03_sessions/):
-FLOOR = {
-    # planted corpus, bitlevel 1: 8 workers -1.0 ... +0.1 %; 64 workers (every row updated atomically: small flat
-    # vocabulary) -1.05 ... +0.3 %
-    "planted_b1_d200": 0.015,
-    # planted corpus, 2 bits, size 400: 8 workers -0.2 ... +1.9 %; 64 workers -1.0 ... -2.9 % (without the atomic
-    # updates: +4 ... +6 %)
-    "planted_cfg2_b2_d400": 0.035,
-    # text8-sized corpus (default -sample 1e-3): 64 workers <= 0.36 %, 256 workers <= 0.9 %, 850 workers (-threads 0) <= 1 %
-    "text8size": 0.015,
-    # benchmarked regime (-sample 0: the ten most frequent words are a third of all context positions): -threads 0
-    # (1024 workers) +0.0 ... +1.0 %, 256 -2.7 ... -2.9 %, 64 -2.1 ... -2.3 %
-    "headline": 0.035,
-}
-ACC_POINTS = 5.0      # (two-bit models at 64 workers score 19.7-21.7 % where the reference scores 16.9-17.8 %)
+FLOOR = 0.015            # of the reference's mean epoch loss; every regime, every worker count, the automatic kernel
+# The sentence-resident kernel (explicit: -window-cache 1) where it was measured (profiles/r03_sessions, r04_sessions):
+# planted corpus and text8-sized corpus within 2.5 %; NOT asserted on the held-out regimes (-13 % on heldout_zipf12).
+FLOOR_RESIDENT = 0.025
+ACC_POINTS = 2.0
 
 
 def band(job, threads):
@@ -63,9 +65,9 @@ def band(job, threads):
     return L.mean(0), L.std(0, ddof=1), acc
 
 
-def loss_tolerance(job, threads):
+def loss_tolerance(job, threads, floor=FLOOR):
     mean, std, _ = band(job, threads)
-    return np.maximum(3 * std, FLOOR[job] * np.abs(mean))
+    return np.maximum(3 * std, floor * np.abs(mean))
 
 
 def train(corpus, out, threads, flags, extra=()):
@@ -89,9 +91,9 @@ def score(vec, questions):
     return parse_accuracy(got.decode())
 
 
-def check_losses(tag, job, ref_threads, losses):
+def check_losses(tag, job, ref_threads, losses, floor=FLOOR):
     mean, std, _ = band(job, ref_threads)
-    tol = loss_tolerance(job, ref_threads)
+    tol = loss_tolerance(job, ref_threads, floor)
     dev = 100 * (losses - mean) / np.abs(mean)
     print("FIDELITY %s: losses %s | reference @%d threads %s (3 sigma %s %%) | deviation %s %% (allowed %s %%)" %
           (tag, np.round(losses).tolist(), ref_threads, np.round(mean).tolist(), np.round(300 * std / np.abs(mean), 2).tolist(),
@@ -112,30 +114,31 @@ def planted(tmp_path_factory):
 @pytest.mark.parametrize("job,threads", [("planted_b1_d200", 8), ("planted_b1_d200", 64),
                                          ("planted_cfg2_b2_d400", 8), ("planted_cfg2_b2_d400", 64)])
 def test_planted_matches_reference_at_equal_thread_count(gpu, planted, job, threads):
-    """epoch losses and total accuracy of both worker kernels against the reference at the same thread count;
-    planted_cfg2_b2_d400 is BASELINE configs[2]'s shape (bitlevel 2, size 400, negative 24, iter 5) with its
-    compute-accuracy parity"""
+    """epoch losses and total accuracy against the reference at the same thread count: the automatic kernel (plain) within
+    FLOOR, the sentence-resident kernel (explicit choice) within FLOOR_RESIDENT; planted_cfg2_b2_d400 is BASELINE
+    configs[2]'s shape (bitlevel 2, size 400, negative 24, iter 5) with its compute-accuracy parity"""
     corpus, questions, d = planted
     flags = BANDS[job]["flags"]
     _, _, acc_ref = band(job, threads)
     margin = max(ACC_POINTS, 3 * float(acc_ref.std(ddof=1)))
-    for kernel, extra in (("resident", ["-window-cache", "1"]), ("plain", ["-window-cache", "0"])):
+    for kernel, extra, floor in (("auto", [], FLOOR), ("resident", ["-window-cache", "1"], FLOOR_RESIDENT)):
         out = str(d / ("%s_%s_%d.bin" % (job, kernel, threads)))
         losses, _, _ = train(corpus, out, threads, flags, extra)
         acc = score(out, questions)
         assert acc["seen"] == acc["questions"] == 7728
         print("FIDELITY %s threads=%d %s: accuracy %.2f | reference %s +- %.1f" %
               (job, threads, kernel, acc["total"], acc_ref.tolist(), margin))
-        check_losses("%s threads=%d %s" % (job, threads, kernel), job, threads, losses)
-        assert acc_ref.min() - margin <= acc["total"] <= acc_ref.max() + margin, (kernel, acc["total"], acc_ref.tolist())
+        check_losses("%s threads=%d %s" % (job, threads, kernel), job, threads, losses, floor)
+        if kernel == "auto":
+            assert acc_ref.min() - margin <= acc["total"] <= acc_ref.max() + margin, (kernel, acc["total"], acc_ref.tolist())
 
 
 def test_more_workers_than_the_corpus_supports_is_warned_about(gpu, planted):
     """512 workers on a 564 K-token corpus leaves 1 100 words per worker and epoch: alpha (re-computed per worker every
     10 000 words, ref :379-393) never moves.  The reference accepts that silently (its own 512-thread runs end 4 % off its
     8-thread ones, and diverge at bitlevel 2); `-threads 0` never picks such a count, and an explicit one is accepted with
-    a warning.  The run itself is only bounded: bitlevel 1, plain kernel, epoch losses within 2 x the planted floor of the
-    reference's 512-thread runs (measured: -1.3 % / +0.7 %)."""
+    a warning.  The run itself is only bounded: bitlevel 1, plain kernel, epoch losses within 2 x FLOOR of the
+    reference's 512-thread runs (measured in round 3: -1.3 % / +0.7 %)."""
     corpus, questions, d = planted
     flags = BANDS["planted_b1_d200"]["flags"]
     losses, _, err = train(corpus, str(d / "w512.bin"), 512, flags, ["-window-cache", "0"])
@@ -143,7 +146,7 @@ def test_more_workers_than_the_corpus_supports_is_warned_about(gpu, planted):
     mean, _, _ = band("planted_b1_d200", 512)
     dev = (losses - mean) / np.abs(mean)
     print("FIDELITY planted_b1_d200 threads=512 plain: deviation %s %%" % np.round(100 * dev, 2).tolist())
-    assert np.all(np.abs(dev) <= 2 * FLOOR["planted_b1_d200"])
+    assert np.all(np.abs(dev) <= 2 * FLOOR)
     losses8, _, err8 = train(corpus, str(d / "w8.bin"), 8, dict(flags, iter=1), [])
     assert "warning" not in err8
 
@@ -155,26 +158,27 @@ def text8size(tmp_path_factory):
     return write_zipf_text_corpus(str(d / "c.txt")), d
 
 
-@pytest.mark.parametrize("threads,ref_threads,kernels", [(64, 64, ("resident", "plain")), (256, 256, ("resident", "plain")),
+@pytest.mark.parametrize("threads,ref_threads,kernels", [(64, 64, ("auto", "resident")), (256, 256, ("auto", "resident")),
                                                          (0, 256, ("auto",))])
 def test_text8_size_matches_reference(gpu, text8size, threads, ref_threads, kernels):
     """17 M tokens, 70 K words, bitlevel 1, size 200, window 8, negative 24, 3 epochs: equal thread counts (64, 256), and
-    `-threads 0` -- as many workers as the GPU holds, 850 here -- against the most threads the host can run at once"""
+    `-threads 0` -- 340 workers here: 50 000 words per worker and epoch -- against the most threads the host can run at once"""
     corpus, d = text8size
     flags = BANDS["text8size"]["flags"]
     for kernel in kernels:
-        extra = {"resident": ["-window-cache", "1"], "plain": ["-window-cache", "0"], "auto": []}[kernel]
+        extra = {"resident": ["-window-cache", "1"], "auto": []}[kernel]
         losses, workers, _ = train(corpus, str(d / "o.bin"), threads, flags, extra)
-        check_losses("text8size threads=%d (%d workers) %s" % (threads, workers, kernel), "text8size", ref_threads, losses)
+        check_losses("text8size threads=%d (%d workers) %s" % (threads, workers, kernel), "text8size", ref_threads, losses,
+                     FLOOR if kernel == "auto" else FLOOR_RESIDENT)
 
 
 def test_text8_size_window_residency_alone_is_loss_neutral(gpu, text8size):
-    """same corpus, 128 workers, no hot-row copies: what remains of the sentence-resident kernel (LDS window, scratch
-    entries, exact-or-merge write-back) must give the plain kernel's epoch loss (measured: -58.58 M vs -58.62 M)"""
+    """same corpus, 128 workers, no hot-row copies, no lossless rows: what remains of the sentence-resident kernel (LDS window,
+    scratch entries, exact-or-merge write-back) must give the plain kernel's epoch loss (measured: -58.58 M vs -58.62 M)"""
     corpus, d = text8size
     flags = dict(BANDS["text8size"]["flags"], iter=1)
-    r, _, _ = train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "1", "-hot-rows", "0"])
-    p, _, _ = train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "0", "-hot-rows", "0"])
+    r, _, _ = train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "1", "-hot-rows", "0", "-atomic-rank-u", "-1"])
+    p, _, _ = train(corpus, str(d / "o.bin"), 128, flags, ["-window-cache", "0", "-hot-rows", "0", "-atomic-rank-u", "-1"])
     print("FIDELITY text8size threads=128 hot rows off: resident %s plain %s" % (r.tolist(), p.tolist()))
     assert np.all(np.abs(r - p) <= 0.005 * np.abs(p))
 
@@ -188,12 +192,34 @@ def headline(tmp_path_factory):
     os.remove(corpus)
 
 
-@pytest.mark.parametrize("threads,ref_threads", [(0, 256), (256, 256), (64, 64)])
+@pytest.mark.parametrize("threads,ref_threads", [(0, 256), (1024, 256), (256, 256), (64, 64)])
 def test_benchmarked_regime_matches_reference(gpu, headline, threads, ref_threads):
-    """BASELINE configs[1] -- what bench.py times: V = 400 K, size 800, window 8, negative 24, bitlevel 1, -sample 0, with
-    the defaults bench.py runs (`-threads 0`: the kernel and the hot rows the library derives from the word counts), and
-    at the reference's own thread counts."""
+    """BASELINE configs[1] -- what bench.py times: V = 400 K, size 800, window 8, negative 24, bitlevel 1, -sample 0.
+    `-threads 0` on this 22 M-token file is 440 workers (50 000 words each); 1024 is what bench.py runs on its 100 M-token
+    stream: a full device, the one case with per-XCD copies of the hottest rows (the CLI warns about the short shards; the
+    reference's band is its 256-thread one, the most the host runs at once); 256 and 64 against the same thread counts."""
     corpus, d = headline
     flags = BANDS["headline"]["flags"]
     losses, workers, _ = train(corpus, "/dev/null", threads, flags)
     check_losses("headline threads=%d (%d workers)" % (threads, workers), "headline", ref_threads, losses)
+
+
+@pytest.fixture(scope="module", params=sorted(HELDOUT))
+def heldout(request, tmp_path_factory):
+    from w2b_testlib import write_heldout_corpus
+    d = tmp_path_factory.mktemp(request.param)
+    corpus = write_heldout_corpus(str(d / "c.txt"), request.param)
+    yield request.param, corpus
+    os.remove(corpus)
+
+
+@pytest.mark.parametrize("threads,ref_threads", [(0, 256), (256, 256), (64, 64)])
+def test_held_out_regimes_match_reference(gpu, heldout, threads, ref_threads):
+    """The regimes no knob was ever swept on (w2b_testlib.HELDOUT; bands recorded once, in round 4, before the rules that
+    pass them were written): every rule that picks lossless rows / copies / the kernel from the word counts and the worker
+    count has to carry over unchanged.  Same FLOOR as everywhere."""
+    job, corpus = heldout
+    flags = BANDS[job]["flags"]
+    assert BANDS[job]["flags"] == HELDOUT[job]["flags"]
+    losses, workers, _ = train(corpus, "/dev/null", threads, flags)
+    check_losses("%s threads=%d (%d workers)" % (job, threads, workers), job, ref_threads, losses)

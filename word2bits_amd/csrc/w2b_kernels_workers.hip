@@ -36,11 +36,6 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
   if (!hot) { XH.nu = 0; XH.nv = 0; }
   int since_merge = 0, merge_cursor = (wid >> 3) * P.xhot_m;      // (workgroup b runs on XCD b % 8: take turns)
   const int W = P.window, K = P.negative;
-  // wavefront 0: the unigram-table entries of the NEXT position's first 64 negative draws, requested one position ahead
-  // (the draws depend on nothing but the LCG state, ref :455-457), so that their trip to the 400 MB table overlaps with
-  // this position's row traffic instead of standing between two positions while the other three wavefronts wait
-  int pf_t = 0;
-  unsigned long long pf_rng = ~0ull;                              // LCG state before the window draw the prefetch was made for
   for (long long it = 0; it < max_positions; ++it) {
     if (wave == 0) {
       unsigned long long rng = S->rng;
@@ -71,11 +66,6 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
         done = 1;
       } else {
         const int word = (sen_len > 0) ? s_sen[sen_pos] : 0;          // ref :424
-#ifdef W2B_NO_TABLE_PREFETCH
-        const bool pf_ok = false;
-#else
-        const bool pf_ok = (rng == pf_rng);
-#endif
         rng = rng * W2B_LCG_A + W2B_LCG_C;                            // ref :428-429
         const int b = (int)fast_mod(rng, (unsigned long long)W, P.window_magic);
         const int hi = 2 * W + 1 - b;
@@ -95,7 +85,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
             int t = 0;
             if (d <= K) {
               const unsigned long long x = lcg_jump(P, rng, d);
-              t = (d0 == 1 && pf_ok) ? pf_t : P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
+              t = P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
               if (t == 0) t = (int)(x % (unsigned long long)(P.vocab_size - 1)) + 1;
               keep = (t != word);
             }
@@ -112,16 +102,6 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
         sen_pos++;                                                    // ref :505-509
         if (sen_pos >= sen_len) sen_len = 0;
       }
-#ifndef W2B_NO_TABLE_PREFETCH
-      if (!done && K > 0) {                                           // next position's table entries (valid if its LCG state is `rng`)
-        const unsigned long long r1 = rng * W2B_LCG_A + W2B_LCG_C;
-        pf_rng = rng;
-        if (lane < K) {
-          const unsigned long long x = lcg_jump(P, r1, lane + 1);
-          pf_t = P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
-        }
-      }
-#endif
       if (lane == 0) {
         S->rng = rng; S->cursor = cursor; S->wc = wc; S->last_wc = last_wc;
         S->sen_len = sen_len; S->sen_pos = sen_pos; S->override_ = ovr; S->eof = eof;

@@ -365,6 +365,7 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
   if (in->window_refresh < 0) return fail(W2B_EINVAL, "w2b_set_tuning: window_refresh must be >= 0");
   if (in->atomic_rank_u < -1) return fail(W2B_EINVAL, "w2b_set_tuning: atomic_rank_u >= -1");
   if (in->fresh_rank_u < -1) return fail(W2B_EINVAL, "w2b_set_tuning: fresh_rank_u >= -1");
+  if (in->exchange_sat_updates < 0) return fail(W2B_EINVAL, "w2b_set_tuning: exchange_sat_updates >= 0");
   if (in->hot_weight_permille < 1 || in->hot_weight_permille > 1000)
     return fail(W2B_EINVAL, "w2b_set_tuning: hot_weight_permille must be 1..1000");
   for (int r : in->reserved) if (r != 0) return fail(W2B_EINVAL, "w2b_set_tuning: reserved fields must be zero");
@@ -762,10 +763,18 @@ static int effective_radius(const w2b_trainer *t, long long workers) {
 // 400 K-word Zipf vocabulary), none for 8 workers and none on flat distributions.  Only for 16-byte columns, coherent
 // rows, and not in the parity mode.
 static const double W2B_HOT_LOAD = 6400.0;
-// u: round 4 -- the automatic choice gives the context rows NO copies (w2b_tuning.hot_rows_u = -1 -> 0): their updates are
-// atomic adds at the master rows instead (atomic_plan_u; the reference's `u[c] += e[c]`, ref :500-502), which one row
-// takes at 37 M per second (tools/atomic_probe.hip; row 1 of the headline stream needs 19 M).  legacy_u: the load rule of
-// round 3, which the sentence-resident kernel still uses to pick its consensus rows (uavg_rank).
+// legacy_u: the load rule of round 3 whatever the number of workers, which the sentence-resident kernel still uses to pick
+// its consensus rows (uavg_rank).
+// Round 4: per-XCD copies are a FULL-DEVICE mechanism.  Measured on the benchmarked regime (profiles/r04_sessions/): with
+// up to a few hundred workers the copies cost fidelity whatever their number and merge period (64 workers: 3-5 copies -2.5 %,
+// none +0.3 %; 256 workers: 16 copies -3.8 %, none +0.9 %) and buy nothing (the rows do not queue yet); on a full device
+// (1024 workers) the picture turns: without copies the hottest rows queue at their memory lines (13.4 M words/s against
+// 28.0 M) and 113 + 113 copies with the consensus rule are within 0.1-0.4 % of the reference's epoch loss.  So the automatic
+// choice gives copies only when the launch has at least W2B_FULL_DEVICE_WG_PER_CU workgroups per CU; below that every row
+// is shared by all workers as in the reference, and the context rows are updated by lossless adds (atomic_plan_u).
+static const int W2B_FULL_DEVICE_WG_PER_CU = 3;
+static bool full_device(const w2b_trainer *t, long long workers) { return workers >= (long long)W2B_FULL_DEVICE_WG_PER_CU * t->num_cus; }
+
 static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv, bool legacy_u) {
   *nu = *nv = 0;
   const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
@@ -782,8 +791,10 @@ static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int 
     }
     return (int)(n < vmax ? n : (vmax > 0 ? vmax : 0));
   };
-  *nv = pick(t->tune.hot_rows_v, t->rate_v);
-  if (with_u) *nu = (t->tune.hot_rows_u < 0 && !legacy_u) ? 0 : pick(t->tune.hot_rows_u, t->rate_u);
+  // (legacy_u / !with_u: the sentence-resident kernel, an explicit choice, keeps the rule it was measured with)
+  const bool gated = with_u && !legacy_u && !full_device(t, workers);
+  *nv = (t->tune.hot_rows_v < 0 && gated) ? 0 : pick(t->tune.hot_rows_v, t->rate_v);
+  if (with_u) *nu = (t->tune.hot_rows_u < 0 && gated) ? 0 : pick(t->tune.hot_rows_u, t->rate_u);
 }
 
 // Rows 1..n (by count) whose updates are atomic adds at their master address (w2b_tuning.atomic_rank).  A load / modify /
@@ -839,6 +850,9 @@ static int atomic_plan_u(const w2b_trainer *t, long long workers, int atomic_ran
   const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
   if (t->cfg.exact_reduction || wide || mem_mode != 0) return atomic_rank_v;
   if (t->tune.atomic_rank >= 0) return atomic_rank_v;            // an explicit atomic_rank speaks for both tables (round-3 meaning)
+  // full device with per-XCD copies: the rows that matter are at their copies, and adds for the rows below them cost 7 % of
+  // the throughput for nothing measurable (+0.37 % against -0.09 % of the reference's loss)
+  if (full_device(t, workers) && t->tune.hot_rows_u != 0) return atomic_rank_v;
   long long n = atomic_rank_v;
   if (!t->counts.empty() && t->counts_tot_kept > 0) {
     const double st = (double)t->cfg.sample * (double)t->cfg.train_words;
@@ -902,11 +916,10 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   const long long per_xcd = workers / W2B_NXCD > 0 ? workers / W2B_NXCD : 1;
   const int most = nu > nv ? nu : nv;
   p.xhot_m = (int)((most + per_xcd - 1) / per_xcd);       // every copy of an XCD is merged about once per hot_period steps
-  // Automatic merge period (measured): with 768 and more workers a worker merges every 32 centre words
-  // (benchmarked regime at 1024 workers: +0.06 % of the reference's epoch loss and 75 % of the roofline, against +0.9 % and
-  // 71 % at 8; 768 workers: -1.4 %); with fewer workers every 8 (512 workers: -1.4 % at 8, -2.5 % at 32; 256 workers: -2.9 %
-  // at 8, -3.4 % at 32).
-  if (t->tune.hot_period <= 0) p.hot_period = workers >= 768 ? 32 : 8;
+  // Merge period: a worker merges every 32 centre words (benchmarked regime at 1024 workers: +0.06 % of the reference's epoch
+  // loss and 75 % of the roofline, against +0.9 % and 71 % at 8).  Round 3 switched to 8 below 768 workers; copies below a
+  // full device are no longer chosen automatically (xhot_plan), so the switch is gone.
+  if (t->tune.hot_period <= 0) p.hot_period = 32;     // (automatic copies exist only on a full device: the period measured there)
   if (fresh) {         // copy == entry (== 0) everywhere: the fold below adopts the master rows
     HIPCHK(hipMemsetAsync(t->xhot, 0, sizeof(float) * need, t->stream));
     t->xhot_nu = nu;
@@ -1270,6 +1283,7 @@ static void xchg_saturated_prefix(const w2b_trainer *t, long long words, int *sa
   *sat_u = *sat_v = 0;
   const long long V = t->cfg.vocab_size;
   if (t->counts.empty() || t->counts_tot <= 0 || words <= 0) return;
+  const double sat = t->tune.exchange_sat_updates > 0 ? (double)t->tune.exchange_sat_updates : W2B_SAT_UPDATES;
   auto prefix = [&](bool is_v) -> int {
     long long lo = 0, hi = V - 1;
     while (lo < hi) {
@@ -1277,7 +1291,7 @@ static void xchg_saturated_prefix(const w2b_trainer *t, long long words, int *sa
       const double c = (double)t->counts[(size_t)mid];
       const double rate = is_v ? t->cfg.negative * pow(c, 0.75) / t->counts_pw + c / t->counts_tot
                                : (t->cfg.window + 1) * c / t->counts_tot;
-      if (rate * (double)words >= W2B_SAT_UPDATES) lo = mid; else hi = mid - 1;
+      if (rate * (double)words >= sat) lo = mid; else hi = mid - 1;
     }
     return (int)lo;
   };
