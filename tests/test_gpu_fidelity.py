@@ -71,6 +71,9 @@ def loss_tolerance(job, threads, floor=FLOOR):
 
 
 def train(corpus, out, threads, flags, extra=()):
+    # (W2B_FIDELITY_EXTRA: extra command-line flags for every run -- how the builder sessions re-run these tests under a
+    # knob arm, e.g. "-atomic-rank 0"; never set by the driver)
+    extra = list(extra) + os.environ.get("W2B_FIDELITY_EXTRA", "").split()
     args = [CLI, "-train", corpus, "-output", out, "-threads", str(threads), "-min-count", "5", "-binary", "1"]
     for k, v in flags.items():
         args += ["-" + k, str(v)]
