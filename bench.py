@@ -61,10 +61,12 @@ def parse():
     ap.add_argument("--ids", choices=["zipf", "uniform"], default="zipf")
     ap.add_argument("--zipf-shift", type=int, default=0,
                     help="experiment: Zipf weights 1/(rank + N) instead of 1/rank (a Zipf stream without its N hottest words)")
-    ap.add_argument("--sync-every", type=int, default=16)
-    ap.add_argument("--sync-hot-mb", type=int, default=64,
+    ap.add_argument("--sync-every", type=int, default=1,
+                    help="N>1: steps between two full replica exchanges (1 = after every step, what ./word2bits -gpus N does: the "
+                         "interval is what costs epoch loss, tests/test_gpu_exchange.py; 16 until round 4)")
+    ap.add_argument("--sync-hot-mb", type=int, default=0,
                     help="N>1: after every step that has no full exchange, the hot tier -- at most this many MB of leading rows "
-                         "per table (w2b_sync_hot_rows; 0 = off), as ./word2bits -gpus N does")
+                         "per table (w2b_sync_hot_rows; 0 = off, the default: on one GPU it measured no gain over the full exchanges alone)")
     ap.add_argument("--sync-mode", type=int, default=2,
                     help="0 delta-sum, 1 average, 2 contributor average (what ./word2bits -gpus N uses)")
     ap.add_argument("--sync-impl", choices=["lib", "torch"], default="lib",
@@ -794,7 +796,7 @@ def main():
     result["roofline"]["algorithmic_bytes_per_launch"] = words_per_step * bpw
     # HBM bytes per launch from the counters: collected by tools/gpu_profile_session.sh with rocprofv3 --pmc (separate
     # FETCH_SIZE / WRITE_SIZE passes of this same command) and committed; quoted only for the shape they were measured on
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % args.form)
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % args.form)
     if world == 1 and os.path.exists(pmc) and args.ids == "zipf" and not args.relaxed:
         try:
             pj = json.load(open(pmc))
@@ -806,7 +808,8 @@ def main():
                 result["roofline"]["traffic_GBps"] = per_word * words_per_step / avg_launch_s / 1e9
                 result["roofline"]["traffic_frac"] = per_word * words_per_step / avg_launch_s / HBM_PEAK
                 result["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
-                                                        "passes, FETCH x2 gfx950 correction) on this command, %d centre "
+                                                        "passes; factors calibrated on known row bytes, profiles/r04_pmc_calibration.json: "
+                                                        "FETCH x2.00, WRITE x1.00 for sc1 rows) on this command, %d centre "
                                                         "words per launch there" %
                                                         (os.path.basename(pmc), pj["words_per_launch"]))
         except Exception:

@@ -31,9 +31,10 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   float alpha = 0.05f, sample = 1e-3f, reg = 0.f;
   // GPU-only
   int gpus = 1, device = 0;
-  long long sync_every = 8;            // -gpus > 1: launches between two replica exchanges
+  long long sync_every = 1;            // -gpus > 1: launches between two replica exchanges (8 until round 4: the interval is what
+                                       // costs epoch loss -- tests/test_gpu_exchange.py; keep -positions short with replicas)
   long long positions = 4096;          // sentence positions per worker per launch
-  long long sync_hot_mb = 64;          // -gpus > 1: MB of leading rows per table exchanged after EVERY launch (0 = off; w2b_sync_hot_rows)
+  long long sync_hot_mb = 0;           // -gpus > 1: MB of leading rows per table exchanged after every launch without a full exchange (w2b_sync_hot_rows; 0 = off, the default: measured no gain)
   long long table_size = W2B_UNIGRAM_TABLE_SIZE;
   int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
   int window_cache = -1;               // -1 automatic, 0 plain worker kernel, 1 sentence-resident kernel
