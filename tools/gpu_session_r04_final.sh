@@ -25,13 +25,13 @@ K=$(tail -1 $OUT/bench_default.log | python -c "import json,sys; print(json.load
 CMD="python $R/bench.py --steps 8 --warmup 2 --cpu-baseline none --also-relaxed 0 --also-legs 0 --also-shapes 0"
 echo "== (3) rocprofv3 of: $CMD   (kernel $K)"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_stats -o $RND -- $CMD > $R/$OUT/rocprof_stats.log 2>&1)
-tail -1 $OUT/rocprof_stats.log > $OUT/bench_profiled.json
+grep "^{" $OUT/rocprof_stats.log | tail -1 > $OUT/bench_profiled.json
 head -4 $OUT/prof_stats/${RND}_kernel_stats.csv | cut -c1-250
 for c in FETCH_SIZE WRITE_SIZE; do
 (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $R/$OUT/prof_$c -o $RND -- $CMD > $R/$OUT/rocprof_$c.log 2>&1)
 done
 (cd /tmp && timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/$OUT/prof_l2 -o $RND -- $CMD > $R/$OUT/rocprof_l2.log 2>&1)
-tail -1 $OUT/rocprof_FETCH_SIZE.log > $OUT/bench_pmc.json
+grep "^{" $OUT/rocprof_FETCH_SIZE.log | tail -1 > $OUT/bench_pmc.json
 python tools/pmc_summary.py $OUT/prof_FETCH_SIZE/${RND}_counter_collection.csv $OUT/prof_WRITE_SIZE/${RND}_counter_collection.csv $OUT/prof_l2/${RND}_counter_collection.csv $OUT/pmc_worker.json $K $OUT/bench_pmc.json | cut -c1-900
 echo "== (4) cache-resident bound (row_probe small)"
 timeout 120 tools/row_probe small 2>&1 | tee $OUT/row_probe_small.txt
