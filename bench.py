@@ -106,7 +106,6 @@ def parse():
     ap.add_argument("--atomic-cap", type=int, default=-1, help="w2b_tuning.atomic_cap (-1 = library default)")
     ap.add_argument("--hot-weight", type=int, default=0, help="w2b_tuning.hot_weight_permille (0 = library default)")
     ap.add_argument("--atomic-rank-u", type=int, default=0, help="w2b_tuning.atomic_rank_u (0 = as atomic_rank, -1 = none)")
-    ap.add_argument("--hot-mode", type=int, default=0, help="w2b_tuning.hot_mode (0 library's choice, 1 consensus, 2 cache)")
     ap.add_argument("--fresh-rank-u", type=int, default=0, help="w2b_tuning.fresh_rank_u (0 = library default, -1 = none)")
     ap.add_argument("--window-refresh", type=int, default=-1, help="w2b_tuning.window_refresh (-1 = library default)")
     ap.add_argument("--eval-questions", type=int, default=19544, help="--form eval: questions (questions-words.txt)")
@@ -581,8 +580,6 @@ def main():
         tune["atomic_rank_u"] = args.atomic_rank_u
     if args.fresh_rank_u != 0:
         tune["fresh_rank_u"] = args.fresh_rank_u
-    if args.hot_mode != 0:
-        tune["hot_mode"] = args.hot_mode
 
     def make_trainer(relaxed, loss=bool(args.loss), bitlevel=args.bitlevel):
         tr = w2b.Trainer(V, D, W, K, bitlevel, num_threads=nw_local,

@@ -146,10 +146,7 @@ typedef struct w2b_tuning {
   int32_t exchange_sat_updates;  /* replica exchange, mode 2 / hot tier: a row counts as SATURATED (moves by the mean of its
                                   * contributors' deltas instead of their sum) when every replica has updated it at least this
                                   * often since the last exchange; 0 = the library's default */
-  int32_t hot_mode;        /* what the per-XCD copies of the hottest rows are (plain worker / tuple kernels): 1 = CONSENSUS (rounds 3-4:
-                            * workers update the copies, merges average copy and master); 2 = CACHE (round 4: every update goes to the
-                            * master row -- a lossless add for u, a store for v -- and to the copy, merges refresh the copy from the
-                            * master); 0 = the library decides */
+  int32_t reserved[1];
 } w2b_tuning;
 int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out);
 int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in);

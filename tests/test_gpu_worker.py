@@ -256,7 +256,6 @@ def test_epoch_poll_one_launch_behind(gpu, window_cache):
     dict(fresh_rank_u=149),                                   # context rows re-read before their update
     dict(hot_rows_v=8, hot_rows_u=0, atomic_rank_u=149, hot_period=2),     # copies of hot target rows + lossless context rows
     dict(hot_rows_v=8, hot_rows_u=4, fresh_rank_u=60, atomic_rank=60, atomic_rank_u=60, hot_period=4),
-    dict(hot_mode=2, hot_rows_v=8, hot_rows_u=8, hot_period=2),            # copies as read caches: adds / stores written through to the masters
 ])
 @pytest.mark.parametrize("D,bitlevel,loss", [(800, 1, True), (200, 2, False), (36, 0, True)])
 def test_single_worker_is_bit_identical_under_every_round4_knob(gpu, knobs, D, bitlevel, loss):

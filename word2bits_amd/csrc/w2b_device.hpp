@@ -434,27 +434,9 @@ __device__ __forceinline__ void xhot_merge_row(float *tab, float *copy, float *e
   if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one merge event of a workgroup of the plain kernels: P.xhot_m rows of each table, rotating through the sets
-// CACHE mode (W2bParams::xhot_cache, round 4): the copies are READ caches.  Every update of a hot row goes to its master
-// row -- a lossless atomic add for u (the reference's `u[c] += e[c]`), an agent-scope store for v (the reference's racy shared
-// row) -- and to this XCD's copy so that the XCD sees its own progress at once; what the other XCDs did arrives when a
-// worker REFRESHES the copy from the master (no merge rule, no entry values, no lock: a refresh that races with a
-// worker's store to the copy loses nothing that matters, the master has every update).
-template <int MM>
-__device__ __forceinline__ void xhot_refresh_row(const float *tab, float *copy, int k, int n, int dim, int col0, bool active, unsigned tab_bytes) {
-  if (active) xhot_st(copy, k, n, dim, col0, load_col<4, MM, -1>(tab, k + 1, dim, col0, tab_bytes));
-}
 template <int MM>
 __device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot &X, int &cursor, int col0, bool active) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (P.xhot_cache) {
-    for (int j = 0; j < P.xhot_m; j++) {
-      const int i = cursor + j;
-      if (X.nu > 0 && j < X.nu) xhot_refresh_row<MM>(P.u, X.cu, i % X.nu, X.nu, P.dim, col0, active, P.tab_bytes);
-      if (X.nv > 0 && j < X.nv) xhot_refresh_row<MM>(P.v, X.cv, i % X.nv, X.nv, P.dim, col0, active, P.tab_bytes);
-    }
-    cursor += P.xhot_m;
-    return;
-  }
   for (int j = 0; j < P.xhot_m; j++) {
     const int i = cursor + j;
     if (X.nu > 0 && j < X.nu)
@@ -495,7 +477,6 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
   };
   chunk_rows();
   const int nhu = (VEC == 4) ? X.nu : 0, nhv = (VEC == 4) ? X.nv : 0;
-  const bool xcache = (VEC == 4) && P.xhot_cache != 0;
   // row accesses: a hot row at this XCD's copy (VEC == 4 only), every other row at its master address
   auto ld_u = [&](int row) -> Col<VEC> {
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) return xhot_ld(X.cu, row - 1, nhu, dim, col0); }
@@ -514,13 +495,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
     return load_col<VEC, MM>(P.v, row, dim, col0, P.tab_bytes);
   };
   auto up_v = [&](int row, const Col<VEC> &val, const Col<VEC> &d) {
-    if constexpr (VEC == 4) {
-      if ((unsigned)(row - 1) < (unsigned)nhv) {
-        xhot_st(X.cv, row - 1, nhv, dim, col0, val);
-        if (xcache) store_col<VEC, MM>(P.v, row, dim, col0, val, P.tab_bytes);     // cache mode: write through to the shared row
-        return;
-      }
-    }
+    if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) { xhot_st(X.cv, row - 1, nhv, dim, col0, val); return; } }
     if (row <= atomic_rank) add_col<VEC>(P.v, row, dim, col0, d, P.tab_bytes);
     else store_col<VEC, MM>(P.v, row, dim, col0, val, P.tab_bytes);
   };
@@ -707,9 +682,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
           const int m = L.umult[j0 + jj];
           if (m > 0) {
             const int crow = __builtin_amdgcn_readfirstlane(L.ctx[j0 + jj]);
-            const bool is_hot = (unsigned)(crow - 1) < (unsigned)nhu;
-            // a hot row in cache mode: the add goes to the master row, the new value to this XCD's copy as well
-            const bool by_add = is_hot ? xcache : crow <= atomic_rank_u;
+            const bool by_add = crow <= atomic_rank_u && !((unsigned)(crow - 1) < (unsigned)nhu);
             Col<VEC> dl;
 #pragma unroll
             for (int e = 0; e < VEC; e++) dl.e[e] = 0.f;
@@ -723,7 +696,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
               }
               if (by_add) add_col_contig<>(P.u, crow, dim, dl, P.tab_bytes);   // (every one of the m updates is an add of its own)
             }
-            if ((!by_add || is_hot) && active) up_u(crow, r[jj], dl);          // (hot: the copy; others: the row itself)
+            if (!by_add && active) up_u(crow, r[jj], dl);
           }
         }
       } else {

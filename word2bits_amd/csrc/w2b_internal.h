@@ -70,8 +70,6 @@ struct W2bParams {
   int xhot_m;                     // hot rows of each table that one merge event brings up to date
   int uavg_rank;                  // sentence-resident kernel: context rows 1..uavg_rank are merged by consensus and refreshed
   int win_refresh;                // ... at the latest after this many steps in a worker's window (0 = never)
-  int xhot_cache;                 // 1: the copies are read caches -- updates go to the master rows (u: atomic adds, v: stores) AND the copy,
-                                  // merges are refreshes from the master (w2b_device.hpp xhot_merge_event)
   float xhot_w;                   // weight of one XCD's copy in the consensus of a merge (1 / W2B_NXCD by default)
   float *wide_scratch;            // rows too long for one thread per column: [workgroups][2][dim] (process_word_wide)
   int wide;                       // 1: such rows (1024 threads, every thread owns several columns)

@@ -167,16 +167,6 @@ __global__ void k_xhot_fold(const W2bParams P) {
   if (threadIdx.x < W2B_MAXW)                      // (no merge is in progress between launches)
     for (int x = 0; x < W2B_NXCD; x++)
       reinterpret_cast<unsigned *>(P.xhot + x * per_xcd + 2ll * (nu + nv) * dim)[(is_u ? k : nu + k) * W2B_MAXW + threadIdx.x] = 0u;
-  if (P.xhot_cache) {                              // read caches: every copy (and entry) <- master; the master has every update
-    for (int c = threadIdx.x; c < dim / 4; c += blockDim.x) {
-      const w2b_f4 m = xchg_ld_sc1(rm, c);
-      for (int x = 0; x < W2B_NXCD; x++) {
-        reinterpret_cast<w2b_f4 *>(P.xhot + x * per_xcd + copy_off)[c] = m;
-        reinterpret_cast<w2b_f4 *>(P.xhot + x * per_xcd + entry_off)[c] = m;
-      }
-    }
-    return;
-  }
   for (int c = threadIdx.x; c < dim / 4; c += blockDim.x) {
     w2b_f4 m = xchg_ld_sc1(rm, c);
     for (int x = 0; x < W2B_NXCD; x++) {

@@ -99,8 +99,7 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
 #define W2B_LAUNCH_T(VEC, LOSS) \
     do { if (threads <= 256) W2B_LAUNCH_T2(VEC, LOSS, 256); else W2B_LAUNCH_T2(VEC, LOSS, 1024); } while (0)
     if constexpr (MM == 0) {          // rows updated with atomic adds: the ATOM instantiations (16-byte columns, <= 256 threads)
-      // (cache mode of the per-XCD copies: the hot context rows' updates are atomic adds at their master rows)
-      const int atom = p.atomic_rank > 0 ? 2 : ((p.atomic_rank_u > 0 || (p.xhot_cache && p.xhot && p.xhot_u > 0)) ? 1 : 0);
+      const int atom = p.atomic_rank > 0 ? 2 : (p.atomic_rank_u > 0 ? 1 : 0);
       if (atom && vec == 4 && threads <= 256) {
 #define W2B_LAUNCH_TA(LOSS, ATOM)                                                                            \
         do {                                                                                                 \

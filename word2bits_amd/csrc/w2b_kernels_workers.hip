@@ -172,8 +172,7 @@ hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool 
     do { if (threads <= 256) hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 256, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); \
          else hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 1024, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); } while (0)
     if constexpr (MM == 0) {          // rows updated with atomic adds (w2b_tuning.atomic_rank*): the ATOM instantiations (16-byte columns)
-      // (cache mode of the per-XCD copies: the hot context rows' updates are atomic adds at their master rows)
-      const int atom = p.atomic_rank > 0 ? 2 : ((p.atomic_rank_u > 0 || (p.xhot_cache && p.xhot && p.xhot_u > 0)) ? 1 : 0);
+      const int atom = p.atomic_rank > 0 ? 2 : (p.atomic_rank_u > 0 ? 1 : 0);
       if (atom && vec == 4 && threads <= 256) {
 #define W2B_LAUNCH_A(LOSS, ATOM) hipLaunchKernelGGL((k_train_workers<QM, 4, LOSS, 256, 0, ATOM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions)
         if (atom == 2) { if (loss) W2B_LAUNCH_A(true, 2); else W2B_LAUNCH_A(false, 2); }

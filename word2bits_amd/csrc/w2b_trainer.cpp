@@ -222,7 +222,6 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.xhot_u = p.xhot_v = 0;
   p.xhot_m = 1;
   p.xhot_w = (float)t->tune.hot_weight_permille / 1000.f;
-  p.xhot_cache = 0;                    // set by xhot_prepare()
   p.uavg_rank = 0;
   p.win_refresh = t->tune.window_refresh;
   p.atomic_rank = 0;
@@ -369,7 +368,7 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
   if (in->exchange_sat_updates < 0) return fail(W2B_EINVAL, "w2b_set_tuning: exchange_sat_updates >= 0");
   if (in->hot_weight_permille < 1 || in->hot_weight_permille > 1000)
     return fail(W2B_EINVAL, "w2b_set_tuning: hot_weight_permille must be 1..1000");
-  if (in->hot_mode < 0 || in->hot_mode > 2) return fail(W2B_EINVAL, "w2b_set_tuning: hot_mode must be 0, 1 or 2");
+  for (int r : in->reserved) if (r != 0) return fail(W2B_EINVAL, "w2b_set_tuning: reserved fields must be zero");
   t->tune = *in;
   return W2B_OK;
 }
@@ -713,7 +712,6 @@ extern "C" int w2b_epoch_begin(w2b_trainer *t) {
   return W2B_OK;
 }
 
-static const double W2B_PLAIN_CTX_SHARE = 0.2;     // share of the context positions held by hot rows above which the plain kernel runs
 static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv, bool legacy_u);
 
 // Which worker kernel runs: plain_worker_kernel 0 = automatic (sentence-resident kernel for coherent rows when
@@ -776,13 +774,6 @@ static const double W2B_HOT_LOAD = 6400.0;
 static const int W2B_FULL_DEVICE_WG_PER_CU = 3;
 static bool full_device(const w2b_trainer *t, long long workers) { return workers >= (long long)W2B_FULL_DEVICE_WG_PER_CU * t->num_cus; }
 
-// hot_mode 2 (cache): possible where the ATOM instantiations exist (16-byte columns, <= 256 threads per workgroup)
-static bool cache_mode(const w2b_trainer *t) {
-  int vec = 0, wide = 0;
-  const int threads = w2b_block_threads(t->cfg.layer1_size, &vec, &wide);
-  return t->tune.hot_mode == 2 && vec == 4 && !wide && threads <= 256;
-}
-
 static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv, bool legacy_u) {
   *nu = *nv = 0;
   const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
@@ -800,8 +791,7 @@ static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int 
     return (int)(n < vmax ? n : (vmax > 0 ? vmax : 0));
   };
   // (legacy_u / !with_u: the sentence-resident kernel, an explicit choice, keeps the rule it was measured with)
-  // (cache mode: the copies do not change what an update does to the master rows, so they are not gated)
-  const bool gated = with_u && !legacy_u && !full_device(t, workers) && !cache_mode(t);
+  const bool gated = with_u && !legacy_u && !full_device(t, workers);
   *nv = (t->tune.hot_rows_v < 0 && gated) ? 0 : pick(t->tune.hot_rows_v, t->rate_v);
   if (with_u) *nu = (t->tune.hot_rows_u < 0 && gated) ? 0 : pick(t->tune.hot_rows_u, t->rate_u);
 }
@@ -861,7 +851,7 @@ static int atomic_plan_u(const w2b_trainer *t, long long workers, int atomic_ran
   if (t->tune.atomic_rank >= 0) return atomic_rank_v;            // an explicit atomic_rank speaks for both tables (round-3 meaning)
   // full device with per-XCD copies: the rows that matter are at their copies, and adds for the rows below them cost 7 % of
   // the throughput for nothing measurable (+0.37 % against -0.09 % of the reference's loss)
-  if (full_device(t, workers) && t->tune.hot_rows_u != 0 && !cache_mode(t)) return atomic_rank_v;
+  if (full_device(t, workers) && t->tune.hot_rows_u != 0) return atomic_rank_v;
   long long n = atomic_rank_v;
   if (!t->counts.empty() && t->counts_tot_kept > 0) {
     const double st = (double)t->cfg.sample * (double)t->cfg.train_words;
@@ -904,7 +894,6 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   p.atomic_rank = atomic_plan(t, workers);
   p.atomic_rank_u = with_u ? atomic_plan_u(t, workers, p.atomic_rank) : 0;   // (the sentence-resident kernel keeps its context rows in LDS)
   p.fresh_rank_u = t->tune.fresh_rank_u > 0 ? t->tune.fresh_rank_u : 0;
-  p.xhot_cache = (with_u && cache_mode(t)) ? 1 : 0;
   if (!with_u) {          // sentence-resident kernel: its context rows live in LDS; the most frequent ones (the rows that
     int un = 0, vn = 0;   // would be hot rows of u) are merged by consensus and refreshed (w2b_kernels_resident.hip)
     xhot_plan(t, workers, true, &un, &vn, true);

@@ -49,7 +49,6 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int hot_weight = 0;                  // -hot-weight N: w2b_tuning.hot_weight_permille (0 = default)
   int atomic_cap = -1;                 // -atomic-cap N: most rows the automatic choice takes
   int atomic_rank_u = 0;               // -atomic-rank-u N: w2b_tuning.atomic_rank_u (0 = as -atomic-rank, -1 = none)
-  int hot_mode = 0;                    // -hot-mode N: w2b_tuning.hot_mode (0 library's choice, 1 consensus copies, 2 copies as read caches)
   int fresh_rank_u = 0;                // -fresh-rank-u N: w2b_tuning.fresh_rank_u (0 = the library decides, -1 = none)
   std::string packed_file;             // -packed FILE: also write the final vectors bit-packed (-bitlevel 1 / 2; word2bits_corpus.h)
   int row_desc = 0;                    // -row-desc 1: the row addressing of tables >= 2 GiB on any table (w2b_tuning.force_row_desc)
@@ -199,7 +198,6 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-atomic-cap", argc, argv)) > 0) o.atomic_cap = atoi(argv[i + 1]);
   if ((i = arg_pos("-atomic-rank-u", argc, argv)) > 0) o.atomic_rank_u = atoi(argv[i + 1]);
   if ((i = arg_pos("-fresh-rank-u", argc, argv)) > 0) o.fresh_rank_u = atoi(argv[i + 1]);
-  if ((i = arg_pos("-hot-mode", argc, argv)) > 0) o.hot_mode = atoi(argv[i + 1]);
   if ((i = arg_pos("-hot-weight", argc, argv)) > 0) o.hot_weight = atoi(argv[i + 1]);
   if ((i = arg_pos("-window-refresh", argc, argv)) > 0) o.window_refresh = atoi(argv[i + 1]);
 
@@ -302,7 +300,7 @@ int main(int argc, char **argv) {
     cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
-    if (o.hot_rows >= 0 || o.hot_rows_u >= 0 || o.hot_rows_v >= 0 || o.hot_cap >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0 || o.atomic_rank_u != 0 || o.fresh_rank_u != 0 || o.hot_mode != 0) {
+    if (o.hot_rows >= 0 || o.hot_rows_u >= 0 || o.hot_rows_v >= 0 || o.hot_cap >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0 || o.atomic_rank_u != 0 || o.fresh_rank_u != 0) {
       w2b_tuning tn;
       CK(w2b_get_tuning(a->r->t, &tn));
       if (o.hot_rows >= 0) tn.hot_rows_v = tn.hot_rows_u = o.hot_rows;
@@ -317,7 +315,6 @@ int main(int argc, char **argv) {
       if (o.window_refresh >= 0) tn.window_refresh = o.window_refresh;
       if (o.atomic_rank_u != 0) tn.atomic_rank_u = o.atomic_rank_u;
       if (o.fresh_rank_u != 0) tn.fresh_rank_u = o.fresh_rank_u;
-      if (o.hot_mode != 0) tn.hot_mode = o.hot_mode;
       CK(w2b_set_tuning(a->r->t, &tn));
     }
     CK(w2b_init_net(a->r->t));                              // ref :528
