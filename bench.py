@@ -19,10 +19,17 @@ the replicas are combined every --sync-every steps by an RCCL all-reduce of [u||
 default 2: contributor average), inside the timed region.  `--gpus N` launched without a rendezvous
 starts the N ranks itself (torch.distributed.run); with a rendezvous of another size it exits 2.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     -- algorithmic HBM bytes per launch / hipEvent-measured launch duration vs 8 TB/s
-  cpu_baseline -- the reference CPU program (oracle/_ref/word2bits_stock, built from the unmodified
-                  reference sources) timed on this host on a bounded sample of the same shape
+The headline runs WITH the loss bookkeeping (--loss 1): the instantiation ./word2bits runs (it prints "Epoch Loss").
+
+Prints ONE JSON line on rank 0 (contract in the task description) with extra objects:
+  roofline     -- algorithmic HBM bytes per launch / hipEvent-measured launch duration vs 8 TB/s, min / median / max per
+                  launch, and the HBM bytes of the calibrated rocprofv3 counters (profiles/r04_pmc_worker.json)
+  cpu_baseline -- the reference CPU program (oracle/_ref/word2bits_stock, built from the unmodified reference sources)
+                  on all host threads, training phase of a whole epoch over a bounded corpus of the same shape;
+                  cpu_baseline_1thread (the same with -threads 1, a 20 s sample), cpu_baseline_configs0 (BASELINE
+                  configs[0]: size 200, -threads 1)
+  legs         -- without_loss_bookkeeping, bitlevel2, relaxed_coherence, other_shapes (tuples, configs[4] shape, size 200,
+                  size 400: automatic kernel and the explicit sentence-resident one), e2e (quoted from profiles/)
 """
 import argparse
 import json

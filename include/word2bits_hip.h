@@ -112,15 +112,15 @@ void w2b_trainer_destroy(w2b_trainer *t);
  * Hot rows: with coherent rows the few most frequent rows of u (context words) and v (targets) queue at their memory
  * lines.  Rows 1..hot_rows_u / 1..hot_rows_v (the vocabulary is sorted by count) therefore get one copy per XCD, shared
  * by all workers of the XCD through its L2, and every hot_period centre words a worker brings a few copies and their
- * master rows together (a running average over the eight XCDs).  -1 = automatic: as many rows as reach a load threshold computed from
- * the word counts of w2b_set_vocab_counts and the number of workers (0 on flat distributions and for few workers), at
+ * master rows together (a running average over the eight XCDs).  -1 = automatic: NONE unless the launch fills
+ * the device (>= 3 workgroups per CU: below that copies cost fidelity and buy nothing, round 4), then as many rows as reach a load
+ * threshold computed from the word counts of w2b_set_vocab_counts and the number of workers (0 on flat distributions), at
  * most hot_cap.  0 = every access goes to the master rows.  A single worker is bit-identical with and without copies. */
 typedef struct w2b_tuning {
   int32_t struct_size;     /* sizeof(w2b_tuning) */
   int32_t hot_rows_v;      /* -1 automatic (default), else 0..128 leading rows of v */
   int32_t hot_rows_u;      /* same for u (plain worker kernel and tuple kernel; the sentence-resident kernel keeps context rows in LDS) */
-  int32_t hot_period;      /* centre words between two merge events of a worker; a power of two; 0 (default) = automatic: 32 with
-                            * 768 and more workers, else 8 */
+  int32_t hot_period;      /* centre words between two merge events of a worker; a power of two; 0 (default) = automatic: 32 */
   int32_t hot_cap;         /* most rows the automatic choice takes; default 128 */
   int32_t force_row_desc;  /* 1: address rows through per-row buffer descriptors (the form tables >= 2 GiB use) on any table */
   int32_t grid_per_cu;     /* tuple form: workgroups per CU (0 = occupancy query) */

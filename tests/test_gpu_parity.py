@@ -348,3 +348,35 @@ def test_tuple_hot_rows_hogwild_tracks_plain(gpu, monkeypatch):
           (ls, lp, lh, np.abs(uh - up).mean(), np.abs(up).mean()))
     assert abs(lh - lp) <= 0.06 * abs(lp)
     assert np.isfinite(uh).all() and np.isfinite(vh).all()
+
+
+def test_copies_only_on_a_full_device_and_lossless_context_rows_below_it(gpu):
+    """Round-4 policy, read back through w2b_worker_kernel_info on a Zipf vocabulary: the automatic
+    kernel is the plain one; a launch with fewer than 3 workgroups per CU has NO per-XCD copies (every row is shared by all
+    workers as in the reference); a full device has them; explicit numbers win either way."""
+    import torch
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    V, D = 50_000, 800
+    cn = np.maximum((2.0e7 / np.arange(1, V + 1)).astype(np.int64), 5)
+    cn[0] = 1000
+    tw = int(cn.sum())
+    for workers, want_copies in ((64, False), (2 * ncu, False), (3 * ncu, True), (4 * ncu, True)):
+        t = w2b.Trainer(V, D, 8, 24, 1, num_threads=workers, sample=0.0, train_words=tw, compute_loss=True)
+        t.set_vocab_counts(cn, 0)
+        resident, _, colb, per_cu, hot = t.worker_kernel_info()
+        assert not resident and colb == 16 and per_cu == 4
+        assert (hot > 0) == want_copies, (workers, hot)
+        t.close()
+    t = w2b.Trainer(V, D, 8, 24, 1, num_threads=64, sample=0.0, train_words=tw, hot_rows_v=5, hot_rows_u=0)
+    t.set_vocab_counts(cn, 0)
+    assert t.worker_kernel_info()[4] == 5
+    t.close()
+    t = w2b.Trainer(V, D, 8, 24, 1, num_threads=4 * ncu, sample=0.0, train_words=tw, hot_rows_v=0, hot_rows_u=0)
+    t.set_vocab_counts(cn, 0)
+    assert t.worker_kernel_info()[4] == 0
+    t.close()
+    # -threads 0: never fewer than 50 000 words per worker and epoch
+    p = w2b.Trainer(V, D, 8, 24, 1, num_threads=1, sample=0.0, train_words=10_000_000)
+    p.set_vocab_counts(cn, 0)
+    assert p.suggested_threads() == 10_000_000 // 50_000
+    p.close()
