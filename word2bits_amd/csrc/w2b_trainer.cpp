@@ -1337,7 +1337,10 @@ static int xchg_begin(w2b_trainer *t, int hot_u, int hot_v) {
   t->x_ev.push_back(a);
   t->x_ev.push_back(b);
   t->x_open = true;
-  HIPCHK(hipEventRecord(a, t->xs[0]));
+  {
+    const hipError_t e = hipEventRecord(a, t->xs[0]);
+    if (e != hipSuccess) { xchg_abort(t); return fail(W2B_EHIP, std::string("replica exchange begin: ") + hipGetErrorString(e)); }
+  }
   t->x_ranges.clear();
   t->x_hot = hot_u >= 0;
   const long long TE = t->table_elems, D = t->cfg.layer1_size;
@@ -1371,7 +1374,9 @@ static int xchg_apply(w2b_trainer *t, long long c, float scale) {
 static int xchg_touched(w2b_trainer *t, hipStream_t s) {
   const long long V = t->cfg.vocab_size, D = t->cfg.layer1_size;
   if (!t->x_hot) return w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, 2 * V, (int)D, s) == hipSuccess ? W2B_OK : fail(W2B_EHIP, "k_xchg_touched");
-  hipError_t e = w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, t->x_hot_u + 1, (int)D, s);
+  // (the host sums the whole count buffer over the replicas: the entries outside the tier must not carry old sums along)
+  hipError_t e = hipMemsetAsync(t->xcnt, 0, sizeof(float) * 2 * V, s);
+  if (e == hipSuccess) e = w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, t->x_hot_u + 1, (int)D, s);
   if (e == hipSuccess) e = w2b_launch_xchg_touched(t->uv + t->table_elems, t->base + t->table_elems, t->xcnt + V, t->x_hot_v + 1, (int)D, s);
   return e == hipSuccess ? W2B_OK : fail(W2B_EHIP, "k_xchg_touched");
 }
