@@ -398,14 +398,16 @@ def other_shapes():
     so that the driver's line carries them: value, roofline fraction (algorithmic bytes of THAT shape), kernel, workload"""
     legs = {
         "tuples": ["--form", "tuples"],
-        "cfg5_b1": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "1"],
-        "cfg5_b0": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "0"],
+        # (configs[4] is a Wikipedia-scale stream sharded over 8 GPUs: a full device per GPU, which -threads 0 gives from
+        # 52 M tokens on -- 60 M here; the text8-shaped legs below keep a stream that leaves the device partly filled)
+        "cfg5_b1": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "1", "--tokens", "60000000"],
+        "cfg5_b0": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "0", "--tokens", "60000000"],
         "d200": ["--vocab", "60238", "--dim", "200"],
         "d400_b2": ["--vocab", "60238", "--dim", "400", "--bitlevel", "2"],
         # the sentence-resident kernel (context window rows stay in LDS): the faster kernel at these shapes, an explicit
         # choice since round 4 (./word2bits -window-cache 1) because it keeps context rows private for up to 2 x window + 1
         # positions and is up to 13 % off the reference's epoch loss on a held-out regime (DESIGN.md section 6)
-        "cfg5_b1_resident": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "1", "--window-cache", "1"],
+        "cfg5_b1_resident": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "1", "--window-cache", "1", "--tokens", "60000000"],
         "d200_resident": ["--vocab", "60238", "--dim", "200", "--window-cache", "1"],
         "d400_b2_resident": ["--vocab", "60238", "--dim", "400", "--bitlevel", "2", "--window-cache", "1"],
     }
