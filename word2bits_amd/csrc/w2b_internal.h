@@ -59,8 +59,6 @@ struct W2bParams {
   unsigned long long table_magic, window_magic;   // floor(2^64 / table_size), floor(2^64 / window)
   int dim, window, negative, bitlevel, num_threads;
   int total_threads;              // workers across all replicas (quota ref :414, alpha extrapolation)
-  long long alpha_period;         // a worker publishes its word count and re-computes alpha after MORE than this many of its own words:
-                                  // 10000 (ref :379) up to 256 workers in total; beyond that 10000 * 256 / workers (w2b_trainer.cpp)
   int mem_mode;                   // 0 coherent (sc1 row accesses), 1 relaxed (plain cached accesses)
   float *entry;                   // sentence-resident kernel: scratch rows [num_threads][2][slots][dim] (see w2b_kernels_resident.hip)
   // XCD-shared copies of the hottest rows (w2b_device.hpp "XHot"): [W2B_NXCD][copies of u rows 1..xhot_u | copies of v rows

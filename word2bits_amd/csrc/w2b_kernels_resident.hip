@@ -407,7 +407,7 @@ k_train_resident(const W2bParams P, const long long max_positions, const int R, 
       int p = 0, b = 0, word = 0;
       bool train = false;
       if (!last) {
-        if (wc - last_wc > P.alpha_period) {                                    // ref :379-393
+        if (wc - last_wc > 10000) {                                    // ref :379-393
           if (lane == 0) {
             const unsigned long long d = (unsigned long long)(wc - last_wc);
             const unsigned long long wca = atomicAdd(&P.shared->word_count_actual, d) + d;

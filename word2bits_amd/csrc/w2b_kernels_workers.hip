@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
       int sen_len = S->sen_len, sen_pos = S->sen_pos, ovr = S->override_, eof = S->eof;
       int done = 0, cw = 0, nt = 0;
       float alpha = 0.f;
-      if (wc - last_wc > P.alpha_period) {                                    // ref :379-393
+      if (wc - last_wc > 10000) {                                    // ref :379-393
         if (lane == 0) {
           const unsigned long long d = (unsigned long long)(wc - last_wc);
           const unsigned long long wca = atomicAdd(&P.shared->word_count_actual, d) + d;

@@ -211,14 +211,6 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.bitlevel = t->cfg.bitlevel;
   p.num_threads = t->cfg.num_threads;
   p.total_threads = t->cfg.total_threads > 0 ? t->cfg.total_threads : t->cfg.num_threads;
-  // The reference's thread adds its words to the shared count -- and re-computes alpha -- only after more than 10000 of them
-  // (ref :379-393), so the shared count lags by up to threads x 10000 words.  That lag is part of what a run at N threads IS:
-  // up to the 256 threads the reference bands come from it is reproduced exactly (and bit for bit at one worker).  A GPU
-  // runs four to eight times as many workers; with the same per-worker period the count would lag by a third of a small
-  // corpus's epoch (text8-sized corpus, 850 workers: later epochs +2 % whatever the row-update scheme, round 4).  Beyond 256
-  // workers the period shrinks so that the total lag stays that of a 256-thread run.
-  p.alpha_period = p.total_threads <= 256 ? 10000 : (10000ll * 256) / p.total_threads;
-  if (p.alpha_period < 100) p.alpha_period = 100;
   p.mem_mode = t->cfg.relaxed_coherence;   // 0 coherent (sc1), 1 relaxed (plain); >1 experimental builds only
   if (t->tune.mem_mode >= 0) p.mem_mode = t->tune.mem_mode;
   p.exact = t->cfg.exact_reduction != 0;
