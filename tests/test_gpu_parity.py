@@ -380,3 +380,12 @@ def test_copies_only_on_a_full_device_and_lossless_context_rows_below_it(gpu):
     p.set_vocab_counts(cn, 0)
     assert p.suggested_threads() == 10_000_000 // 50_000
     p.close()
+    # ... and between the reference's scale and a full device (here: 600 by the word count) it stays at 256 workers
+    p = w2b.Trainer(V, D, 8, 24, 1, num_threads=1, sample=0.0, train_words=30_000_000)
+    p.set_vocab_counts(cn, 0)
+    assert p.suggested_threads() == 256
+    p.close()
+    p = w2b.Trainer(V, D, 8, 24, 1, num_threads=1, sample=0.0, train_words=100_000_000)
+    p.set_vocab_counts(cn, 0)
+    assert p.suggested_threads() == 4 * ncu
+    p.close()

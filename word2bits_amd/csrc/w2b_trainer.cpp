@@ -953,6 +953,10 @@ extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
     const long long cap = t->cfg.train_words / (W2B_WORDS_PER_WORKER_MIN * (total > 0 ? total : 1));
     if (n > cap) n = cap > 1 ? cap : 1;
   }
+  // Plain kernel, not enough words for a full device: at most 256 workers.  Between the reference's own scale (its bands
+  // end at the 256 hardware threads of the host) and a full device the shared-row mode gains little speed (benchmark
+  // stream: 10.5 M words/s at 256 workers, 13.5 M at 512) and its epoch loss drifts (+0.8 % at 256, +1.3 ... +1.5 % at 440).
+  if (radius < 0 && n < (long long)W2B_FULL_DEVICE_WG_PER_CU * t->num_cus && n > 256) n = 256;
   *out = (int32_t)n;
   return W2B_OK;
 }
