@@ -70,8 +70,9 @@ typedef struct w2b_config {
   /* form (i) has two kernels.  Sentence-resident: the fp32 rows of the sliding context window stay in LDS
    * while a worker walks a sentence (a row is read once when it enters the window and merged back once
    * when it leaves).  Plain: every context row of every position is read from / written to memory.
-   * 0 = automatic (sentence-resident for coherent rows when the window fits in LDS, plain otherwise),
-   * 1 = plain, 2 = sentence-resident whenever it fits -- for coherent rows: with relaxed_coherence or exact_reduction
+   * 0 = automatic = plain (round 4: the sentence-resident kernel keeps context rows private for up to 2 x window + 1 positions,
+   * which is up to 13 % off the reference's epoch loss on a held-out regime; rounds 2-3 chose it wherever it fitted),
+   * 1 = plain, 2 = sentence-resident whenever it fits (the faster kernel at short rows) -- for coherent rows: with relaxed_coherence or exact_reduction
    * set the plain kernel runs whatever this field says (w2b_worker_kernel_info tells which one a trainer uses). */
   int32_t plain_worker_kernel;
   /* 1: parity mode.  The dot product of ref :461-467 is accumulated serially in the reference's own order
@@ -206,7 +207,9 @@ int w2b_epoch_poll(w2b_trainer *t, int32_t lag, int32_t *finished, int64_t *word
 /* Number of Hogwild workers (-threads) that exactly fills this GPU for the configured shape: the workgroups
  * of the worker kernel that are resident at once (more workers run in rounds; fewer leave CUs idle) -- but, when
  * cfg.train_words is known, never more than train_words / 50000 (20000 until round 4): a worker re-computes alpha only after >10000 of
- * its own words (ref :379-393), so shorter shards would freeze the learning rate for the whole epoch. */
+ * its own words (ref :379-393), so shorter shards would freeze the learning rate for the whole epoch; and, when that is
+ * fewer than 3 workgroups per CU (not a full device) with the plain kernel, never more than 256 -- the scale of the
+ * reference's own runs: beyond it the shared-row mode gains little speed and drifts from the reference. */
 int w2b_suggested_threads(w2b_trainer *t, int32_t *out);
 
 /* Which form-(i) kernel w2b_train_step() runs for this trainer: *resident = 1 for the sentence-resident kernel
