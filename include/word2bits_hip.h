@@ -149,6 +149,17 @@ typedef struct w2b_tuning {
                                   * often since the last exchange; 0 = the library's default */
   int32_t reserved[1];
 } w2b_tuning;
+/* What the library decides for a launch of the plain worker kernel with `workers` concurrent workers on a GPU with `num_cus`
+ * compute units, from the word counts alone (pure host arithmetic: usable -- and tested -- without a GPU): per-XCD copies
+ * of the leading rows (none below a full device), rows updated by lossless adds, merge period.  tune = NULL: the defaults. */
+typedef struct w2b_row_plan {
+  int32_t copies_u, copies_v;          /* rows 1..N of u / v with per-XCD copies */
+  int32_t atomic_rank_u, atomic_rank_v;/* rows 1..N of u / v updated by atomic adds (rows with copies excepted) */
+  int32_t full_device;                 /* 1: >= 3 workgroups per compute unit */
+  int32_t merge_period;                /* centre words between two merge events of a worker */
+} w2b_row_plan;
+int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, const int64_t *cn, int32_t num_cus, int32_t workers,
+                  w2b_row_plan *out);
 int w2b_get_tuning(w2b_trainer *t, w2b_tuning *out);
 int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in);
 

@@ -304,3 +304,76 @@ def test_no_parked_patches():
     experiments live on branches, not as patch files in the tree."""
     import glob
     assert not glob.glob(os.path.join(ROOT, "tools", "patches", "*.patch"))
+
+
+# ------------------------------------------------------------------ round 4: the row rules, without a GPU (w2b_plan_rows)
+def _plan(cn, workers, num_cus=256, D=800, window=8, negative=24, sample=0.0, **tune):
+    import ctypes as C
+    from word2bits_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.Config()
+    cfg.vocab_size, cfg.train_words, cfg.iter = len(cn), int(cn.sum()), 1
+    cfg.layer1_size, cfg.window, cfg.negative, cfg.bitlevel, cfg.num_threads = D, window, negative, 1, workers
+    cfg.alpha, cfg.sample = 0.05, sample
+    tn = None
+    if tune:
+        tn = _lib.Tuning()
+        tn.struct_size = C.sizeof(_lib.Tuning)
+        tn.hot_rows_v = tn.hot_rows_u = tn.mem_mode = tn.atomic_rank = -1
+        tn.hot_cap, tn.hot_weight_permille, tn.window_refresh = 128, 125, 16
+        for k, v in tune.items():
+            setattr(tn, k, v)
+    out = _lib.RowPlan()
+    cn = np.ascontiguousarray(cn, np.int64)
+    _lib.check(L.w2b_plan_rows(C.byref(cfg), C.byref(tn) if tn is not None else None, cn.ctypes.data_as(_lib.i64p), num_cus, workers, C.byref(out)))
+    return {k: getattr(out, k) for k, _ in _lib.RowPlan._fields_}
+
+
+def test_row_rules_copies_only_on_a_full_device_lossless_context_rows_below():
+    """DESIGN.md section 3.3a as arithmetic on the word counts (no GPU): a Zipf(1) vocabulary of 400 K words without sub-sampling
+    (the benchmarked regime).  Below 3 workgroups per CU: no per-XCD copies, the context rows that at least a quarter of
+    another worker holds at any moment are updated by atomic adds (a prefix that grows with the number of workers), target
+    rows are plain.  On a full device: copies of both tables by the load rule, no adds."""
+    V = 400_000
+    cn = np.maximum((7.4e6 / np.arange(1, V + 1)).astype(np.int64), 5)      # ~100 M tokens, rank-1 word 7.4 %
+    cn[0] = 100_000                                                          # "</s>"
+    share = cn[1:] / cn[1:].sum()                                            # ("</s>" is never a context word, ref :400)
+    prev = 0
+    for workers in (8, 64, 256, 512, 767):
+        p = _plan(cn, workers)
+        assert p["full_device"] == 0 and p["copies_u"] == 0 and p["copies_v"] == 0 and p["atomic_rank_v"] == 0
+        want = int(np.sum(workers * 9 * share >= 0.25))                    # workers x (window + 1) x share of the tokens >= 1/4
+        assert abs(p["atomic_rank_u"] - want) <= 1 and p["atomic_rank_u"] >= prev
+        prev = p["atomic_rank_u"]
+    assert _plan(cn, 8)["atomic_rank_u"] == int(np.sum(8 * 9 * share >= 0.25)) > 0
+    for workers in (768, 1024):
+        p = _plan(cn, workers)
+        assert p["full_device"] == 1 and p["copies_u"] > 50 and p["copies_v"] > 50 and p["merge_period"] == 32
+        assert p["atomic_rank_u"] == 0 and p["atomic_rank_v"] == 0
+    # explicit numbers win on either side of the threshold
+    assert _plan(cn, 64, hot_rows_v=5, hot_rows_u=0)["copies_v"] == 5
+    p = _plan(cn, 1024, hot_rows_v=0, hot_rows_u=0)
+    assert p["copies_u"] == p["copies_v"] == 0 and p["atomic_rank_u"] > 1000          # shared rows on a full device: the adds are back
+    assert _plan(cn, 256, atomic_rank_u=-1)["atomic_rank_u"] == 0
+    # a smaller GPU: "full" is relative to its compute units
+    assert _plan(cn, 256, num_cus=64)["full_device"] == 1
+
+
+def test_row_rules_sub_sampling_and_flat_vocabularies():
+    """With the reference's default sub-sampling the load of a context row is its share of the KEPT tokens (ref :403-406): the
+    frequent words are thinned, the kept stream is shorter, and the prefix of rows that reach the quarter-of-a-worker load is a
+    different (here: longer and flatter) one than without; a small flat vocabulary (the planted corpus: every row hit by
+    several workers per window) updates BOTH tables by adds (round 3's rule, kept)."""
+    V = 70_000
+    cn = np.maximum((1.45e6 / np.arange(1, V + 1)).astype(np.int64), 5)
+    cn[0] = 17_000
+    a = _plan(cn, 256, D=200, sample=0.0)["atomic_rank_u"]
+    b = _plan(cn, 256, D=200, sample=1e-3)["atomic_rank_u"]
+    assert 0 < a < V - 1 and 0 < b < V - 1 and a != b
+    st = 1e-3 * cn.sum()
+    kept = np.minimum(cn[1:], np.sqrt(cn[1:] * st) + st)                          # expected kept occurrences (ref :403-406)
+    assert abs(b - int(np.sum(256 * 9 * kept / kept.sum() >= 0.25))) <= 2
+    flat = np.full(2129, 300, np.int64)
+    p = _plan(flat, 64, D=200)
+    assert p["atomic_rank_v"] == p["atomic_rank_u"] == 2128 and p["copies_v"] == 0
+    assert _plan(flat, 2, D=200)["atomic_rank_v"] == 0

@@ -44,6 +44,12 @@ class Tuning(C.Structure):
     ]
 
 
+class RowPlan(C.Structure):
+    """struct w2b_row_plan -- what w2b_plan_rows decides for a launch (include/word2bits_hip.h)."""
+    _fields_ = [("copies_u", C.c_int32), ("copies_v", C.c_int32), ("atomic_rank_u", C.c_int32), ("atomic_rank_v", C.c_int32),
+                ("full_device", C.c_int32), ("merge_period", C.c_int32)]
+
+
 vp, i32p, i64p, f32p, f64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), \
     C.POINTER(C.c_float), C.POINTER(C.c_double)
 u64p = C.POINTER(C.c_uint64)
@@ -59,6 +65,7 @@ SIGNATURES = {
     "w2b_quantize": (C.c_float, [C.c_float, C.c_int32]),
     "w2b_trainer_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),
     "w2b_trainer_destroy": (None, [vp]),
+    "w2b_plan_rows": (C.c_int, [C.POINTER(Config), C.POINTER(Tuning), i64p, C.c_int32, C.c_int32, C.POINTER(RowPlan)]),
     "w2b_get_tuning": (C.c_int, [vp, C.POINTER(Tuning)]),
     "w2b_set_tuning": (C.c_int, [vp, C.POINTER(Tuning)]),
     "w2b_init_net": (C.c_int, [vp]),

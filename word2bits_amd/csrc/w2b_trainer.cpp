@@ -235,6 +235,22 @@ static W2bParams make_params(const w2b_trainer *t) {
   return p;
 }
 
+static w2b_tuning default_tuning() {
+  w2b_tuning tn{};
+  tn.struct_size = (int32_t)sizeof(w2b_tuning);
+  tn.hot_rows_v = tn.hot_rows_u = -1;
+  tn.hot_period = 0;         // automatic
+  tn.hot_cap = 128;
+  tn.force_row_desc = 0;
+  tn.grid_per_cu = 0;
+  tn.mem_mode = -1;
+  tn.atomic_rank = -1;
+  tn.atomic_cap = 0;         // 0 = no cap
+  tn.hot_weight_permille = 1000 / W2B_NXCD;
+  tn.window_refresh = 16;
+  return tn;
+}
+
 extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
   if (!cfg || !out) return fail(W2B_EINVAL, "w2b_trainer_create: null argument");
   *out = nullptr;
@@ -257,17 +273,7 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
   HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
   t->num_cus = prop.multiProcessorCount;
   t->debug = getenv("W2B_DEBUG") != nullptr;
-  t->tune.struct_size = (int32_t)sizeof(w2b_tuning);
-  t->tune.hot_rows_v = t->tune.hot_rows_u = -1;
-  t->tune.hot_period = 0;         // automatic
-  t->tune.hot_cap = 128;
-  t->tune.force_row_desc = 0;
-  t->tune.grid_per_cu = 0;
-  t->tune.mem_mode = -1;
-  t->tune.atomic_rank = -1;
-  t->tune.atomic_cap = 0;         // 0 = no cap
-  t->tune.hot_weight_permille = 1000 / W2B_NXCD;
-  t->tune.window_refresh = 16;
+  t->tune = default_tuning();
   HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
   t->table_elems = (long long)cfg->vocab_size * cfg->layer1_size;
   HIPCHK(hipMalloc(&t->uv, sizeof(float) * 2 * t->table_elems));
@@ -511,6 +517,42 @@ extern "C" int w2b_set_unigram_table(w2b_trainer *t, const int32_t *table, int64
   return W2B_OK;
 }
 
+// How often is row i of v a target (ref :450-460)?  Per centre word: negative * cn_i^0.75 / sum cn^0.75 (the unigram
+// table) + cn_i / train_words (as the centre word itself); and row i of u a context row: (window + 1 on average,
+// SURVEY A.3) * cn_i / train_words.  The vocabulary is sorted by count, so the rows worth per-XCD copies / lossless adds
+// are a prefix; how long a prefix is decided per launch from these rates and the number of workers (xhot_plan,
+// atomic_plan, atomic_plan_u).  Host arithmetic only (w2b_plan_rows runs it without a device).
+// (a token is a centre / context word only if it survives sub-sampling, ref :403-406: the counts that matter for
+// those two roles are the expected KEPT occurrences; the negative draws use the raw counts, ref :112-128)
+static void word_rates(w2b_trainer *t, const int64_t *cn, const std::vector<float> &keep) {
+  const int64_t V = t->cfg.vocab_size;
+  double pw = 0, tot = 0, tot_kept = 0;
+  auto kept = [&](int64_t a) -> double {
+    if (a == 0) return 0.0;                                  // "</s>" is never a centre or context word (ref :400)
+    const double k = t->cfg.sample > 0 ? (double)keep[(size_t)a] : 1.0;
+    return (double)cn[a] * (k < 1.0 ? k : 1.0);
+  };
+  for (int64_t a = 0; a < V; a++) { pw += pow((double)cn[a], 0.75); tot += (double)cn[a]; tot_kept += kept(a); }
+  t->counts.assign(cn, cn + V);
+  t->counts_pw = pw;
+  t->counts_tot = tot;
+  t->counts_tot_kept = tot_kept;
+  const int n = (int)(V - 1 < W2B_XHOT_MAX ? V - 1 : W2B_XHOT_MAX);
+  t->rate_v.assign((size_t)(n > 0 ? n : 0), 0.0);
+  t->rate_u.assign((size_t)(n > 0 ? n : 0), 0.0);
+  t->ctx_share.assign((size_t)(n > 0 ? n : 0), 0.0);
+  {
+    double acc = 0;
+    for (int k = 0; k < n; k++) { acc += tot_kept > 0 ? kept(k + 1) / tot_kept : 0; t->ctx_share[(size_t)k] = acc; }
+  }
+  for (int k = 0; k < n; k++) {
+    const double c = (double)cn[k + 1];
+    // (raw counts for the choice of the rows with copies: measured in round 3 on the text8-sized corpus at 256 workers)
+    t->rate_v[k] = (pw > 0 ? t->cfg.negative * pow(c, 0.75) / pw : 0) + (tot > 0 ? c / tot : 0);
+    t->rate_u[k] = tot > 0 ? (t->cfg.window + 1) * c / tot : 0;
+  }
+}
+
 extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t table_size) {
   NEED(t);
   if (!cn) return fail(W2B_EINVAL, "w2b_set_vocab_counts: null counts");
@@ -519,41 +561,7 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
   if (t->cfg.sample > 0) w2b_build_keep_prob(cn, V, t->cfg.sample, t->cfg.train_words, keep.data());
   if (!t->keep) HIPCHK(hipMalloc(&t->keep, sizeof(float) * V));
   HIPCHK(hipMemcpy(t->keep, keep.data(), sizeof(float) * V, hipMemcpyHostToDevice));
-  {
-    // How often is row i of v a target (ref :450-460)?  Per centre word: negative * cn_i^0.75 / sum cn^0.75 (the unigram
-    // table) + cn_i / train_words (as the centre word itself); and row i of u a context row: (window + 1 on average,
-    // SURVEY A.3) * cn_i / train_words.  The vocabulary is sorted by count, so the rows worth per-XCD copies are a prefix;
-    // how long a prefix is decided per launch from these rates and the number of workers (xhot_plan).
-    // (a token is a centre / context word only if it survives sub-sampling, ref :403-406: the counts that matter for
-    // those two roles are the expected KEPT occurrences; the negative draws use the raw counts, ref :112-128)
-    double pw = 0, tot = 0, tot_kept = 0;
-    auto kept = [&](int64_t a) -> double {
-      if (a == 0) return 0.0;                                  // "</s>" is never a centre or context word (ref :400)
-      const double k = t->cfg.sample > 0 ? (double)keep[(size_t)a] : 1.0;
-      return (double)cn[a] * (k < 1.0 ? k : 1.0);
-    };
-    for (int64_t a = 0; a < V; a++) { pw += pow((double)cn[a], 0.75); tot += (double)cn[a]; tot_kept += kept(a); }
-    t->counts.assign(cn, cn + V);
-    t->counts_pw = pw;
-    t->counts_tot = tot;
-    t->counts_tot_kept = tot_kept;
-    const int n = (int)(V - 1 < W2B_XHOT_MAX ? V - 1 : W2B_XHOT_MAX);
-    t->rate_v.assign((size_t)(n > 0 ? n : 0), 0.0);
-    t->rate_u.assign((size_t)(n > 0 ? n : 0), 0.0);
-    t->ctx_share.assign((size_t)(n > 0 ? n : 0), 0.0);
-    {
-      double acc = 0;
-      for (int k = 0; k < n; k++) { acc += tot_kept > 0 ? kept(k + 1) / tot_kept : 0; t->ctx_share[(size_t)k] = acc; }
-    }
-    for (int k = 0; k < n; k++) {
-      const double c = (double)cn[k + 1];
-      // (raw counts for the choice of the rows: measured on the text8-sized corpus at 256 workers, the larger set that the
-      // raw counts give -- sub-sampling thins exactly these words -- keeps the later epochs within 1 % of the
-      // reference's losses, the set from the kept counts leaves them 2.4 % off)
-      t->rate_v[k] = (pw > 0 ? t->cfg.negative * pow(c, 0.75) / pw : 0) + (tot > 0 ? c / tot : 0);
-      t->rate_u[k] = tot > 0 ? (t->cfg.window + 1) * c / tot : 0;
-    }
-  }
+  word_rates(t, cn, keep);
   if (table_size > 0) {
     std::vector<int32_t> tab((size_t)table_size);
     int rc = w2b_build_unigram_table(cn, V, tab.data(), table_size);
@@ -977,6 +985,31 @@ extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t
   if (workgroups_per_cu)
     *workgroups_per_cu = r >= 0 ? w2b_resident_per_cu(p, r, t->cfg.compute_loss != 0)
                                 : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
+  return W2B_OK;
+}
+
+// The row rules of a launch without a device (pure host arithmetic on the word counts): what w2b_train_step would decide for
+// `workers` concurrent workers of the plain kernel on a GPU with `num_cus` compute units.
+extern "C" int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, const int64_t *cn, int32_t num_cus, int32_t workers,
+                             w2b_row_plan *out) {
+  if (!cfg || !cn || !out || num_cus < 1 || workers < 1 || cfg->vocab_size < 2 || cfg->layer1_size < 1)
+    return fail(W2B_EINVAL, "w2b_plan_rows: bad argument");
+  if (tune && tune->struct_size != (int32_t)sizeof(w2b_tuning)) return fail(W2B_EINVAL, "w2b_plan_rows: struct_size of w2b_tuning");
+  w2b_trainer t;                               // a host-side stand-in: no device member is touched by the plan functions
+  t.cfg = *cfg;
+  t.num_cus = num_cus;
+  t.tune = tune ? *tune : default_tuning();
+  std::vector<float> keep((size_t)cfg->vocab_size, 1.f);
+  if (cfg->sample > 0) w2b_build_keep_prob(cn, cfg->vocab_size, cfg->sample, cfg->train_words, keep.data());
+  word_rates(&t, cn, keep);
+  int nu = 0, nv = 0;
+  xhot_plan(&t, workers, true, &nu, &nv, false);
+  out->copies_u = nu;
+  out->copies_v = nv;
+  out->atomic_rank_v = atomic_plan(&t, workers);
+  out->atomic_rank_u = atomic_plan_u(&t, workers, out->atomic_rank_v);
+  out->full_device = full_device(&t, workers) ? 1 : 0;
+  out->merge_period = t.tune.hot_period > 0 ? t.tune.hot_period : 32;
   return W2B_OK;
 }
 
