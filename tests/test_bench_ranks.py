@@ -41,3 +41,29 @@ def test_rendezvous_of_another_size_is_refused():
                         {"W2B_BENCH_DRY": "1", "WORLD_SIZE": world, "RANK": "0", "LOCAL_RANK": "0"}, timeout=60)
         assert r.returncode == 2, (gpus, world, r.returncode, r.stderr[-500:])
         assert not lines and "refusing" in r.stderr
+
+
+def test_cpu_legs_of_bench_read_the_reference_programs_stdout():
+    """bench.py's CPU legs watch the unmodified reference program through its unbuffered stdout ('Starting epoch' -> 'Epoch Loss'
+    for a whole epoch, the progress line's percentage for a bounded sample): both modes on a corpus of a few seconds.  Needs
+    oracle/_ref (built where /root/reference is mounted); the legs themselves only ever run in bench.py's cpu_baseline part."""
+    import argparse
+    import importlib.util
+    import pytest
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "word2bits_stock")):
+        pytest.skip("oracle/_ref/word2bits_stock not built here")
+    spec = importlib.util.spec_from_file_location("bench", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = argparse.Namespace(vocab=5000, cpu_tokens=400_000, bitlevel=1, dim=100, window=8, negative=24)
+    path = bench.write_cpu_corpus(a)
+    try:
+        whole = bench.cpu_baseline_reference(a, path)
+        assert whole["kind"] == "reference" and whole["cores"] == (os.cpu_count() or 1) and whole["value"] > 1000
+        assert "424995 tokens" in whole["sample"] or "tokens =" in whole["sample"]
+        r = bench.RefProbe(path, bench.ref_flags(a), 1, sample_seconds=4.0).result()
+        assert r and 1000 < r["words_per_s"] < 5e6
+        assert r["whole_epoch"] or r["train_s"] >= 2.0          # (a fast host may finish the epoch inside the sample)
+    finally:
+        os.remove(path)
+        os.rmdir(os.path.dirname(path))
