@@ -3,7 +3,7 @@ several ARMS of w2b_tuning knobs, all in ONE process on ONE box: the synthetic s
 fresh trainer, `--rounds` interleaved rounds (A B C A B C ...) so that clock / thermal drift does not favour an arm.
 
   python tests/experiments/arm_bench.py --arms "default:;loss:loss=1;late:hot_late=1;fresh:fresh_rank_u=2000"
-An arm is name:key=value,key=value ; keys are w2b_tuning fields plus loss / window_cache / workers / bitlevel."""
+An arm is name:key=value,key=value ; keys are w2b_tuning fields plus loss / window_cache / row_groups / workers / bitlevel."""
 import argparse, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -58,21 +58,24 @@ def one(name, kw):
     loss = bool(kw.pop("loss", 0))
     wc = kw.pop("window_cache", -1)
     wcache = None if wc < 0 else bool(wc)
+    rg = kw.pop("row_groups", -1)
+    rgroups = None if rg < 0 else bool(rg)
     workers = kw.pop("workers", 0)
     bitlevel = kw.pop("bitlevel", a.bitlevel)
     if workers <= 0:
-        probe = w2b.Trainer(V, D, W, K, bitlevel, num_threads=1, device=0, sample=0.0, train_words=train_words, window_cache=wcache, compute_loss=loss)
+        probe = w2b.Trainer(V, D, W, K, bitlevel, num_threads=1, device=0, sample=0.0, train_words=train_words, window_cache=wcache, row_groups=rgroups, compute_loss=loss)
         probe.set_vocab_counts(counts, 0)
         workers = probe.suggested_threads()
         probe.close()
     t = w2b.Trainer(V, D, W, K, bitlevel, num_threads=workers, iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words,
-                    compute_loss=loss, device=0, window_cache=wcache, **kw)
+                    compute_loss=loss, device=0, window_cache=wcache, row_groups=rgroups, **kw)
     t.init_net()
     t.set_vocab_counts(counts, 100_000_000)
     t.set_corpus_device(stream.data_ptr(), a.tokens)
     t.set_shards(replicas.token_shard_starts(a.tokens, workers, 0, workers))
     t.epoch_begin()
     info = t.worker_kernel_info()
+    kname = t.worker_kernel_name()
     positions = max(1, a.batch // workers)
     for _ in range(a.warmup):
         t.train_step(positions)
@@ -83,7 +86,7 @@ def one(name, kw):
     ms, n = t.timing_read()
     t.close()
     wps = workers * positions / (ms / n / 1e3)
-    return {"arm": name, "knobs": kw, "loss": loss, "workers": workers, "resident": bool(info[0]), "hot_rows": info[4], "Mwords_s": wps / 1e6,
+    return {"arm": name, "knobs": kw, "loss": loss, "workers": workers, "resident": bool(info[0]), "kernel": kname, "us_per_word_per_worker": 1e6 * workers / wps, "hot_rows": info[4], "Mwords_s": wps / 1e6,
             "frac": wps * bpw / 8e12, "launch_ms": ms / n}
 
 
@@ -96,8 +99,8 @@ for r in range(a.rounds):
             print("%-26s FAILED %r" % (name, e), flush=True)
             continue
         res.setdefault(name, []).append(x)
-        print("round %d %-26s %7.2f Mw/s  frac %.3f  launch %.2f ms  workers %d resident %d hot %d" % (
-            r, name, x["Mwords_s"], x["frac"], x["launch_ms"], x["workers"], x["resident"], x["hot_rows"]), flush=True)
+        print("round %d %-26s %7.2f Mw/s  frac %.3f  launch %.2f ms  workers %d %s hot %d  %.1f us/word/worker" % (
+            r, name, x["Mwords_s"], x["frac"], x["launch_ms"], x["workers"], x["kernel"], x["hot_rows"], x["us_per_word_per_worker"]), flush=True)
 print("== best of %d rounds" % a.rounds)
 for name, xs in res.items():
     b = max(xs, key=lambda x: x["Mwords_s"])

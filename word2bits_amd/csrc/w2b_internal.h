@@ -97,6 +97,11 @@ bool w2b_resident_atomic_ok(const W2bParams &p, int radius);           // atomic
 long long w2b_resident_scratch_rows(int radius);                       // scratch rows per worker
 hipError_t w2b_launch_resident(const W2bParams &p, long long max_positions, int radius, bool loss, hipStream_t s,
                                bool debug = false);
+// row-group variant of the worker kernel (w2b_kernels_groups.hip): short rows / few workers, every row shared
+bool w2b_groups_ok(const W2bParams &p);                                 // can it run this shape / these row rules?
+size_t w2b_groups_lds_bytes(int dim, int window, int negative);
+int w2b_groups_per_cu(const W2bParams &p, bool loss);                   // resident workgroups per CU
+hipError_t w2b_launch_groups(const W2bParams &p, long long max_positions, bool loss, hipStream_t s);
 int w2b_workers_per_cu(const W2bParams &p, bool loss);                  // resident workgroups per CU, plain kernel
 int w2b_resident_per_cu(const W2bParams &p, int radius, bool loss);     // ... sentence-resident kernel
 hipError_t w2b_launch_init_net(float *u, float *v, long long n_per_table, const float *lut,

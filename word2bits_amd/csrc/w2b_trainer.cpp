@@ -728,7 +728,7 @@ static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int 
 // the parity mode always run the plain kernel.  Returns the radius (-1 = plain kernel).
 static int worker_plan(const w2b_trainer *t) {
   const int mode = t->cfg.plain_worker_kernel;
-  if (mode == 1 || t->cfg.exact_reduction) return -1;   // the serial reduction lives in the plain kernel
+  if (mode == 1 || mode == 3 || t->cfg.exact_reduction) return -1;   // the serial reduction lives in the plain kernel
   if (t->cfg.relaxed_coherence) return -1;              // the sentence-resident kernel exists for coherent rows only
   if (t->tune.mem_mode > 0) return -1;
   if (mode == 0) {
@@ -875,6 +875,26 @@ static int atomic_plan_u(const w2b_trainer *t, long long workers, int atomic_ran
   return (int)(n < V - 1 ? n : V - 1);
 }
 
+// The row-group kernel (w2b_kernels_groups.hip; round 5) runs a worker as G row groups + a producer + an adder wavefront:
+// all targets of a centre word in flight at once, the scalar side one word ahead, the lossless adds to the frequent context
+// rows off the data wavefronts' path.  It implements the SHARED-ROW rules only (every row at its master address, context
+// rows 1..atomic_rank_u by lossless adds) -- what the library runs below a full device (xhot_plan) -- for 16-byte
+// columns up to -size 1024, window <= 16, negative + 1 <= 27/28, tables below 2 GiB.  plain_worker_kernel: 3 = wherever it
+// fits, 1 / 2 = never; 0 = automatic: wherever it fits and rows are at most W2B_GROUPS_AUTO_DIM floats long (at -size 800 a
+// row already fills four wavefronts and the plain kernel keeps 4 workgroups per CU; measured).
+static const int W2B_GROUPS_AUTO_DIM = 512;
+static bool groups_plan(const w2b_trainer *t, long long workers) {
+  const int mode = t->cfg.plain_worker_kernel;
+  if (mode == 1 || mode == 2) return false;
+  if (mode == 0 && t->cfg.layer1_size > W2B_GROUPS_AUTO_DIM) return false;
+  W2bParams probe = make_params(t);
+  int nu = 0, nv = 0;
+  xhot_plan(t, workers, true, &nu, &nv, false);
+  if (nu + nv > 0) return false;                       // per-XCD copies live in the plain kernel
+  probe.fresh_rank_u = t->tune.fresh_rank_u > 0 ? t->tune.fresh_rank_u : 0;
+  return w2b_groups_ok(probe);
+}
+
 // scratch rows of process_word_wide for `workgroups` workgroups (grown on demand)
 static int wide_prepare(w2b_trainer *t, W2bParams &p, long long workgroups) {
   if (!p.wide) return W2B_OK;
@@ -976,7 +996,8 @@ extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t
   const int r = effective_radius(t, t->cfg.num_threads);
   int hu = 0, hot = 0;
   xhot_plan(t, t->cfg.num_threads, r < 0, &hu, &hot, false);
-  if (resident) *resident = r >= 0;
+  const bool groups = r < 0 && groups_plan(t, t->cfg.num_threads);
+  if (resident) *resident = r >= 0 ? 1 : (groups ? 2 : 0);      // 0 plain, 1 sentence-resident, 2 row groups
   if (radius) *radius = r;
   if (hot_rows) *hot_rows = hot;
   int vec = 0;
@@ -984,7 +1005,7 @@ extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t
   if (column_bytes) *column_bytes = 4 * (r >= 0 ? 4 : vec);
   if (workgroups_per_cu)
     *workgroups_per_cu = r >= 0 ? w2b_resident_per_cu(p, r, t->cfg.compute_loss != 0)
-                                : w2b_workers_per_cu(p, t->cfg.compute_loss != 0);
+                                : (groups ? w2b_groups_per_cu(p, t->cfg.compute_loss != 0) : w2b_workers_per_cu(p, t->cfg.compute_loss != 0));
   return W2B_OK;
 }
 
@@ -1039,6 +1060,7 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   t->x_words_full += (long long)max_positions * t->cfg.num_threads;
   HIPCHK(timing_begin(t));
   if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream, t->debug));
+  else if (groups_plan(t, t->cfg.num_threads) && w2b_groups_ok(p)) HIPCHK(w2b_launch_groups(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));
   HIPCHK(w2b_launch_xhot_fold(p, t->stream));      // the master rows are complete again when the stream is idle

@@ -38,6 +38,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   long long table_size = W2B_UNIGRAM_TABLE_SIZE;
   int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
   int window_cache = -1;               // -1 automatic, 0 plain worker kernel, 1 sentence-resident kernel
+  int row_groups = -1;                 // -row-groups N: -1 automatic, 0 never, 1 the row-group worker kernel wherever it fits
   int exact = 0;                       // 1: serial dot product in the reference's order (bit parity at -threads 1)
   std::string eval_file;               // -eval FILE: questions to score on the GPU after the final save (-binary 1)
   int hot_rows = -1;                   // -hot-rows N: leading rows of v (and u) with per-XCD copies; -1 = from the counts
@@ -53,6 +54,14 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   std::string packed_file;             // -packed FILE: also write the final vectors bit-packed (-bitlevel 1 / 2; word2bits_corpus.h)
   int row_desc = 0;                    // -row-desc 1: the row addressing of tables >= 2 GiB on any table (w2b_tuning.force_row_desc)
 };
+
+// w2b_config.plain_worker_kernel from -window-cache / -row-groups: 0 automatic, 1 plain, 2 sentence-resident, 3 row groups
+int worker_kernel_choice(const Options &o) {
+  if (o.window_cache > 0) return 2;
+  if (o.row_groups > 0) return 3;
+  if (o.window_cache == 0 || o.row_groups == 0) return 1;
+  return 0;
+}
 
 // ArgPos, ref :579-589: exact-match search; a flag in last position has no value -> exit(1)
 int arg_pos(const char *flag, int argc, char **argv) {
@@ -185,6 +194,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-table-size", argc, argv)) > 0) o.table_size = atoll(argv[i + 1]);
   if ((i = arg_pos("-relaxed", argc, argv)) > 0) o.relaxed = atoi(argv[i + 1]);
   if ((i = arg_pos("-window-cache", argc, argv)) > 0) o.window_cache = atoi(argv[i + 1]);
+  if ((i = arg_pos("-row-groups", argc, argv)) > 0) o.row_groups = atoi(argv[i + 1]);
   if ((i = arg_pos("-exact", argc, argv)) > 0) o.exact = atoi(argv[i + 1]);
   if ((i = arg_pos("-eval", argc, argv)) > 0) o.eval_file = argv[i + 1];
   if ((i = arg_pos("-packed", argc, argv)) > 0) o.packed_file = argv[i + 1];
@@ -249,7 +259,7 @@ int main(int argc, char **argv) {
     probe_cfg.negative = o.negative; probe_cfg.bitlevel = o.bitlevel; probe_cfg.num_threads = 1;
     probe_cfg.alpha = o.alpha; probe_cfg.compute_loss = 1; probe_cfg.device = o.device;
     probe_cfg.relaxed_coherence = o.relaxed;
-    probe_cfg.plain_worker_kernel = o.window_cache < 0 ? 0 : (o.window_cache ? 2 : 1);
+    probe_cfg.plain_worker_kernel = worker_kernel_choice(o);
     probe_cfg.exact_reduction = o.exact;
     w2b_trainer *probe = nullptr;
     int32_t per_gpu = 1024;
@@ -296,7 +306,7 @@ int main(int argc, char **argv) {
     cfg.device = o.device + a->r->index;
     cfg.worker_offset = a->r->index * a->per_gpu;             // worker_offset: global id of local worker 0
     cfg.relaxed_coherence = o.relaxed;
-    cfg.plain_worker_kernel = o.window_cache < 0 ? 0 : (o.window_cache ? 2 : 1);
+    cfg.plain_worker_kernel = worker_kernel_choice(o);
     cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));

@@ -124,7 +124,8 @@ class Trainer:
 
     def __init__(self, vocab_size, layer1_size=100, window=5, negative=5, bitlevel=1, num_threads=12,
                  iter=5, alpha=0.05, sample=1e-3, reg=0.0, train_words=0, compute_loss=True, device=0,
-                 worker_offset=0, total_threads=0, relaxed_coherence=False, window_cache=None, exact=False, **tuning):
+                 worker_offset=0, total_threads=0, relaxed_coherence=False, window_cache=None, exact=False, row_groups=None,
+                 **tuning):
         cfg = Config()
         cfg.vocab_size, cfg.train_words, cfg.iter = int(vocab_size), int(train_words), int(iter)
         cfg.layer1_size, cfg.window, cfg.negative = int(layer1_size), int(window), int(negative)
@@ -134,7 +135,8 @@ class Trainer:
         cfg.worker_offset, cfg.total_threads = int(worker_offset), int(total_threads)
         cfg.relaxed_coherence = int(bool(relaxed_coherence))
         # window_cache: None = automatic, True = sentence-resident kernel whenever it fits, False = plain
-        cfg.plain_worker_kernel = 0 if window_cache is None else (2 if window_cache else 1)
+        # row_groups: None = automatic, True = the row-group kernel wherever it fits, False = never
+        cfg.plain_worker_kernel = 2 if window_cache else (3 if row_groups else (1 if (window_cache is False or row_groups is False) else 0))
         # exact: serial dot product in the reference's order -> a 1-worker run is bit-identical to the CPU program
         cfg.exact_reduction = int(bool(exact))
         self.cfg = cfg
@@ -270,7 +272,13 @@ class Trainer:
         """(resident, radius, column_bytes, workgroups_per_cu, hot_rows) of the form-(i) kernel train_step() runs"""
         a, b, c, d, e = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
         check(lib().w2b_worker_kernel_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
-        return bool(a.value), b.value, c.value, d.value, e.value
+        return a.value == 1, b.value, c.value, d.value, e.value
+
+    def worker_kernel_name(self):
+        """which form-(i) kernel train_step() runs: "plain", "resident" (sentence-resident) or "groups" (row groups)"""
+        a = C.c_int32(0)
+        check(lib().w2b_worker_kernel_info(self._h, C.byref(a), None, None, None, None))
+        return ("plain", "resident", "groups")[a.value]
 
     def suggested_threads(self):
         n = C.c_int32(0)
