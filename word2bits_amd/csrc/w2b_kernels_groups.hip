@@ -339,7 +339,7 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
           idx[k] = __builtin_amdgcn_readlane(mine, k);
           rows[k] = __builtin_amdgcn_readlane(trow, k);
         }
-        for (int j0 = 0; g + j0 * G < cw; j0 += CB) {
+        for (int j0 = 0; j0 == 0 || g + j0 * G < cw; j0 += CB) {    // (the first trip also issues the target loads)
           Col<4> r[CB];
 #pragma unroll
           for (int jj = 0; jj < CB; jj++) {
