@@ -147,7 +147,12 @@ typedef struct w2b_tuning {
   int32_t exchange_sat_updates;  /* replica exchange, mode 2 / hot tier: a row counts as SATURATED (moves by the mean of its
                                   * contributors' deltas instead of their sum) when every replica has updated it at least this
                                   * often since the last exchange; 0 = the library's default */
-  int32_t reserved[1];
+  /* round 5 (the last reserved field; struct_size unchanged): row-group worker kernel -- context rows 1..N are READ at a copy
+   * per XCD that one refresher workgroup per XCD keeps re-filling from the master rows for as long as a launch runs, while
+   * their updates stay lossless adds at the master address (a read of a line that is being added to at the memory side is
+   * what bounds the shared-row mode: DESIGN.md section 3.3c).  0 = the library decides from the word counts and the number
+   * of workers (none for a few workers), -1 = none, > 0 = rows 1..N (at most 64, and never beyond the rows with lossless adds). */
+  int32_t refresh_rows_u;
 } w2b_tuning;
 /* What the library decides for a launch of the plain worker kernel with `workers` concurrent workers on a GPU with `num_cus`
  * compute units, from the word counts alone (pure host arithmetic: usable -- and tested -- without a GPU): per-XCD copies

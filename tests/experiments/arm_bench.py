@@ -25,11 +25,13 @@ ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--out", default="")
+ap.add_argument("--ids", choices=["zipf", "uniform"], default="zipf")
+ap.add_argument("--zipf-shift", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 V, D, W, K = a.vocab, a.dim, a.window, a.negative
 gen = torch.Generator(device=dev); gen.manual_seed(1000)
-w = 1.0 / torch.arange(1, V, dtype=torch.float64, device=dev)
+w = torch.ones(V - 1, dtype=torch.float64, device=dev) if a.ids == "uniform" else 1.0 / (torch.arange(1, V, dtype=torch.float64, device=dev) + a.zipf_shift)
 cdf = torch.cumsum(w, 0)
 cdf = cdf / cdf[-1]
 stream = torch.empty(a.tokens, dtype=torch.int32, device=dev)

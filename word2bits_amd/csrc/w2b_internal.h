@@ -26,6 +26,7 @@ struct W2bShared {
   unsigned long long wca_others;      // sum of the other replicas' word_count_actual at the last exchange
   unsigned long long wca_at_sync;     // this replica's word_count_actual at the last exchange
   double loss_epoch;                  // sum of the workers' total_loss of the running epoch (ref :537-538)
+  int launch_done, pad1;              // worker workgroups of the running launch that have finished (the refreshers of the row-group kernel wait for it)
   unsigned long long dbg[16];   // phase timers of workgroup 0 (builds with -DW2B_PHASE_TIMERS only)
 };
 
@@ -78,6 +79,12 @@ struct W2bParams {
   int fresh_rank_u;               // plain kernels, phase C: context rows 1..fresh_rank_u are re-read before their update instead of
                                   // taken from the LDS stash of phase A (the update lands on the current value, ref :500-502)
   int exact;                      // serial dot product in the reference's order (plain worker / tuple kernels)
+  // Refreshed read copies of the hottest context rows (row-group kernel, w2b_kernels_groups.hip): rows 1..rc_rows of u are READ
+  // at this XCD's copy (nt: served by the XCD's L2) while their updates stay lossless adds at the master address; one
+  // refresher workgroup per XCD copies master -> copy in a loop for as long as the launch's workers run.
+  int rc_rows;                    // 0 = none
+  float *rc;                      // [W2B_NXCD][rc_rows][dim]
+  int *rc_flags;                  // [0..8) claim (one refresher per XCD), [16..24) alive (the XCD's copies have been filled in this launch)
   float starting_alpha, sample, reg;
 };
 
@@ -102,6 +109,9 @@ bool w2b_groups_ok(const W2bParams &p);                                 // can i
 size_t w2b_groups_lds_bytes(int dim, int window, int negative);
 int w2b_groups_per_cu(const W2bParams &p, bool loss);                   // resident workgroups per CU
 hipError_t w2b_launch_groups(const W2bParams &p, long long max_positions, bool loss, hipStream_t s);
+hipError_t w2b_launch_refresher(const W2bParams &p, hipStream_t s);        // k_refresh_rows, beside a launch of the row-group kernel
+#define W2B_RC_MAX 64               // most rows of u with refreshed read copies
+#define W2B_RC_BLOCKS 16            // refresher workgroups started per launch (one per XCD claims its copy, the others leave)
 int w2b_workers_per_cu(const W2bParams &p, bool loss);                  // resident workgroups per CU, plain kernel
 int w2b_resident_per_cu(const W2bParams &p, int radius, bool loss);     // ... sentence-resident kernel
 hipError_t w2b_launch_init_net(float *u, float *v, long long n_per_table, const float *lut,

@@ -33,6 +33,19 @@
 #define W2G_CMAX 32      // context rows of a centre word (window <= 16)
 #define W2G_TMAX 32      // targets of a centre word (negative + 1 <= G * TC <= 32)
 
+// Phase timers (builds with -DW2B_PHASE_TIMERS; worker 0 only; printed by w2b_trainer_destroy under W2B_DEBUG):
+//   producer: [0] produce(), [1] waiting at the barriers;  adder: [2] loss terms + adds issued, [3] barriers
+//   data wavefront 0: [4] B0 -> loads issued -> context rows arrived and staged, [5] B1 wait, [6] window average + dot
+//   products + g + row updates, [7] B3 wait, [8] error accumulation, [9] B4 wait, [10] phase C, [11] B0 wait, [12] words
+#ifdef W2B_PHASE_TIMERS
+#define W2G_TICK(k) do { if (timing_) { const unsigned long long n_ = __builtin_readcyclecounter(); \
+    atomicAdd(&P.shared->dbg[k], n_ - tick_); tick_ = n_; } } while (0)
+#define W2G_COUNT(k) do { if (timing_) atomicAdd(&P.shared->dbg[k], 1ull); } while (0)
+#else
+#define W2G_TICK(k) do { } while (0)
+#define W2G_COUNT(k) do { } while (0)
+#endif
+
 namespace {
 
 typedef float w2g_f4 __attribute__((ext_vector_type(4)));
@@ -41,7 +54,9 @@ typedef float w2g_f4 __attribute__((ext_vector_type(4)));
 struct GLists {
   int cw, nt, npass, stop;        // stop: nothing to train -- the epoch is finished or the launch is over
   float alpha;
-  int n_dup, pad0, pad1;
+  int n_dup;
+  int rc_n;                       // rows 1..rc_n of u are read at this XCD's refreshed copy for this word (0: the copies are not filled yet)
+  int pad1;
   int ctx[W2G_CMAX];              // context rows of u, window order (ref :431-436)
   int umult[W2G_CMAX];            // multiplicity at the first occurrence of a row, 0 at later ones
   int tgt[W2G_TMAX];              // target rows of v: [0] = centre word, then the kept negatives (ref :450-460)
@@ -113,10 +128,18 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
   constexpr int NDW = G * RW, NTHR = (NDW + 2) * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wid = blockIdx.x;
-  if (wid >= P.num_threads) return;
-  W2bWorker *const Gw = P.workers + wid;
-  if (Gw->done) return;
+  const int nrf = 0;
+  const bool rc_on = P.rc_rows > 0;                                    // a refresher kernel runs beside this launch (k_refresh_rows)
+  // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): the XCD this workgroup runs on
+  const int xcd = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (W2B_NXCD - 1);
+  const unsigned rc_bytes = (unsigned)(P.rc_rows * dim * 4);
+  float *const rc_copy = P.rc + (long long)xcd * P.rc_rows * dim;
+  const int wid = (int)blockIdx.x - nrf;
+  W2bWorker *const Gw = P.workers + (wid < P.num_threads ? wid : 0);
+  if (wid >= P.num_threads || Gw->done) {
+    if (rc_on && tid == 0 && wid < P.num_threads) atomicAdd(&P.shared->launch_done, 1);
+    return;
+  }
   QParam qp;
   qp.bitlevel = P.bitlevel;
   qp.steps_i = (P.bitlevel >= 4) ? (1 << (P.bitlevel - 1)) : 1;
@@ -135,6 +158,10 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
   const bool reg_on = P.reg != 0.f;
   const int atomic_rank_v = P.atomic_rank, atomic_rank_u = P.atomic_rank_u;
   double loss_acc = 0.0;
+#ifdef W2B_PHASE_TIMERS
+  const bool timing_ = (wid == 0) && (lane == 0) && (wave == 0 || wave >= NDW);
+  unsigned long long tick_ = __builtin_readcyclecounter();
+#endif
 
   if (wave == NDW) {
     // ------------------------------------------------------------------------------------------ producer wavefront
@@ -242,6 +269,7 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
         if (done) S->done = 1;
         O->stop = (done || last) ? 1 : 0;
         O->cw = cw; O->nt = nt; O->npass = 1 + ndup; O->n_dup = ndup; O->alpha = alpha;
+        O->rc_n = (P.rc_rows > 0 && __builtin_nontemporal_load(&P.rc_flags[16 + xcd]) != 0) ? P.rc_rows : 0;
       }
     };
     produce(&F->lists[0], max_positions <= 0);
@@ -250,7 +278,9 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
       const W2G_LDS GLists *const L = &F->lists[it & 1];
       if (L->stop) break;
       const int cw = L->cw, npass = L->npass;
+      W2G_TICK(1);
       produce(&F->lists[(it + 1) & 1], it + 1 >= max_positions);        // (under the data wavefronts' wait for their rows)
+      W2G_TICK(0);
       if (cw > 0) {
         __syncthreads();                                                // B1
         if (RW > 1) for (int ps = 0; ps < npass; ps++) __syncthreads();
@@ -273,6 +303,7 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
         __syncthreads();                                                // B1
         if (RW > 1) for (int ps = 0; ps < npass; ps++) __syncthreads();
         __syncthreads();                                                // B3
+        W2G_TICK(3);
         if (LOSS) {                                                     // ref :480-483: lane j books target j
           for (int j = lane; j < nt; j += 64) {
             const float f = F->fs[j];
@@ -284,7 +315,9 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
             loss_acc += (double)logf(sg);
           }
         }
+        W2G_TICK(2);
         __syncthreads();                                                // B4
+        W2G_TICK(3);
         if (!reg_on && atomic_rank_u > 0) {                             // u[c] += e[c] on the current value (ref :500-502)
           float ev[NE];
 #pragma unroll
@@ -307,6 +340,7 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
             }
           }
         }
+        W2G_TICK(2);
       }
       __syncthreads();                                                  // B0
     }
@@ -327,6 +361,7 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
         const int nt = L->nt, npass = L->npass;
         const float alpha = L->alpha;
         const float ar2 = (2.f * alpha) * P.reg;                        // 2*alpha*reg (ref :490,:501)
+        const int rc_n = L->rc_n;
         float regsq = 0.f;
         // ---- loads: this group's context rows (window positions g, g + G, ...: CB of them per trip -- one trip up to
         // window = 8), then its distinct target rows
@@ -344,7 +379,12 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
 #pragma unroll
           for (int jj = 0; jj < CB; jj++) {
             const int j = g + (j0 + jj) * G;
-            if (j < cw && active) r[jj] = load_col<4, 0, 0>(P.u, __builtin_amdgcn_readfirstlane(L->ctx[j]), dim, col0, tab_bytes);
+            if (j < cw && active) {
+              const int crow = __builtin_amdgcn_readfirstlane(L->ctx[j]);
+              // a hot context row is read at this XCD's refreshed copy (its updates are lossless adds at the master address)
+              if (crow <= rc_n) r[jj] = load_col<4, W2B_MM_XCD, 0>(rc_copy, crow - 1, dim, col0, rc_bytes);
+              else r[jj] = load_col<4, 0, 0>(P.u, crow, dim, col0, tab_bytes);
+            }
           }
           if (j0 == 0) {
 #pragma unroll
@@ -360,7 +400,9 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
             if (j < cw && active) lds_st4(stash + j * dim + col0, r[jj]);
           }
         }
+        W2G_TICK(4);
         __syncthreads();                                                // B1
+        W2G_TICK(5);
         // ---- phase A: context_avg = (1/cw) * sum_j quantize(u[ctx_j]), window order (ref :431-449)
         Col<4> avg;
 #pragma unroll
@@ -486,7 +528,9 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
             finish_row(i, row, gk, xx);
           }
         }
+        W2G_TICK(6);
         __syncthreads();                                                // B3
+        W2G_TICK(7);
         // ---- error accumulation in target order (ref :486-488)
         Col<4> err;
 #pragma unroll
@@ -500,7 +544,9 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
           }
         }
         if (g == 0 && active) lds_st4(errbuf + col0, err);
+        W2G_TICK(8);
         __syncthreads();                                                // B4
+        W2G_TICK(9);
         // ---- phase C: u[ctx_j] += context_avge - 2*alpha*reg*u[ctx_j]   (ref :494-503); the adder wavefront takes the rows
         // that get lossless adds (reg == 0: their delta is the error vector itself)
 #pragma unroll
@@ -535,8 +581,11 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
           const float s = wave_sum(active ? regsq : 0.f);
           if (lane == 0) loss_acc -= (double)(P.reg * s);               // ref :437-445 and :463-471
         }
+        W2G_TICK(10);
+        W2G_COUNT(12);
       }
       __syncthreads();                                                  // B0
+      W2G_TICK(11);
     }
   }
   // save the worker
@@ -552,10 +601,47 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
       atomicAdd(&P.shared->loss_epoch, loss_acc);
     }
   }
+  if (rc_on && tid == 0) atomicAdd(&P.shared->launch_done, 1);
   if (tid == NDW * 64) {                                                // lane 0 of the producer
     Gw->rng = S->rng; Gw->cursor = S->cursor; Gw->word_count = S->wc; Gw->last_word_count = S->last_wc;
     Gw->sen_len = S->sen_len; Gw->sen_pos = S->sen_pos; Gw->first_override = S->override_;
     if (S->done) { Gw->done = 1; atomicAdd(&P.shared->workers_done, 1); }
+  }
+}
+
+// The refresher of the hottest context rows' read copies: W2B_RC_BLOCKS small workgroups on a stream of their own, beside a
+// launch of k_train_groups.  One per XCD (the first to claim it; the others leave) copies rows 1..rc_rows of u from their
+// master addresses (agent scope) to this XCD's copies (nt: kept in this XCD's L2, where the workers of the XCD read them)
+// over and over until every worker workgroup of the launch has finished.  Nobody waits for a refresher: while an XCD's
+// copies are not filled its workers read the master rows.
+__global__ void __launch_bounds__(256) k_refresh_rows(const W2bParams P) {
+  __shared__ int claim;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, dim = P.dim;
+  const int xcd = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (W2B_NXCD - 1);
+  if (tid == 0) claim = (atomicCAS(&P.rc_flags[xcd], 0, 1) == 0) ? 1 : 0;
+  __syncthreads();
+  if (!claim) return;
+  const unsigned rc_bytes = (unsigned)(P.rc_rows * dim * 4);
+  float *const rc_copy = P.rc + (long long)xcd * P.rc_rows * dim;
+  const unsigned long long t_start = __builtin_readcyclecounter();
+  for (long long sweep = 0;; ++sweep) {
+    for (int r0 = wave; r0 < P.rc_rows; r0 += 16) {                  // four rows of this wavefront in flight at a time
+      for (int c = lane * 4; c < dim; c += 256) {
+        Col<4> v[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if (r0 + 4 * b < P.rc_rows) v[b] = load_col<4, 0, 0>(P.u, r0 + 4 * b + 1, dim, c, P.tab_bytes);
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if (r0 + 4 * b < P.rc_rows) store_col<4, W2B_MM_XCD, 0>(rc_copy, r0 + 4 * b, dim, c, v[b], rc_bytes);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (sweep == 0 && tid == 0) __builtin_nontemporal_store(1, &P.rc_flags[16 + xcd]);       // the copies of this XCD are filled
+    const int done = __hip_atomic_load(&P.shared->launch_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done >= P.num_threads) break;
+    if (__builtin_readcyclecounter() - t_start > 240000000000ull) break;     // (100 s of shader clock: never spin forever)
   }
 }
 
@@ -610,6 +696,11 @@ int w2b_groups_per_cu(const W2bParams &p, bool loss) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, s.threads, lds);
   });
   return nb > 0 ? nb : 1;
+}
+
+hipError_t w2b_launch_refresher(const W2bParams &p, hipStream_t st) {
+  hipLaunchKernelGGL(k_refresh_rows, dim3(W2B_RC_BLOCKS), dim3(256), 0, st, p);
+  return hipGetLastError();
 }
 
 hipError_t w2b_launch_groups(const W2bParams &p, long long max_positions, bool loss, hipStream_t st) {

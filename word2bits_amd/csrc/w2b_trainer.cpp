@@ -59,6 +59,10 @@ struct w2b_trainer {
   size_t wide_floats = 0;
   float *xhot = nullptr;        // [W2B_NXCD]{copies [nu + nv][dim], entries [nu + nv][dim], merge locks [nu + nv][W2B_MAXW]}
   size_t xhot_floats = 0;
+  float *rc = nullptr;          // row-group kernel: 64 ints of flags + refreshed per-XCD copies of the hottest context rows
+  size_t rc_floats = 0;
+  hipStream_t rc_stream = nullptr;   // the refresher kernel's stream
+  hipEvent_t rc_go = nullptr, rc_end = nullptr;
   int xhot_nu = -1, xhot_nv = -1;       // layout the buffer currently has (-1: none)
   bool xhot_master_changed = true;      // the master rows may differ from what the copies were folded into
   bool debug = false;           // W2B_DEBUG was set when the trainer was created (diagnostics on stderr)
@@ -229,6 +233,9 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.fresh_rank_u = 0;
   (void)w2b_block_threads(t->cfg.layer1_size, nullptr, &p.wide);   // rows longer than a workgroup has columns
   p.wide_scratch = t->wide_scratch;
+  p.rc_rows = 0;
+  p.rc = nullptr;
+  p.rc_flags = nullptr;
   p.starting_alpha = t->cfg.alpha;
   p.sample = t->cfg.sample;
   p.reg = t->cfg.reg;
@@ -324,10 +331,13 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
     W2bShared sh;
     if (hipMemcpy(&sh, t->shared, sizeof sh, hipMemcpyDeviceToHost) == hipSuccess) {
       fprintf(stderr, "w2b debug: phase ticks (100 MHz wall clock) of workgroup 0:");
-      for (int k = 0; k < 12; k++) fprintf(stderr, " [%d]=%llu", k, sh.dbg[k]);
+      for (int k = 0; k < 16; k++) fprintf(stderr, " [%d]=%llu", k, sh.dbg[k]);
       fprintf(stderr, "\n");
     }
   }
+  if (t->rc_stream) { (void)hipStreamSynchronize(t->rc_stream); (void)hipStreamDestroy(t->rc_stream); }
+  if (t->rc_go) (void)hipEventDestroy(t->rc_go);
+  if (t->rc_end) (void)hipEventDestroy(t->rc_end);
   if (t->comm) ncclCommDestroy(t->comm);
   for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : t->ev_pool) (void)hipEventDestroy(e);
@@ -336,7 +346,7 @@ extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
   for (hipStream_t q : t->xs) if (q) (void)hipStreamSynchronize(q);
   for (hipEvent_t e : t->x_ev) (void)hipEventDestroy(e);
   xchg_teardown(t);
-  void *ptrs[] = {t->uv, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->xhot, t->wide_scratch, t->corpus_owned, t->workers, t->shared,
+  void *ptrs[] = {t->uv, t->wca_buf, t->exp_table, t->table, t->keep, t->entry, t->xhot, t->rc, t->wide_scratch, t->corpus_owned, t->workers, t->shared,
                   t->jump_a, t->jump_c, t->st_center, t->st_off, t->st_ctx, t->st_neg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -374,7 +384,7 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
   if (in->exchange_sat_updates < 0) return fail(W2B_EINVAL, "w2b_set_tuning: exchange_sat_updates >= 0");
   if (in->hot_weight_permille < 1 || in->hot_weight_permille > 1000)
     return fail(W2B_EINVAL, "w2b_set_tuning: hot_weight_permille must be 1..1000");
-  for (int r : in->reserved) if (r != 0) return fail(W2B_EINVAL, "w2b_set_tuning: reserved fields must be zero");
+  if (in->refresh_rows_u < -1 || in->refresh_rows_u > W2B_RC_MAX) return fail(W2B_EINVAL, "w2b_set_tuning: refresh_rows_u must be -1 .. 64");
   t->tune = *in;
   return W2B_OK;
 }
@@ -895,6 +905,58 @@ static bool groups_plan(const w2b_trainer *t, long long workers) {
   return w2b_groups_ok(probe);
 }
 
+// Rows 1..n of u that the row-group kernel reads at refreshed per-XCD copies (w2b_tuning.refresh_rows_u).  Measured
+// (profiles/r05_sessions/r05d_hot_reads.txt): what bounds the shared-row mode on a Zipf stream is not the adds to the hottest
+// context rows and not their reads, but the two ON THE SAME LINES -- a read of a line that the memory side is adding to
+// waits for the adds in front of it.  With the reads of the 4 hottest rows moved elsewhere the -size 200 stream runs at
+// 23.9 M words/s instead of 14.0 M at 256 workers.  A row is taken when `workers x uses per centre word` reaches
+// W2B_RC_LOAD -- about 25 rows of a 60 K-word Zipf vocabulary at 256 workers, 6 at 64, none at 8 and none for flat
+// vocabularies -- and only among the rows whose updates are lossless adds (a stored `copy value + e` would lose updates).
+static const double W2B_RC_LOAD = 8.0;
+static int rc_plan(const w2b_trainer *t, long long workers, int atomic_rank_u) {
+  const long long V = t->cfg.vocab_size;
+  long long n = 0;
+  if (t->tune.refresh_rows_u < 0) return 0;
+  if (t->tune.refresh_rows_u > 0) n = t->tune.refresh_rows_u;
+  else if (!t->counts.empty() && t->counts_tot_kept > 0) {
+    const double st = (double)t->cfg.sample * (double)t->cfg.train_words;
+    auto kept = [&](double c) { return (t->cfg.sample > 0 && st > 0) ? (c < sqrt(c * st) + st ? c : sqrt(c * st) + st) : c; };
+    while (n < W2B_RC_MAX && n + 1 < V &&
+           (double)workers * (t->cfg.window + 1) * kept((double)t->counts[(size_t)(n + 1)]) / t->counts_tot_kept >= W2B_RC_LOAD) n++;
+  }
+  if (n > W2B_RC_MAX) n = W2B_RC_MAX;
+  if (n > atomic_rank_u) n = atomic_rank_u;
+  if (n > V - 1) n = V - 1;
+  return (int)(n > 0 ? n : 0);
+}
+
+// buffer, flags and counters of the refreshed copies for one launch of the row-group kernel
+static int rc_prepare(w2b_trainer *t, W2bParams &p, long long workers) {
+  p.rc_rows = rc_plan(t, workers, p.atomic_rank_u);
+  p.rc = nullptr;
+  p.rc_flags = nullptr;
+  if (p.rc_rows <= 0) { p.rc_rows = 0; return W2B_OK; }
+  const size_t need = 64 + (size_t)W2B_NXCD * W2B_RC_MAX * t->cfg.layer1_size;     // 64 ints of flags, then the copies
+  if (need > t->rc_floats) {
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if (t->rc) HIPCHK(hipFree(t->rc));
+    t->rc = nullptr;
+    t->rc_floats = 0;
+    HIPCHK(hipMalloc(&t->rc, sizeof(float) * need));
+    t->rc_floats = need;
+  }
+  if (!t->rc_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&t->rc_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&t->rc_go, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&t->rc_end, hipEventDisableTiming));
+  }
+  HIPCHK(hipMemsetAsync(t->rc, 0, 64 * sizeof(int), t->stream));                    // claims and alive flags of this launch
+  HIPCHK(hipMemsetAsync(&t->shared->launch_done, 0, sizeof(int), t->stream));
+  p.rc_flags = reinterpret_cast<int *>(t->rc);
+  p.rc = t->rc + 64;
+  return W2B_OK;
+}
+
 // scratch rows of process_word_wide for `workgroups` workgroups (grown on demand)
 static int wide_prepare(w2b_trainer *t, W2bParams &p, long long workgroups) {
   if (!p.wide) return W2B_OK;
@@ -1060,9 +1122,19 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   t->x_words_full += (long long)max_positions * t->cfg.num_threads;
   HIPCHK(timing_begin(t));
   if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream, t->debug));
-  else if (groups_plan(t, t->cfg.num_threads) && w2b_groups_ok(p)) HIPCHK(w2b_launch_groups(p, max_positions, t->cfg.compute_loss != 0, t->stream));
+  else if (groups_plan(t, t->cfg.num_threads) && w2b_groups_ok(p)) {
+    if (int rc = rc_prepare(t, p, t->cfg.num_threads)) return rc;
+    if (p.rc_rows > 0) {               // the refresher runs beside the launch on its own stream and ends when the workers have
+      HIPCHK(hipEventRecord(t->rc_go, t->stream));
+      HIPCHK(hipStreamWaitEvent(t->rc_stream, t->rc_go, 0));
+      HIPCHK(w2b_launch_refresher(p, t->rc_stream));
+      HIPCHK(hipEventRecord(t->rc_end, t->rc_stream));
+    }
+    HIPCHK(w2b_launch_groups(p, max_positions, t->cfg.compute_loss != 0, t->stream));
+  }
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));
+  if (p.rc_rows > 0) HIPCHK(hipStreamWaitEvent(t->stream, t->rc_end, 0));   // (what follows on this stream also follows the refresher's end)
   HIPCHK(w2b_launch_xhot_fold(p, t->stream));      // the master rows are complete again when the stream is idle
   {   // progress snapshot of this launch for w2b_epoch_poll (asynchronous; pinned host memory)
     if (!t->poll_host) {
