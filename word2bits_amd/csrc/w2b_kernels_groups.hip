@@ -166,13 +166,26 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
   if (wave == NDW) {
     // ------------------------------------------------------------------------------------------ producer wavefront
     const int W = P.window, K = P.negative;
+    // unigram-table draws of the NEXT pass, requested at the end of a pass (lane l: draw l + 1).  Valid when the next pass
+    // stays inside the sentence: then its LCG ledger is one window draw, then the negative draws (ref :428,455) -- a sentence
+    // read in between (sub-sampling draws, ref :405) would move it.
+    int t_pref = 0;
+    bool pref_ok = false;
+    // LCG jump-ahead constants of this lane's draw (x_{n+d} = ja x_n + jc, d = lane + 1) and of the whole word's negative draws
+    const unsigned long long ja_l = P.jump_a[lane + 1 <= K ? lane + 1 : 0], jc_l = P.jump_c[lane + 1 <= K ? lane + 1 : 0];
+    const unsigned long long ja_k = P.jump_a[K], jc_k = P.jump_c[K];
     // one loop pass of TrainModelThread's scalar side (the wavefront-0 block of k_train_workers) into the lists O
     auto produce = [&](W2G_LDS GLists *O, const bool last) {
       unsigned long long rng = S->rng;
       long long cursor = S->cursor, wc = S->wc, last_wc = S->last_wc;
       int sen_len = S->sen_len, sen_pos = S->sen_pos, ovr = S->override_, eof = S->eof;
       int done = 0, cw = 0, nt = 0, ndup = 0;
+      // (requested first, used last: its round trip runs beside the unigram-table draws'.  The schedule below may store a new
+      // alpha in this very pass -- only every 10000 words of this worker, and the other workers' stores land at any time anyway)
+      const float alpha_now = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       float alpha = 0.f;
+      bool alpha_own = false;
+      float alpha_set = 0.f;
       if (!last) {
         if (wc - last_wc > 10000) {                                    // ref :379-393
           if (lane == 0) {
@@ -182,12 +195,16 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
             float a = P.starting_alpha * (1.f - (float)wca_all / (float)(P.iter * P.train_words + 1));
             if ((double)a < (double)P.starting_alpha * 0.0001) a = (float)((double)P.starting_alpha * 0.0001);
             __hip_atomic_store(&P.shared->alpha, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alpha_set = a;
           }
+          alpha_own = true;
+          alpha_set = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(alpha_set)));
           last_wc = wc;
         }
         if (sen_len == 0) {                                            // ref :394-413
           read_sentence(P, (int *)s_sen, rng, cursor, wc, ovr, eof, sen_len, lane);
           sen_pos = 0;
+          pref_ok = false;
           W2B_WAVE_SYNC();
         }
         if (eof || wc > P.train_words / P.total_threads) {            // ref :414-423 (local_iter == 1)
@@ -212,8 +229,8 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
             int t = 0;
             const int d = 1 + lane;
             if (d <= K) {
-              const unsigned long long x = lcg_jump(P, rng, d);
-              t = P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
+              const unsigned long long x = ja_l * rng + jc_l;
+              t = pref_ok ? t_pref : P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
               if (t == 0) t = (int)(x % (unsigned long long)(P.vocab_size - 1)) + 1;
               keep = (t != word);
             }
@@ -221,8 +238,8 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
             if (keep) O->tgt[1 + __popcll(m & lane_lt_mask(lane))] = t;
             if (lane == 0) O->tgt[0] = word;
             nt = 1 + __popcll(m);
-            rng = lcg_jump(P, rng, K);
-            alpha = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rng = ja_k * rng + jc_k;
+            alpha = alpha_own ? alpha_set : alpha_now;                // (a worker sees the alpha it has just stored, as the plain kernel's load after the store does)
             if (lane < W2G_TMAX) O->own[lane] = -1;
             W2B_WAVE_SYNC();
             // duplicates among the targets: occurrence number and first occurrence of every row
@@ -262,7 +279,14 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
           sen_pos++;                                                    // ref :505-509
           if (sen_pos >= sen_len) sen_len = 0;
         }
-      }
+        // the next pass's table draws (see t_pref); its window draw comes first
+        pref_ok = !done && sen_len != 0;
+        if (pref_ok && lane < K) {
+          const unsigned long long xb = rng * W2B_LCG_A + W2B_LCG_C;
+          const unsigned long long x = ja_l * xb + jc_l;
+          t_pref = P.table[fast_mod(x >> 16, (unsigned long long)P.table_size, P.table_magic)];
+        }
+      } else pref_ok = false;
       if (lane == 0) {
         S->rng = rng; S->cursor = cursor; S->wc = wc; S->last_wc = last_wc;
         S->sen_len = sen_len; S->sen_pos = sen_pos; S->override_ = ovr; S->eof = eof;
@@ -278,11 +302,11 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
       const W2G_LDS GLists *const L = &F->lists[it & 1];
       if (L->stop) break;
       const int cw = L->cw, npass = L->npass;
+      if (cw > 0) __syncthreads();                                      // B1
       W2G_TICK(1);
-      produce(&F->lists[(it + 1) & 1], it + 1 >= max_positions);        // (under the data wavefronts' wait for their rows)
+      produce(&F->lists[(it + 1) & 1], it + 1 >= max_positions);        // (under the data wavefronts' wait for their target rows)
       W2G_TICK(0);
       if (cw > 0) {
-        __syncthreads();                                                // B1
         if (RW > 1) for (int ps = 0; ps < npass; ps++) __syncthreads();
         __syncthreads();                                                // B3
         __syncthreads();                                                // B4
@@ -351,6 +375,7 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
     const bool active = col0 < dim;
     constexpr int CA = (W2G_CMAX + G - 1) / G;                          // context rows per group
     constexpr int CB = (G == 3) ? 6 : 4;                                // ... loaded per trip (2 window <= 16: one trip)
+    constexpr int LA = (RW == 4) ? 2 : 4, LE = (RW == 4) ? 4 : 8;       // LDS rows read ahead in the window average / the error sum
     const unsigned tab_bytes = P.tab_bytes;
     __syncthreads();                                                    // B0
     for (long long it = 0;; ++it) {
@@ -374,7 +399,7 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
           idx[k] = __builtin_amdgcn_readlane(mine, k);
           rows[k] = __builtin_amdgcn_readlane(trow, k);
         }
-        for (int j0 = 0; j0 == 0 || g + j0 * G < cw; j0 += CB) {    // (the first trip also issues the target loads)
+        for (int j0 = 0; g + j0 * G < cw; j0 += CB) {
           Col<4> r[CB];
 #pragma unroll
           for (int jj = 0; jj < CB; jj++) {
@@ -386,14 +411,6 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
               else r[jj] = load_col<4, 0, 0>(P.u, crow, dim, col0, tab_bytes);
             }
           }
-          if (j0 == 0) {
-#pragma unroll
-            for (int k = 0; k < TC; k++) {
-#pragma unroll
-              for (int e = 0; e < 4; e++) x[k].e[e] = 0.f;
-              if (idx[k] >= 0 && active) x[k] = load_col<4, 0, 0>(P.v, rows[k], dim, col0, tab_bytes);
-            }
-          }
 #pragma unroll
           for (int jj = 0; jj < CB; jj++) {
             const int j = g + (j0 + jj) * G;
@@ -403,13 +420,38 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
         W2G_TICK(4);
         __syncthreads();                                                // B1
         W2G_TICK(5);
-        // ---- phase A: context_avg = (1/cw) * sum_j quantize(u[ctx_j]), window order (ref :431-449)
+        // ---- the target rows are requested only now: a target row is open (read -> dot product -> update -> store) for one
+        // memory round trip + its own arithmetic, not for the context rows' round trip as well.  What a racy shared row costs
+        // in epoch loss grows with throughput x the time it is open (measured: heldout_zipf12 at 256 workers -1.6 % with the
+        // targets requested beside the context rows, -1.1 % like this; planted corpus, configs[2] shape, 8 workers: +2.6 % / +1.3 %)
+#pragma unroll
+        for (int k = 0; k < TC; k++) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) x[k].e[e] = 0.f;
+          if (idx[k] >= 0 && active) x[k] = load_col<4, 0, 0>(P.v, rows[k], dim, col0, tab_bytes);
+        }
+        // ---- phase A: context_avg = (1/cw) * sum_j quantize(u[ctx_j]), window order (ref :431-449); LDS reads LA rows ahead
         Col<4> avg;
 #pragma unroll
         for (int e = 0; e < 4; e++) avg.e[e] = 0.f;
         if (active) {
-          for (int j = 0; j < cw; j++) {
-            const Col<4> c = lds_ld4(stash + j * dim + col0);
+          int j0 = 0;
+          for (; j0 + LA <= cw; j0 += LA) {                            // whole trips: straight-line code
+            Col<4> c[LA];
+#pragma unroll
+            for (int jj = 0; jj < LA; jj++) c[jj] = lds_ld4(stash + (j0 + jj) * dim + col0);
+#pragma unroll
+            for (int jj = 0; jj < LA; jj++) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float q = quant<QM>(c[jj].e[e], qp);
+                avg.e[e] += q;
+                if (LOSS && reg_on && g == 0) regsq += q * q;
+              }
+            }
+          }
+          for (; j0 < cw; j0++) {
+            const Col<4> c = lds_ld4(stash + j0 * dim + col0);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
               const float q = quant<QM>(c.e[e], qp);
@@ -423,6 +465,7 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
 #pragma unroll
           for (int e = 0; e < 4; e++) avg.e[e] = active ? avg.e[e] / cwf : 0.f;   // ref :449
         }
+
         // one target: gradient scalar known -> quantized row to LDS (error accumulation), row update (ref :486-491)
         auto finish_row = [&](const int i, const int row, const float gk, Col<4> xr) {
           const bool by_add = row <= atomic_rank_v;                    // (uniform) lossless add of the delta instead of a store
@@ -535,12 +578,30 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
         Col<4> err;
 #pragma unroll
         for (int e = 0; e < 4; e++) err.e[e] = 0.f;
-        for (int i = 0; i < nt; i++) {
-          const float gi = F->gs[i];
-          if (active) {
-            const Col<4> c = lds_ld4(xq + i * dim + col0);
+        {
+          const float gv = (lane < nt) ? F->gs[lane] : 0.f;             // lane i: g of target i (negative + 1 <= 32)
+          int i0 = 0;
+          for (; i0 + LE <= nt; i0 += LE) {                             // whole trips: straight-line code, LDS reads LE rows ahead
+            Col<4> c[LE];
 #pragma unroll
-            for (int e = 0; e < 4; e++) err.e[e] += gi * c.e[e];
+            for (int ii = 0; ii < LE; ii++)
+              if (active) c[ii] = lds_ld4(xq + (i0 + ii) * dim + col0);
+#pragma unroll
+            for (int ii = 0; ii < LE; ii++) {
+              const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), i0 + ii));
+              if (active) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) err.e[e] += gi * c[ii].e[e];
+              }
+            }
+          }
+          for (; i0 < nt; i0++) {
+            const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), i0));
+            if (active) {
+              const Col<4> c = lds_ld4(xq + i0 * dim + col0);
+#pragma unroll
+              for (int e = 0; e < 4; e++) err.e[e] += gi * c.e[e];
+            }
           }
         }
         if (g == 0 && active) lds_st4(errbuf + col0, err);

@@ -906,13 +906,17 @@ static bool groups_plan(const w2b_trainer *t, long long workers) {
 }
 
 // Rows 1..n of u that the row-group kernel reads at refreshed per-XCD copies (w2b_tuning.refresh_rows_u).  Measured
-// (profiles/r05_sessions/r05d_hot_reads.txt): what bounds the shared-row mode on a Zipf stream is not the adds to the hottest
-// context rows and not their reads, but the two ON THE SAME LINES -- a read of a line that the memory side is adding to
-// waits for the adds in front of it.  With the reads of the 4 hottest rows moved elsewhere the -size 200 stream runs at
-// 23.9 M words/s instead of 14.0 M at 256 workers.  A row is taken when `workers x uses per centre word` reaches
-// W2B_RC_LOAD -- about 25 rows of a 60 K-word Zipf vocabulary at 256 workers, 6 at 64, none at 8 and none for flat
-// vocabularies -- and only among the rows whose updates are lossless adds (a stored `copy value + e` would lose updates).
-static const double W2B_RC_LOAD = 8.0;
+// (profiles/r05_sessions/): what bounds the shared-row mode on a Zipf stream is neither the adds to the hottest context rows
+// nor their reads, but the two ON THE SAME LINES -- a read of a line that the memory side is adding to waits for the adds in
+// front of it (about 50 ns per operation on the hottest line, whatever the row length: 13-15 M words/s at -size 200 ... 1000).
+// With the reads of the 4 hottest rows moved to copies the -size 200 stream runs at 22 M words/s instead of 14 M at 256
+// workers.  The price is freshness: a copy lags its master row by a refresher sweep (a few us), which adds to the staleness
+// of exactly the rows that are updated most often -- heldout_zipf12 at 256 workers: -1.1 % of the reference's epoch loss
+// without copies, -1.35 % with 4, -2.7 % with 16, -3.9 ... -5.6 % with ~25.  So only the very hottest rows are taken: a row
+// whose load `workers x uses per centre word` reaches W2B_RC_LOAD -- 4-5 rows of a Zipf(1) vocabulary at 256 workers, 1 at
+// 64, none below 40 workers and none on flat vocabularies -- and only among the rows whose updates are lossless adds (a
+// stored `copy value + e` would lose every update since the last refresh).
+static const double W2B_RC_LOAD = 40.0;
 static int rc_plan(const w2b_trainer *t, long long workers, int atomic_rank_u) {
   const long long V = t->cfg.vocab_size;
   long long n = 0;

@@ -51,6 +51,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int atomic_cap = -1;                 // -atomic-cap N: most rows the automatic choice takes
   int atomic_rank_u = 0;               // -atomic-rank-u N: w2b_tuning.atomic_rank_u (0 = as -atomic-rank, -1 = none)
   int fresh_rank_u = 0;                // -fresh-rank-u N: w2b_tuning.fresh_rank_u (0 = the library decides, -1 = none)
+  int refresh_rows_u = 0;              // -refresh-rows N: w2b_tuning.refresh_rows_u (0 = the library decides, -1 = none)
   std::string packed_file;             // -packed FILE: also write the final vectors bit-packed (-bitlevel 1 / 2; word2bits_corpus.h)
   int row_desc = 0;                    // -row-desc 1: the row addressing of tables >= 2 GiB on any table (w2b_tuning.force_row_desc)
 };
@@ -208,6 +209,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-atomic-cap", argc, argv)) > 0) o.atomic_cap = atoi(argv[i + 1]);
   if ((i = arg_pos("-atomic-rank-u", argc, argv)) > 0) o.atomic_rank_u = atoi(argv[i + 1]);
   if ((i = arg_pos("-fresh-rank-u", argc, argv)) > 0) o.fresh_rank_u = atoi(argv[i + 1]);
+  if ((i = arg_pos("-refresh-rows", argc, argv)) > 0) o.refresh_rows_u = atoi(argv[i + 1]);
   if ((i = arg_pos("-hot-weight", argc, argv)) > 0) o.hot_weight = atoi(argv[i + 1]);
   if ((i = arg_pos("-window-refresh", argc, argv)) > 0) o.window_refresh = atoi(argv[i + 1]);
 
@@ -310,7 +312,7 @@ int main(int argc, char **argv) {
     cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
-    if (o.hot_rows >= 0 || o.hot_rows_u >= 0 || o.hot_rows_v >= 0 || o.hot_cap >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0 || o.atomic_rank_u != 0 || o.fresh_rank_u != 0) {
+    if (o.hot_rows >= 0 || o.hot_rows_u >= 0 || o.hot_rows_v >= 0 || o.hot_cap >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0 || o.atomic_rank_u != 0 || o.fresh_rank_u != 0 || o.refresh_rows_u != 0) {
       w2b_tuning tn;
       CK(w2b_get_tuning(a->r->t, &tn));
       if (o.hot_rows >= 0) tn.hot_rows_v = tn.hot_rows_u = o.hot_rows;
@@ -325,6 +327,7 @@ int main(int argc, char **argv) {
       if (o.window_refresh >= 0) tn.window_refresh = o.window_refresh;
       if (o.atomic_rank_u != 0) tn.atomic_rank_u = o.atomic_rank_u;
       if (o.fresh_rank_u != 0) tn.fresh_rank_u = o.fresh_rank_u;
+      if (o.refresh_rows_u != 0) tn.refresh_rows_u = o.refresh_rows_u;
       CK(w2b_set_tuning(a->r->t, &tn));
     }
     CK(w2b_init_net(a->r->t));                              // ref :528
