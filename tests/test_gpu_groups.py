@@ -96,10 +96,19 @@ def test_row_group_kernel_falls_back_where_it_does_not_fit(gpu):
         t.set_vocab_counts(np.full(V, 50, np.int64), 0)
         assert t.worker_kernel_name() == "plain", kw
         t.close()
-    t = w2b.Trainer(V, 200, 8, 24, 1, num_threads=4, train_words=10000)          # automatic: short rows run the row groups
-    t.set_vocab_counts(np.full(V, 50, np.int64), 0)
-    assert t.worker_kernel_name() == "groups"
-    t.close()
+    # automatic: short rows run the row groups -- unless the fidelity budget is thin already (w2b_trainer.cpp groups_plan):
+    # shards shorter than 50 000 words per worker, or a vocabulary so small and flat that every row collides
+    Vz = 60000
+    zipf = np.maximum(5, (3e7 / (np.arange(Vz) + 1.0))).astype(np.int64)
+    zipf[0] = 0
+    for kw, want in ((dict(), "groups"), (dict(layer1_size=800), "plain"), (dict(train_words=256 * 40000), "plain"),
+                     (dict(flat=True, train_words=10 ** 9), "plain")):
+        D = kw.get("layer1_size", 200)
+        cn = np.full(2000, 300, np.int64) if kw.get("flat") else zipf
+        t = w2b.Trainer(len(cn), D, 8, 24, 1, num_threads=256, train_words=kw.get("train_words", int(cn.sum())))
+        t.set_vocab_counts(cn, 0)
+        assert t.worker_kernel_name() == want, kw
+        t.close()
     t = w2b.Trainer(V, 200, 8, 24, 1, num_threads=4, train_words=10000, row_groups=False)
     assert t.worker_kernel_name() == "plain"
     t.close()

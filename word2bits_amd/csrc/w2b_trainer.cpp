@@ -890,13 +890,32 @@ static int atomic_plan_u(const w2b_trainer *t, long long workers, int atomic_ran
 // rows off the data wavefronts' path.  It implements the SHARED-ROW rules only (every row at its master address, context
 // rows 1..atomic_rank_u by lossless adds) -- what the library runs below a full device (xhot_plan) -- for 16-byte
 // columns up to -size 1024, window <= 16, negative + 1 <= 27/28, tables below 2 GiB.  plain_worker_kernel: 3 = wherever it
-// fits, 1 / 2 = never; 0 = automatic: wherever it fits and rows are at most W2B_GROUPS_AUTO_DIM floats long (at -size 800 a
-// row already fills four wavefronts and the plain kernel keeps 4 workgroups per CU; measured).
+// fits, 1 / 2 = never; 0 = automatic:
+//   * rows of at most W2B_GROUPS_AUTO_DIM floats (at -size 800 a row already fills four wavefronts, a worker is a 14-wavefront
+//     workgroup and its own latency, not the rows, bounds it: 14.7 M words/s at 256 workers where the plain kernel does 10 and
+//     a full device 26);
+//   * and only where the fidelity budget is not already thin.  With Hogwild rows what a kernel costs in epoch loss grows
+//     with its THROUGHPUT x the time a row is open (measured, profiles/r05_sessions/: at equal words/s the two kernels are
+//     equally far from the reference; the row-group kernel at equal worker counts is about twice as fast and 0.3 ... 0.8 %
+//     further off).  Two regimes sit at the 1.5 % floor with the plain kernel already: vocabularies so small and flat that
+//     every row collides (the quantity atomic_plan uses: 0.6 x workers x rate of the least frequent row, an eighth of
+//     W2B_ATOMIC_LOAD and more -- the planted corpus from 5 workers on), and shards shorter than the library's own guideline
+//     of W2B_WORDS_PER_WORKER_MIN words per worker and epoch (explicit -threads 256 on a 6-8 M-token corpus; the CLI warns
+//     there).  Both keep the plain kernel.
 static const int W2B_GROUPS_AUTO_DIM = 512;
+static const long long W2B_WORDS_PER_WORKER_MIN = 50000;
 static bool groups_plan(const w2b_trainer *t, long long workers) {
   const int mode = t->cfg.plain_worker_kernel;
   if (mode == 1 || mode == 2) return false;
-  if (mode == 0 && t->cfg.layer1_size > W2B_GROUPS_AUTO_DIM) return false;
+  if (mode == 0) {
+    if (t->cfg.layer1_size > W2B_GROUPS_AUTO_DIM) return false;
+    if (t->counts.empty() || t->counts_pw <= 0 || t->counts_tot <= 0) return false;      // (the rules below need the word counts)
+    const long long total = t->cfg.total_threads > 0 ? t->cfg.total_threads : workers;
+    if (t->cfg.train_words > 0 && t->cfg.train_words / (total > 0 ? total : 1) < W2B_WORDS_PER_WORKER_MIN) return false;
+    const double c = (double)t->counts[(size_t)(t->cfg.vocab_size - 1)];                   // the least frequent row (counts are sorted)
+    const double rate = t->cfg.negative * pow(c, 0.75) / t->counts_pw + c / t->counts_tot;
+    if (0.6 * (double)workers * rate >= W2B_ATOMIC_LOAD / 8) return false;
+  }
   W2bParams probe = make_params(t);
   int nu = 0, nv = 0;
   xhot_plan(t, workers, true, &nu, &nv, false);
@@ -1028,7 +1047,6 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
 // worker only every 10000 of its own words (ref :379-393), so short shards coarsen the schedule.  20000 in rounds 2-3; the
 // text8-sized corpus then ran 850 workers and ended its later epochs 2 % off the reference whatever the row-update
 // scheme (256 workers: 0.5 %), i.e. the cap, not a race, was what the gate saw.
-static const long long W2B_WORDS_PER_WORKER_MIN = 50000;
 extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
   NEED(t);
   if (!out) return fail(W2B_EINVAL, "w2b_suggested_threads: null");
