@@ -154,7 +154,7 @@ typedef struct w2b_tuning {
    * of workers (none for a few workers), -1 = none, > 0 = rows 1..N (at most 64, and never beyond the rows with lossless adds). */
   int32_t refresh_rows_u;
 } w2b_tuning;
-/* What the library decides for a launch of the plain worker kernel with `workers` concurrent workers on a GPU with `num_cus`
+/* What the library decides for a launch of the automatic worker kernel with `workers` concurrent workers on a GPU with `num_cus`
  * compute units, from the word counts alone (pure host arithmetic: usable -- and tested -- without a GPU): per-XCD copies
  * of the leading rows (none below a full device), rows updated by lossless adds, merge period.  tune = NULL: the defaults. */
 typedef struct w2b_row_plan {
@@ -162,6 +162,8 @@ typedef struct w2b_row_plan {
   int32_t atomic_rank_u, atomic_rank_v;/* rows 1..N of u / v updated by atomic adds (rows with copies excepted) */
   int32_t full_device;                 /* 1: >= 3 workgroups per compute unit */
   int32_t merge_period;                /* centre words between two merge events of a worker */
+  int32_t row_group_kernel;            /* round 5: 1 = the row-group worker kernel runs (short rows, fidelity budget not thin), 0 = the plain one */
+  int32_t refresh_rows_u;              /* round 5: context rows 1..N read at refreshed per-XCD copies (row-group kernel only) */
 } w2b_row_plan;
 int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, const int64_t *cn, int32_t num_cus, int32_t workers,
                   w2b_row_plan *out);

@@ -377,3 +377,33 @@ def test_row_rules_sub_sampling_and_flat_vocabularies():
     p = _plan(flat, 64, D=200)
     assert p["atomic_rank_v"] == p["atomic_rank_u"] == 2128 and p["copies_v"] == 0
     assert _plan(flat, 2, D=200)["atomic_rank_v"] == 0
+
+
+def test_row_rules_round5_kernel_choice_refreshed_copies_and_unsupported_shapes():
+    """round 5, still pure host arithmetic: (a) the row-group kernel is the automatic choice for rows of at most 512 floats
+    where the fidelity budget is not already thin -- not for shards below 50 000 words per worker, not for vocabularies so
+    small and flat that every row collides, not at -size 800; (b) with it, only the very hottest context rows are read at
+    refreshed copies (load rule 40: a handful at 256 workers, none at 32, never more than the rows with lossless adds);
+    (c) ADVICE r04: shapes without an atomics-capable kernel (16-byte columns beyond 1024 floats, relaxed rows) report NO
+    lossless rows, explicit ranks included -- the plan says what runs."""
+    V = 70_000
+    cn = np.maximum((1.45e6 / np.arange(1, V + 1)).astype(np.int64), 5)       # ~17 M tokens
+    cn[0] = 17_000
+    p = _plan(cn, 256, D=200)
+    assert p["row_group_kernel"] == 1 and 2 <= p["refresh_rows_u"] <= 8 and p["refresh_rows_u"] <= p["atomic_rank_u"]
+    assert _plan(cn, 32, D=200)["refresh_rows_u"] == 0 and _plan(cn, 32, D=200)["row_group_kernel"] == 1
+    assert _plan(cn, 256, D=200, refresh_rows_u=-1)["refresh_rows_u"] == 0
+    assert _plan(cn, 256, D=200, refresh_rows_u=64)["refresh_rows_u"] == 64
+    assert _plan(cn, 256, D=800)["row_group_kernel"] == 0                      # long rows: the plain kernel
+    assert _plan(cn, 512, D=200)["row_group_kernel"] == 0                      # 34 000 words per worker: shards too short
+    assert _plan(cn, 256, D=200, negative=30)["row_group_kernel"] == 0         # more targets than the groups hold
+    flat = np.full(2129, 30_000, np.int64)
+    assert _plan(flat, 8, D=400)["row_group_kernel"] == 0                      # every row collides: the budget is thin
+    # (c)
+    flat2 = np.full(2129, 300, np.int64)
+    assert _plan(flat2, 64, D=800)["atomic_rank_v"] == 2128
+    assert _plan(flat2, 64, D=1024, atomic_rank=100)["atomic_rank_v"] == 100     # the widest row with an ATOM instantiation
+    p = _plan(flat2, 64, D=2048, atomic_rank=100, atomic_rank_u=100)
+    assert p["atomic_rank_v"] == 0 and p["atomic_rank_u"] == 0
+    assert _plan(flat2, 64, D=200, mem_mode=1, atomic_rank_u=100)["atomic_rank_u"] == 0
+    assert _plan(flat2, 64, D=200, atomic_rank_u=100)["atomic_rank_u"] == 100

@@ -110,6 +110,7 @@ struct w2b_trainer {
   long long xchunk = 0;                     // floats per chunk
   hipEvent_t x_train = nullptr;             // "the launches issued so far": the exchange streams wait for it
   hipEvent_t x_done[2] = {nullptr, nullptr};     // last operation of the latest exchange on each exchange stream
+  bool x_any_done = false;                       // x_done[] have been recorded at least once
   bool x_pending = false;                   // the training stream has not yet waited for x_done
   std::vector<hipEvent_t> x_ev;             // (begin, end) pairs of the exchanges since the last w2b_sync_stats
   long long sync_count = 0;
@@ -826,12 +827,20 @@ static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int 
 // (0.6 x workers x rate >= W2B_ATOMIC_LOAD) and the tables are cache-sized, none otherwise; atomic_cap > 0 limits the
 // number of rows.
 static const double W2B_ATOMIC_LOAD = 0.25;
-static int atomic_plan(const w2b_trainer *t, long long workers) {
-  int wide = 0;
-  (void)w2b_block_threads(t->cfg.layer1_size, nullptr, &wide);
-  if (t->cfg.exact_reduction || wide) return 0;
+// Is there a kernel that honours atomic ranks for this trainer?  Coherent rows, fast reduction, one thread per column; with
+// 16-byte columns only the workgroups of at most 256 threads have the ATOM instantiations (-size <= 1024; the row-group
+// kernel covers the same range).  Everywhere else the plans below return 0 -- for explicit ranks too -- so that
+// w2b_plan_rows / w2b_worker_kernel_info describe what runs (round 4 reported ranks that the kernels silently ignored).
+static bool atomics_supported(const w2b_trainer *t) {
+  int wide = 0, vec = 0;
+  const int threads = w2b_block_threads(t->cfg.layer1_size, &vec, &wide);
   const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
-  if (mem_mode != 0) return 0;
+  if (t->cfg.exact_reduction || wide || mem_mode != 0) return false;
+  if (vec == 4 && threads > 256) return false;
+  return true;
+}
+static int atomic_plan(const w2b_trainer *t, long long workers) {
+  if (!atomics_supported(t)) return 0;
   const long long V = t->cfg.vocab_size;
   long long n = 0;
   if (t->tune.atomic_rank >= 0) n = t->tune.atomic_rank;
@@ -860,12 +869,9 @@ static int atomic_plan(const w2b_trainer *t, long long workers) {
 // cost 1-2 % of the throughput in the transposed 16-byte-column form (add_col_contig).
 static int atomic_plan_u(const w2b_trainer *t, long long workers, int atomic_rank_v) {
   const long long V = t->cfg.vocab_size;
+  if (!atomics_supported(t)) return 0;                             // (before an explicit rank: relaxed rows + agent-scope adds do not mix)
   if (t->tune.atomic_rank_u > 0) return (int)(t->tune.atomic_rank_u < V - 1 ? t->tune.atomic_rank_u : V - 1);
   if (t->tune.atomic_rank_u < 0) return 0;
-  int wide = 0;
-  (void)w2b_block_threads(t->cfg.layer1_size, nullptr, &wide);
-  const int mem_mode = t->tune.mem_mode >= 0 ? t->tune.mem_mode : t->cfg.relaxed_coherence;
-  if (t->cfg.exact_reduction || wide || mem_mode != 0) return atomic_rank_v;
   if (t->tune.atomic_rank >= 0) return atomic_rank_v;            // an explicit atomic_rank speaks for both tables (round-3 meaning)
   // full device with per-XCD copies: the rows that matter are at their copies, and adds for the rows below them cost 7 % of
   // the throughput for nothing measurable (+0.37 % against -0.09 % of the reference's loss)
@@ -1115,6 +1121,10 @@ extern "C" int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, cons
   out->atomic_rank_u = atomic_plan_u(&t, workers, out->atomic_rank_v);
   out->full_device = full_device(&t, workers) ? 1 : 0;
   out->merge_period = t.tune.hot_period > 0 ? t.tune.hot_period : 32;
+  t.cfg.num_threads = workers;
+  t.table_elems = (long long)cfg->vocab_size * cfg->layer1_size;
+  out->row_group_kernel = groups_plan(&t, workers) ? 1 : 0;
+  out->refresh_rows_u = out->row_group_kernel ? rc_plan(&t, workers, out->atomic_rank_u) : 0;
   return W2B_OK;
 }
 
@@ -1333,6 +1343,7 @@ static void xchg_teardown(w2b_trainer *t) {
   if (t->x_train) (void)hipEventDestroy(t->x_train);
   if (t->x_evc) (void)hipEventDestroy(t->x_evc);
   t->x_train = t->x_evc = nullptr;
+  t->x_any_done = false;
   if (t->xcnt) (void)hipFree(t->xcnt);
   if (t->base) (void)hipFree(t->base);
   t->xcnt = nullptr;
@@ -1484,6 +1495,11 @@ static int xchg_begin(w2b_trainer *t, int hot_u, int hot_v) {
   // the exchange sees every launch issued so far (and nothing forces the launches issued later to wait for a FULL exchange)
   HIPCHK(hipEventRecord(t->x_train, t->stream));
   for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->xs[k], t->x_train, 0));
+  // ... and follows the PREVIOUS exchange on both of its streams: the collective stream's first operations of this exchange
+  // (word counts, per-row contributor counts: they read `base`, write `xcnt`) must not run beside the previous exchange's
+  // last apply on the elementwise stream (reads `xcnt`, writes `base`).  x_done[0] is recorded after the elementwise stream
+  // has waited for the collective one (xchg_end), so it covers both.
+  if (t->x_any_done) for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->xs[k], t->x_done[0], 0));
   hipEvent_t a, b;
   HIPCHK(hipEventCreate(&a));
   HIPCHK(hipEventCreate(&b));
@@ -1541,6 +1557,7 @@ static int xchg_end(w2b_trainer *t) {
   HIPCHK(hipStreamWaitEvent(t->xs[0], t->x_done[1], 0));
   HIPCHK(hipEventRecord(t->x_ev.back(), t->xs[0]));
   HIPCHK(hipEventRecord(t->x_done[0], t->xs[0]));
+  t->x_any_done = true;
   t->x_open = false;
   t->x_pending = true;
   // a hot-tier exchange moves a few MB of exactly the rows the next launch's hot-row folds and merges work on: the next
