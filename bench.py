@@ -103,6 +103,9 @@ def parse():
     ap.add_argument("--window-cache", type=int, default=-1,
                     help="worker form: -1 = automatic, 1 = sentence-resident kernel (context window rows stay in "
                          "LDS), 0 = plain kernel")
+    ap.add_argument("--row-groups", type=int, default=-1,
+                    help="worker form: -1 = automatic, 1 = the row-group worker kernel wherever it fits, 0 = never")
+    ap.add_argument("--refresh-rows", type=int, default=0, help="w2b_tuning.refresh_rows_u (0 = library default, -1 = none)")
     ap.add_argument("--relaxed", type=int, default=0,
                     help="1: plain cached row accesses (not coherent between XCDs); default 0 = agent-scope (sc1)")
     ap.add_argument("--hot-rows", type=int, default=-1,
@@ -119,6 +122,15 @@ def parse():
     ap.add_argument("--eval-kind", choices=["1bit", "fp"], default="1bit")
     ap.add_argument("--eval-cpu-questions", type=int, default=24)
     return ap.parse_args()
+
+
+def latest_profile(name):
+    """profiles/rNN_<name> of the newest round that has it (committed measurements that this script quotes, never re-labels)"""
+    for rnd in ("r05", "r04", "r03"):
+        f = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))
+        if os.path.exists(f):
+            return f
+    return os.path.join(ROOT, "profiles", "r05_%s" % name)
 
 
 def algorithmic_bytes_per_word(D, cw, K):
@@ -402,27 +414,33 @@ def other_shapes():
         # 52 M tokens on -- 60 M here; the text8-shaped legs below keep a stream that leaves the device partly filled)
         "cfg5_b1": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "1", "--tokens", "60000000"],
         "cfg5_b0": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "0", "--tokens", "60000000"],
+        # text8-shaped legs: a 30 M-token stream leaves the device partly filled (-threads 0 = 256 workers); automatic = the
+        # row-group kernel since round 5 (every row shared, lossless context rows, the very hottest context rows read at
+        # refreshed copies); the plain kernel (round 4's automatic choice) beside it
         "d200": ["--vocab", "60238", "--dim", "200"],
         "d400_b2": ["--vocab", "60238", "--dim", "400", "--bitlevel", "2"],
-        # the sentence-resident kernel (context window rows stay in LDS): the faster kernel at these shapes, an explicit
-        # choice since round 4 (./word2bits -window-cache 1) because it keeps context rows private for up to 2 x window + 1
-        # positions and is up to 13 % off the reference's epoch loss on a held-out regime
+        "d200_plain": ["--vocab", "60238", "--dim", "200", "--row-groups", "0"],
+        "d400_b2_plain": ["--vocab", "60238", "--dim", "400", "--bitlevel", "2", "--row-groups", "0"],
+        # what a user of ./word2bits -threads 0 gets on a file too short for a full device: the headline shape on a 22 M-token stream
+        "partial_device": ["--tokens", "22000000"],
+        # the sentence-resident kernel (context window rows stay in LDS): an explicit choice since round 4 (./word2bits
+        # -window-cache 1) because it keeps context rows private for up to 2 x window + 1 positions and is up to 13 % off the
+        # reference's epoch loss on a held-out regime
         "cfg5_b1_resident": ["--vocab", "3700000", "--dim", "1000", "--negative", "12", "--bitlevel", "1", "--window-cache", "1", "--tokens", "60000000"],
         "d200_resident": ["--vocab", "60238", "--dim", "200", "--window-cache", "1"],
-        "d400_b2_resident": ["--vocab", "60238", "--dim", "400", "--bitlevel", "2", "--window-cache", "1"],
     }
     # tables of 48 / 96 MB live in the 256 MB Infinity Cache: HBM's 8 TB/s is not what bounds those legs.  The bound quoted
     # beside it is what the memory system sustains for the same access shape (random rows, 16 bytes per lane, sc1 read +
     # write) on a cache-sized table: tools/row_probe small, measured in the round's profile session
     cache_bound = {}
     try:
-        cache_bound = json.load(open(os.path.join(ROOT, "profiles", "r04_cache_bound.json")))
+        cache_bound = json.load(open(latest_profile("cache_bound.json")))
     except Exception:
         pass
     out = {}
     for name, extra in legs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--tokens", "30000000", "--steps", "10", "--warmup", "3",
-               "--cpu-baseline", "none", "--also-relaxed", "0", "--also-legs", "0", "--also-shapes", "0"] + extra
+               "--cpu-baseline", "none", "--also-relaxed", "0", "--also-legs", "0", "--also-shapes", "0"] + extra   # (a later --tokens wins)
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -430,7 +448,8 @@ def other_shapes():
             out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                          "roofline_frac": d["roofline"]["frac"], "achieved_GBps": d["roofline"]["achieved"],
                          "kernel": d["roofline"]["kernel"], "avg_launch_ms": d["roofline"]["avg_launch_ms"],
-                         "workload": d["config"]["workload"], "worker_kernel": d["config"].get("worker_kernel")}
+                         "workload": d["config"]["workload"], "worker_kernel": d["config"].get("worker_kernel"),
+                         "workers": d["config"].get("workers"), "us_per_word_per_worker": d.get("us_per_word_per_worker")}
             cb = cache_bound.get(name.replace("_resident", ""))
             if cb:
                 out[name]["cache_resident_bound_GBps"] = cb["GBps"]
@@ -558,11 +577,12 @@ def main():
     props = torch.cuda.get_device_properties(dev)
     ncu = props.multi_processor_count
     wcache = None if args.window_cache < 0 else bool(args.window_cache)
+    rgroups = None if args.row_groups < 0 else bool(args.row_groups)
     workers = args.workers
     if workers <= 0:          # ask the library how many workgroups of the worker kernel are resident at once
         probe = w2b.Trainer(V, D, W, K, args.bitlevel, num_threads=1, device=local_rank, sample=0.0,
                             train_words=train_words * world,
-                            relaxed_coherence=bool(args.relaxed), window_cache=wcache, compute_loss=bool(args.loss))
+                            relaxed_coherence=bool(args.relaxed), window_cache=wcache, row_groups=rgroups, compute_loss=bool(args.loss))
         probe.set_vocab_counts(counts, 0)         # which kernel runs (and how many workers fill the device) depends on the counts
         workers = probe.suggested_threads()
         probe.close()
@@ -589,13 +609,15 @@ def main():
         tune["atomic_rank_u"] = args.atomic_rank_u
     if args.fresh_rank_u != 0:
         tune["fresh_rank_u"] = args.fresh_rank_u
+    if args.refresh_rows != 0:
+        tune["refresh_rows_u"] = args.refresh_rows
 
     def make_trainer(relaxed, loss=bool(args.loss), bitlevel=args.bitlevel):
         tr = w2b.Trainer(V, D, W, K, bitlevel, num_threads=nw_local,
                          iter=1, alpha=0.05, sample=0.0, reg=0.0, train_words=train_words * world,
                          compute_loss=loss, device=local_rank, worker_offset=worker_offset,
                          total_threads=nw_local * world, relaxed_coherence=relaxed,
-                         window_cache=wcache, **tune)
+                         window_cache=wcache, row_groups=rgroups, **tune)
         tr.init_net()                                  # InitNet values (LCG seed 1), ref :343-361
         tr.set_vocab_counts(counts, 100_000_000)       # 1e8-entry unigram table, ref :112-128
         return tr
@@ -627,6 +649,7 @@ def main():
 
     nsteps = args.steps + args.warmup
     kinfo = None
+    kname = None
     if args.form == "tuples":
         B = args.batch
         need = nsteps * B
@@ -672,6 +695,7 @@ def main():
 
         prepare(t)
         kinfo = t.worker_kernel_info()
+        kname = t.worker_kernel_name()
         positions = args.positions if args.positions > 0 else max(1, args.batch // workers)
         words_per_step = workers * positions
 
@@ -789,23 +813,26 @@ def main():
                                     (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl,
                    "exchanges_in_timed_region": n_syncs[0], "hot_tier_exchanges_in_timed_region": n_hot[0],
                    "worker_kernel": (dict(zip(("sentence_resident", "radius", "column_bytes", "workers_per_cu",
-                                               "hot_rows_with_xcd_copies"), kinfo)) if kinfo else None),
+                                               "hot_rows_with_xcd_copies"), kinfo), kernel=kname) if kinfo else None),
                    "tuning": tuning_used,
                    "workers": workers if args.form == "worker" else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
                      "kernel": "k_train_tuples" if args.form == "tuples" else
-                               ("k_train_resident" if kinfo and kinfo[0] else "k_train_workers"),
+                               ("k_train_resident" if kinfo and kinfo[0] else ("k_train_groups" if kname == "groups" else "k_train_workers")),
                      "algorithmic_bytes_per_word": bpw, "avg_launch_ms": avg_launch_s * 1e3,
                      "launches": launches,
                      "launch_ms_min_median_max": ([float(per_launch[0]), float(np.median(per_launch)), float(per_launch[-1])]
                                                   if len(per_launch) else None),
                      "loss_bookkeeping": bool(args.loss)},
     }
+    if args.form == "worker":
+        # one worker's pace beside one thread of the reference (cpu_baseline_configs0 / cpu_baseline_1thread)
+        result["us_per_word_per_worker"] = 1e6 * workers / (words_per_step / avg_launch_s)
     result["roofline"]["algorithmic_bytes_per_launch"] = words_per_step * bpw
     # HBM bytes per launch from the counters: collected by tools/gpu_profile_session.sh with rocprofv3 --pmc (separate
     # FETCH_SIZE / WRITE_SIZE passes of this same command) and committed; quoted only for the shape they were measured on
-    pmc = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % args.form)
+    pmc = latest_profile("pmc_%s.json" % args.form)
     if world == 1 and os.path.exists(pmc) and args.ids == "zipf" and not args.relaxed:
         try:
             pj = json.load(open(pmc))
@@ -816,6 +843,7 @@ def main():
                 result["roofline"]["traffic"] = per_word * words_per_step
                 result["roofline"]["traffic_GBps"] = per_word * words_per_step / avg_launch_s / 1e9
                 result["roofline"]["traffic_frac"] = per_word * words_per_step / avg_launch_s / HBM_PEAK
+                result["roofline"]["traffic_measured_in_this_run"] = False
                 result["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
                                                         "passes; factors calibrated on known row bytes, profiles/r04_pmc_calibration.json: "
                                                         "FETCH x2.00, WRITE x1.00 for sc1 rows) on this command, %d centre "
@@ -933,14 +961,25 @@ def main():
                     except OSError:
                         pass
         result["cpu_baseline"] = cb
-        # end-to-end wall times of ./word2bits and the reference program on one file (tools/e2e_compare.py, run in the
-        # round's profile session and committed): quoted, not re-measured here (the reference takes minutes)
-        e2e = os.path.join(ROOT, "profiles", "r04_e2e.json")
-        if world == 1 and os.path.exists(e2e) and workload_name(args).startswith("BASELINE configs[1]"):
+        # end-to-end wall times of ./word2bits and the reference program on one file (tools/e2e_compare.py): the GPU side
+        # (3 s) is measured in THIS run; the reference side (167 s on 256 host threads) is quoted from the committed file
+        if world == 1 and workload_name(args).startswith("BASELINE configs[1]") and args.also_shapes:
             try:
-                result["e2e"] = dict(json.load(open(e2e)), source="profiles/r04_e2e.json")
-            except Exception:
-                pass
+                quoted = json.load(open(latest_profile("e2e.json")))
+                tmp = os.path.join("/tmp", "w2b_e2e_%d.json" % os.getpid())
+                subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_compare.py"), tmp, "--only", "hip"],
+                               capture_output=True, timeout=300)
+                mine = json.load(open(tmp))
+                os.remove(tmp)
+                result["e2e"] = {"file": mine.get("file"), "flags": mine.get("flags"), "word2bits_hip": mine.get("word2bits_hip"),
+                                 "word2bits_hip_measured_in_this_run": True,
+                                 "reference": quoted.get("reference"), "reference_threads": quoted.get("reference_threads"),
+                                 "reference_source": "quoted from " + os.path.relpath(latest_profile("e2e.json"), ROOT)}
+                if mine.get("word2bits_hip") and quoted.get("reference"):
+                    result["e2e"]["speedup_total"] = round(quoted["reference"]["total_s"] / mine["word2bits_hip"]["total_s"], 1)
+                    result["e2e"]["speedup_train"] = round(quoted["reference"]["train_s"] / max(mine["word2bits_hip"]["train_s"], 1e-3), 1)
+            except Exception as e:
+                result["e2e"] = {"error": repr(e)[:200]}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -31,7 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from planted import make_planted, parse_accuracy                                      # noqa: E402
-from w2b_testlib import write_headline_corpus, write_zipf_text_corpus, write_heldout_corpus, HELDOUT   # noqa: E402
+from w2b_testlib import write_headline_corpus, write_zipf_text_corpus, write_heldout_corpus, HELDOUT, HELDOUT_BIG   # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
 
@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--text8size", default="64x2,256x2")
     ap.add_argument("--planted", default="8x3,64x3,512x3")
     ap.add_argument("--heldout", default="64x2,256x2", help="threads x runs for the held-out regimes (jobs heldout_k5, heldout_zipf12)")
+    ap.add_argument("--cfg1", default="256x1", help="threads x runs for job cfg1_100m: BASELINE configs[1] LITERALLY -- the 100 M-token stream "
+                                                    "bench.py times (every word 5x + 98 M Zipf(1) tokens), ~13 minutes of a 256-thread host per run")
+    ap.add_argument("--heldout-big", default="256x1", help="threads x runs for job heldout_k5_big (60 M tokens, ~5.5 minutes per run)")
     ap.add_argument("--tmp", default="/tmp/w2b_bands")
     a = ap.parse_args()
     os.makedirs(a.tmp, exist_ok=True)
@@ -142,6 +145,27 @@ def main():
             job["runs"] += run_many(corpus, flags, th, runs, a.tmp)
             flush()
         os.remove(corpus)
+    if "cfg1_100m" in jobs:               # round 5: the benchmarked setting itself, not its 22 M-token proxy
+        corpus = write_headline_corpus(os.path.join(a.tmp, "cfg1_100m.txt"), n_zipf=98_000_000)
+        fl = dict(bitlevel=1, size=800, window=8, negative=24, iter=1, sample=0)
+        flags = sum((["-" + k, str(v)] for k, v in fl.items()), []) + ["-min-count", "5", "-binary", "1"]
+        job = {"corpus": "write_headline_corpus(vocab=400000, n_zipf=98000000, seed=1234): BASELINE configs[1] literally", "flags": fl, "runs": []}
+        res["jobs"]["cfg1_100m"] = job
+        for th, runs in spec(a.cfg1):
+            job["runs"] += run_many(corpus, flags, th, runs, a.tmp, serial=True)
+            flush()
+        os.remove(corpus)
+    for name in HELDOUT_BIG:              # round 4 recorded ONE run of this; round 5 adds to it
+        if name in jobs:
+            corpus = write_heldout_corpus(os.path.join(a.tmp, name + ".txt"), name)
+            fl = HELDOUT_BIG[name]["flags"]
+            flags = sum((["-" + k, str(v)] for k, v in fl.items()), []) + ["-min-count", "5", "-binary", "1"]
+            job = {"corpus": "write_heldout_corpus(%r): %r" % (name, HELDOUT_BIG[name]["corpus"]), "flags": fl, "runs": []}
+            res["jobs"][name] = job
+            for th, runs in spec(a.heldout_big):
+                job["runs"] += run_many(corpus, flags, th, runs, a.tmp, serial=True)
+                flush()
+            os.remove(corpus)
     flush()
 
 
