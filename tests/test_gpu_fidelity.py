@@ -84,7 +84,10 @@ def loss_tolerance(job, threads, floor=FLOOR):
 def train(corpus, out, threads, flags, extra=()):
     # (W2B_FIDELITY_EXTRA: extra command-line flags for every run -- how the builder sessions re-run these tests under a
     # knob arm, e.g. "-atomic-rank 0"; never set by the driver)
-    extra = list(extra) + os.environ.get("W2B_FIDELITY_EXTRA", "").split()
+    hook = os.environ.get("W2B_FIDELITY_EXTRA", "").split()
+    if hook:                                            # never silent: a leaked variable would change what the gates measure
+        print("FIDELITY WARNING: W2B_FIDELITY_EXTRA adds %s to this run -- a builder session's knob arm, NOT the shipped defaults" % hook)
+    extra = list(extra) + hook
     args = [CLI, "-train", corpus, "-output", out, "-threads", str(threads), "-min-count", "5", "-binary", "1"]
     for k, v in flags.items():
         args += ["-" + k, str(v)]
@@ -144,8 +147,9 @@ def test_planted_matches_reference_at_equal_thread_count(gpu, planted, job, thre
         print("FIDELITY %s threads=%d %s: accuracy %.2f | reference %s +- %.1f" %
               (job, threads, kernel, acc["total"], acc_ref.tolist(), margin))
         check_losses("%s threads=%d %s" % (job, threads, kernel), job, threads, losses, floor)
-        if kernel == "auto":
-            assert acc_ref.min() - margin <= acc["total"] <= acc_ref.max() + margin, (kernel, acc["total"], acc_ref.tolist())
+        # (the sentence-resident kernel is an explicit choice with a looser loss bound; its accuracy is held to twice the margin)
+        m = margin if kernel == "auto" else 2 * margin
+        assert acc_ref.min() - m <= acc["total"] <= acc_ref.max() + m, (kernel, acc["total"], acc_ref.tolist())
 
 
 def test_more_workers_than_the_corpus_supports_is_warned_about(gpu, planted):
@@ -157,7 +161,7 @@ def test_more_workers_than_the_corpus_supports_is_warned_about(gpu, planted):
     corpus, questions, d = planted
     flags = BANDS["planted_b1_d200"]["flags"]
     losses, _, err = train(corpus, str(d / "w512.bin"), 512, flags, ["-window-cache", "0"])
-    assert "warning: -threads 512" in err and "-threads 0 picks at most" in err
+    assert "warning: -threads 512" in err and "picks at most" in err
     mean, _, _ = band("planted_b1_d200", 512)
     dev = (losses - mean) / np.abs(mean)
     print("FIDELITY planted_b1_d200 threads=512 plain: deviation %s %%" % np.round(100 * dev, 2).tolist())
@@ -208,12 +212,17 @@ def headline(tmp_path_factory):
     os.remove(corpus)
 
 
-@pytest.mark.parametrize("threads,ref_threads", [(0, 256), (1024, 256), (256, 256), (64, 64)])
+@pytest.mark.parametrize("threads,ref_threads", [(0, 256), (1024, 256), (768, 256), (440, 256), (256, 256), (64, 64)])
 def test_benchmarked_regime_matches_reference(gpu, headline, threads, ref_threads):
-    """BASELINE configs[1] -- what bench.py times: V = 400 K, size 800, window 8, negative 24, bitlevel 1, -sample 0.
-    `-threads 0` on this 22 M-token file is 256 workers (not enough words for a full device); 1024 is what bench.py runs on its 100 M-token
-    stream: a full device, the one case with per-XCD copies of the hottest rows (the CLI warns about the short shards; the
-    reference's band is its 256-thread one, the most the host runs at once); 256 and 64 against the same thread counts."""
+    """BASELINE configs[1] -- what bench.py times: V = 400 K, size 800, window 8, negative 24, bitlevel 1, -sample 0 -- on the
+    22 M-token proxy file (the literal 100 M-token setting: test_benchmarked_setting_literally_100m_tokens).  `-threads 0` on
+    this file is 256 workers (not enough words for a full device); 1024 is what bench.py runs: a full device, per-XCD copies of
+    the hottest rows (the CLI warns about the short shards; the reference's band is its 256-thread one, the most the host runs
+    at once).  The row policy is a step function of the worker count -- shared rows with lossless context rows up to 767
+    workers, copies from 768 -- and round 4 left the counts next to the step untested: 440 (measured in round 5: +1.34 / +1.37 %,
+    two runs) and 768 (-1.05 / -1.11 %) are asserted here with the same 1.5 % floor; 512 workers measure +1.51 % (one run) and are
+    NOT inside it -- between the reference's own scale (256) and a full device the shared-row mode drifts, which is why
+    `-threads 0` never picks such a count (w2b_suggested_threads)."""
     corpus, d = headline
     flags = BANDS["headline"]["flags"]
     losses, workers, _ = train(corpus, "/dev/null", threads, flags)
@@ -244,22 +253,41 @@ def test_held_out_regimes_match_reference(gpu, heldout, threads, ref_threads):
 def test_full_device_on_a_held_out_regime(gpu, tmp_path):
     """The per-XCD copies of the hottest rows exist only when a launch fills the device, and their consensus rule is a balance
     measured on the benchmarked regime.  This is that setting on a regime it was never measured on: heldout_k5 on a 60 M-token
-    stream, where `-threads 0` runs 1211 workers.  Band: ONE run of the unmodified reference at 256 threads (5.4 minutes of the
-    host; sigma of that regime on the small corpus: 0.06 %).  Measured (profiles/r04_sessions/r04j_heldout_full_device.txt):
-    +0.60 % with the copies, -0.001 % with `-hot-rows 0` (every row shared, lossless context rows) at the same 1211 workers."""
+    stream, where `-threads 0` runs 1211 workers.  Band: the unmodified reference at 256 threads on the GPU box's host (5.4
+    minutes per run; round 4 had ONE run, round 5 recorded another: the band is their mean, the tolerance max(3 sigma, FLOOR)).
+    Measured: +0.6 % with the copies, +0.0 ... +0.8 % with `-hot-rows 0` (every row shared, lossless context rows) at the same
+    1211 workers."""
     from w2b_testlib import write_heldout_corpus, HELDOUT_BIG
     job = "heldout_k5_big"
     corpus = write_heldout_corpus(str(tmp_path / "c.txt"), job)
     flags = BANDS[job]["flags"]
     assert flags == HELDOUT_BIG[job]["flags"]
-    ref = np.array(BANDS[job]["runs"][0]["epoch_losses"])
     try:
         for extra in ([], ["-hot-rows", "0"]):
             losses, workers, _ = train(corpus, "/dev/null", 0, flags, extra)
-            dev = (losses - ref) / np.abs(ref)
-            print("FIDELITY %s threads=0 (%d workers) %s: losses %s | reference @256 threads %s | deviation %s %%" %
-                  (job, workers, " ".join(extra) or "default", losses.tolist(), ref.tolist(), np.round(100 * dev, 2).tolist()))
             assert workers >= 768                                   # a full device: the copies are on in the default run
-            assert np.all(np.abs(dev) <= FLOOR), (extra, dev.tolist())
+            check_losses("%s threads=0 (%d workers) %s" % (job, workers, " ".join(extra) or "default"), job, 256, losses)
+    finally:
+        os.remove(corpus)
+
+
+def test_benchmarked_setting_literally_100m_tokens(gpu, tmp_path):
+    """BASELINE configs[1] LITERALLY -- the 100 M-token stream bench.py times, at the bench's own 1024 workers (97 K words per
+    worker) and as `-threads 0` picks them -- against the unmodified reference at 256 threads on the same file (job cfg1_100m:
+    13 minutes of the GPU box's 256-thread host per run; round 4 asserted this setting on a 22 M-token proxy file only).
+    One reference run: the tolerance is the FLOOR (the reference's 3 sigma on the proxy file is 0.3 %)."""
+    from w2b_testlib import write_headline_corpus
+    job = "cfg1_100m"
+    corpus = write_headline_corpus(str(tmp_path / "c.txt"), n_zipf=98_000_000)
+    flags = BANDS[job]["flags"]
+    ref = np.array([r["epoch_losses"] for r in BANDS[job]["runs"] if r["threads"] == 256]).mean(0)
+    try:
+        for threads in (1024, 0):
+            losses, workers, err = train(corpus, "/dev/null", threads, flags)
+            dev = (losses - ref) / np.abs(ref)
+            print("FIDELITY %s threads=%d (%d workers): losses %s | reference @256 threads %s | deviation %s %%" %
+                  (job, threads, workers, losses.tolist(), ref.tolist(), np.round(100 * dev, 2).tolist()))
+            assert workers >= 768 and "warning" not in err
+            assert np.all(np.abs(dev) <= FLOOR), (threads, dev.tolist())
     finally:
         os.remove(corpus)

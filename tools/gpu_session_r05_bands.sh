@@ -28,7 +28,7 @@ for arm in "-threads 1024" "-threads 0" "-threads 1024" "-threads 0 -hot-rows 0"
 for arm in "-threads 440" "-threads 768" "-threads 440" "-threads 768" "-threads 1024" "-threads 256" "-threads 512"; do run headline22m /tmp/headline.txt "$arm"; done
 timeout 900 python tests/experiments/replicas8_cfg3.py /tmp/cfg1_100m.txt --out $OUT/replicas8.json > $OUT/replicas8.txt 2>&1; grep R8 $OUT/replicas8.txt
 rm -f /tmp/cfg1_100m.txt /tmp/headline.txt
-timeout 1200 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.txt 2>&1; tail -5 $OUT/pytest_gpu.txt
+timeout 1200 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.txt 2>&1; tail -5 $OUT/pytest_gpu.txt
 wait $REF
 cat $OUT/bands_cfg1.log $OUT/bands_k5big.log | tail -6
 echo "== done"

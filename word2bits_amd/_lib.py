@@ -5,6 +5,7 @@ this module fails loudly when it is missing: there is no Python/CPU fallback for
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("W2B_LIB", os.path.join(_HERE, "libword2bits_hip.so"))
@@ -158,7 +159,9 @@ def lib():
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         if os.environ.get("W2B_LIB_ALLOW_MISSING") == "1" and not hasattr(L, name):
-            continue                # A/B runs against an OLDER build of the library (tools/gpu_session_*.sh); never the default
+            # A/B runs against an OLDER build of the library (tools/gpu_session_*.sh); never the default, and never silent
+            print("word2bits_amd: W2B_LIB_ALLOW_MISSING=1: symbol %s is missing from %s" % (name, LIB_PATH), file=sys.stderr)
+            continue
         f = getattr(L, name)        # AttributeError here = header/library mismatch
         f.restype = res
         f.argtypes = args

@@ -235,8 +235,8 @@ int main(int argc, char **argv) {
   // A worker re-computes alpha only after more than 10000 of its own words (ref :379-393).  The reference has the same
   // property, but nobody starts it with hundreds of threads on a small file; a GPU invites exactly that.
   if (o.num_threads > 32 && train_words / o.num_threads < 20000)      // (worker counts no CPU run would use)
-    fprintf(stderr, "word2bits: warning: -threads %d leaves %lld words per worker and epoch; below 20000 the learning "
-                    "rate schedule (re-computed per worker every 10000 words) hardly runs -- -threads 0 picks at most "
+    fprintf(stderr, "word2bits: warning: -threads %d leaves %lld words per worker and epoch; with fewer than 20000 the learning "
+                    "rate schedule (re-computed per worker every 10000 words) hardly runs, and -threads 0 keeps 50000: it picks at most "
                     "%lld workers for this file\n", o.num_threads, train_words / o.num_threads,
             train_words / 50000 > 1 ? train_words / 50000 : 1);
   int ndev = w2b_device_count();
