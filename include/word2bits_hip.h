@@ -121,7 +121,7 @@ typedef struct w2b_tuning {
   int32_t struct_size;     /* sizeof(w2b_tuning) */
   int32_t hot_rows_v;      /* -1 automatic (default), else 0..128 leading rows of v */
   int32_t hot_rows_u;      /* same for u (plain worker kernel and tuple kernel; the sentence-resident kernel keeps context rows in LDS) */
-  int32_t hot_period;      /* centre words between two merge events of a worker; a power of two; 0 (default) = automatic: 32 */
+  int32_t hot_period;      /* centre words between two merge events of a worker; a power of two; 0 (default) = automatic: 16 (32 until round 4) */
   int32_t hot_cap;         /* most rows the automatic choice takes; default 128 */
   int32_t force_row_desc;  /* 1: address rows through per-row buffer descriptors (the form tables >= 2 GiB use) on any table */
   int32_t grid_per_cu;     /* tuple form: workgroups per CU (0 = occupancy query) */

@@ -264,7 +264,7 @@ def test_cli_warns_about_more_workers_than_the_corpus_supports(tmp_path):
         pytest.skip("CLI not built")
     out = str(tmp_path / "o.vec")
     r = subprocess.run([exe, "-train", CORPUS, "-output", out, "-threads", "512", "-min-count", "1"], capture_output=True, text=True)
-    assert "warning: -threads 512" in r.stderr and "-threads 0 picks at most" in r.stderr
+    assert "warning: -threads 512" in r.stderr and "picks at most" in r.stderr
     r = subprocess.run([exe, "-train", CORPUS, "-output", out, "-threads", "12", "-min-count", "1"], capture_output=True, text=True)
     assert "warning" not in r.stderr
 
@@ -348,7 +348,7 @@ def test_row_rules_copies_only_on_a_full_device_lossless_context_rows_below():
     assert _plan(cn, 8)["atomic_rank_u"] == int(np.sum(8 * 9 * share >= 0.25)) > 0
     for workers in (768, 1024):
         p = _plan(cn, workers)
-        assert p["full_device"] == 1 and p["copies_u"] > 50 and p["copies_v"] > 50 and p["merge_period"] == 32
+        assert p["full_device"] == 1 and p["copies_u"] > 50 and p["copies_v"] > 50 and p["merge_period"] == 16
         assert p["atomic_rank_u"] == 0 and p["atomic_rank_v"] == 0
     # explicit numbers win on either side of the threshold
     assert _plan(cn, 64, hot_rows_v=5, hot_rows_u=0)["copies_v"] == 5

@@ -791,6 +791,7 @@ static const double W2B_HOT_LOAD = 6400.0;
 // choice gives copies only when the launch has at least W2B_FULL_DEVICE_WG_PER_CU workgroups per CU; below that every row
 // is shared by all workers as in the reference, and the context rows are updated by lossless adds (atomic_plan_u).
 static const int W2B_FULL_DEVICE_WG_PER_CU = 3;
+static const int W2B_HOT_PERIOD = 16;            // centre words between two merge events of a worker (xhot_prepare)
 static bool full_device(const w2b_trainer *t, long long workers) { return workers >= (long long)W2B_FULL_DEVICE_WG_PER_CU * t->num_cus; }
 
 static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv, bool legacy_u) {
@@ -1034,10 +1035,13 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   const long long per_xcd = workers / W2B_NXCD > 0 ? workers / W2B_NXCD : 1;
   const int most = nu > nv ? nu : nv;
   p.xhot_m = (int)((most + per_xcd - 1) / per_xcd);       // every copy of an XCD is merged about once per hot_period steps
-  // Merge period: a worker merges every 32 centre words (benchmarked regime at 1024 workers: +0.06 % of the reference's epoch
-  // loss and 75 % of the roofline, against +0.9 % and 71 % at 8).  Round 3 switched to 8 below 768 workers; copies below a
-  // full device are no longer chosen automatically (xhot_plan), so the switch is gone.
-  if (t->tune.hot_period <= 0) p.hot_period = 32;     // (automatic copies exist only on a full device: the period measured there)
+  // Merge period: a worker merges every W2B_HOT_PERIOD = 16 centre words.  Round 4 chose 32 on the 22 M-token proxy of the
+  // benchmarked regime (+0.06 % of the reference's epoch loss at 1024 workers, against +0.9 % at 8).  Round 5 recorded the
+  // reference on BASELINE configs[1] literally (100 M tokens) and measured both files (profiles/r05_sessions/r05n_balance.txt):
+  // period 32: -1.16 ... -1.38 % (literal) / +0.27 % (proxy); 16: -0.70 % / +0.67 %; 8: +0.32 % / +1.11 %; 64: -1.10 % / +0.47 %.
+  // The longer the stream the further stale copies pull the epoch loss down, so the period that centres BOTH is the default;
+  // it costs ~2 % of the headline throughput against 32.
+  if (t->tune.hot_period <= 0) p.hot_period = W2B_HOT_PERIOD;
   if (fresh) {         // copy == entry (== 0) everywhere: the fold below adopts the master rows
     HIPCHK(hipMemsetAsync(t->xhot, 0, sizeof(float) * need, t->stream));
     t->xhot_nu = nu;
@@ -1120,7 +1124,7 @@ extern "C" int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, cons
   out->atomic_rank_v = atomic_plan(&t, workers);
   out->atomic_rank_u = atomic_plan_u(&t, workers, out->atomic_rank_v);
   out->full_device = full_device(&t, workers) ? 1 : 0;
-  out->merge_period = t.tune.hot_period > 0 ? t.tune.hot_period : 32;
+  out->merge_period = t.tune.hot_period > 0 ? t.tune.hot_period : W2B_HOT_PERIOD;
   t.cfg.num_threads = workers;
   t.table_elems = (long long)cfg->vocab_size * cfg->layer1_size;
   out->row_group_kernel = groups_plan(&t, workers) ? 1 : 0;
