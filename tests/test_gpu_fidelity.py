@@ -289,5 +289,12 @@ def test_benchmarked_setting_literally_100m_tokens(gpu, tmp_path):
                   (job, threads, workers, losses.tolist(), ref.tolist(), np.round(100 * dev, 2).tolist()))
             assert workers >= 768 and "warning" not in err
             assert np.all(np.abs(dev) <= FLOOR), (threads, dev.tolist())
+        # An explicit count between the reference's scale and a full device: every row shared by all workers.  On a stream
+        # this long that mode drifts with the worker count (-0.5 / -0.8 / -3.6 / -11 % at 64 / 128 / 256 / 512 workers,
+        # profiles/r05_sessions/r05o_long_stream.txt) -- accepted with a warning that says so, recorded here, not gated.
+        losses, workers, err = train(corpus, "/dev/null", 256, flags)
+        dev = (losses - ref) / np.abs(ref)
+        print("FIDELITY %s threads=256 (%d workers, shared rows; NOT a gate): deviation %s %%" % (job, workers, np.round(100 * dev, 2).tolist()))
+        assert "drifts on long streams" in err and np.all(np.abs(dev) <= 0.08)
     finally:
         os.remove(corpus)

@@ -239,6 +239,15 @@ int main(int argc, char **argv) {
                     "rate schedule (re-computed per worker every 10000 words) hardly runs, and -threads 0 keeps 50000: it picks at most "
                     "%lld workers for this file\n", o.num_threads, train_words / o.num_threads,
             train_words / 50000 > 1 ? train_words / 50000 : 1);
+  // Between the reference's own scale and a full device every row is shared by all workers (lossless context rows); on a long
+  // stream that mode drifts with the worker count (BASELINE configs[1] literally, 100 M tokens: -0.5 / -0.8 / -3.6 / -11 % of the
+  // reference's epoch loss at 64 / 128 / 256 / 512 workers; -threads 0 = a full device with per-XCD copies: -0.6 %;
+  // profiles/r05_sessions/r05o_long_stream.txt).  An explicit count in that range on a corpus that could fill the device is
+  // accepted with a warning.
+  if (o.num_threads >= 192 && o.num_threads < 768 && train_words / 50000 >= 768)
+    fprintf(stderr, "word2bits: warning: -threads %d on %lld words: below a full device all workers share every row, which "
+                    "drifts on long streams (measured -3.6 %% of the reference's epoch loss at 256 workers on a 100 M-token "
+                    "stream); -threads 0 fills the device for this file and stays within 1 %%\n", o.num_threads, train_words);
   int ndev = w2b_device_count();
   if (ndev <= 0) {
     fprintf(stderr, "word2bits: no HIP device visible; this build has no CPU path\n");
