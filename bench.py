@@ -71,9 +71,6 @@ def parse():
     ap.add_argument("--sync-every", type=int, default=1,
                     help="N>1: steps between two full replica exchanges (1 = after every step, what ./word2bits -gpus N does: the "
                          "interval is what costs epoch loss, tests/test_gpu_exchange.py; 16 until round 4)")
-    ap.add_argument("--sync-hot-mb", type=int, default=0,
-                    help="N>1: after every step that has no full exchange, the hot tier -- at most this many MB of leading rows "
-                         "per table (w2b_sync_hot_rows; 0 = off, the default: on one GPU it measured no gain over the full exchanges alone)")
     ap.add_argument("--sync-mode", type=int, default=2,
                     help="0 delta-sum, 1 average, 2 contributor average (what ./word2bits -gpus N uses)")
     ap.add_argument("--sync-impl", choices=["lib", "torch"], default="lib",
@@ -715,17 +712,7 @@ def main():
 
     n_syncs = [0]
 
-    n_hot = [0]
-
-    def exchange(hot=False):
-        if hot:                 # the leading rows only (a few MB), rule of mode 2 over the short interval
-            horizon = args.sync_every * words_per_step
-            if torch_sync is not None:
-                torch_sync.sync_hot(horizon, args.sync_hot_mb << 20)
-            else:
-                t.sync_hot_rows(horizon, args.sync_hot_mb << 20)
-            n_hot[0] += 1
-            return
+    def exchange():
         if torch_sync is not None:
             torch_sync.sync()
         else:
@@ -741,8 +728,6 @@ def main():
                 done = i + 1 - args.warmup
                 if done % args.sync_every == 0 or i + 1 == n1:
                     exchange()
-                elif args.sync_hot_mb > 0:
-                    exchange(hot=True)
 
     run(0, args.warmup, False)
     if world > 1:
@@ -759,10 +744,8 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0 and torch_sync is None:
             raise SystemExit("library exchange failed after its communicator was created")
-        if args.sync_hot_mb > 0:
-            exchange(hot=True)                     # (first use of the hot tier stays out of the timed region as well)
         t.synchronize()
-        n_syncs[0] = n_hot[0] = 0
+        n_syncs[0] = 0
         t.sync_stats()
     t.synchronize()
     t.timing_enable(True)
@@ -811,7 +794,7 @@ def main():
                                     "agent scope (sc1): Hogwild coherent across the 8 XCD L2s",
                    "replica_sync": ("%s every %d steps, mode %d (0 delta-sum, 1 average, 2 contributor average)" %
                                     (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl,
-                   "exchanges_in_timed_region": n_syncs[0], "hot_tier_exchanges_in_timed_region": n_hot[0],
+                   "exchanges_in_timed_region": n_syncs[0],
                    "worker_kernel": (dict(zip(("sentence_resident", "radius", "column_bytes", "workers_per_cu",
                                                "hot_rows_with_xcd_copies"), kinfo), kernel=kname) if kinfo else None),
                    "tuning": tuning_used,
@@ -854,10 +837,11 @@ def main():
     if world > 1:
         result["replica_exchange"] = {
             "every_steps": args.sync_every, "mode": ["delta-sum", "average", "contributor average"][args.sync_mode],
-            "implementation": sync_impl, "exchanges": n_syncs[0], "hot_tier_exchanges": n_hot[0],
-            "hot_tier": ("after every other step: at most %d MB of leading rows per table, %s rows of u / v at this shape"
-                         % (args.sync_hot_mb, list(t.exchange_hot_rows(args.sync_every * words_per_step, args.sync_hot_mb << 20)))
-                         if args.sync_hot_mb > 0 else "off"),
+            "implementation": sync_impl, "exchanges": n_syncs[0],
+            # one full exchange moves the model through k_xchg_delta (4 model-sized passes) and k_xchg_apply (6): measured on one
+            # GPU through the phase API at this shape (8 replicas, tests/experiments/replicas8_cfg3.py, profiles/r05_sessions/
+            # r05m_replicas8.json): 2.2-7.2 ms + 2.9-3.3 ms per exchange beside a training launch of 202 ms per replica
+            "elementwise_cost_measured_on_one_gpu": "k_xchg_delta 2.2-7.2 ms + k_xchg_apply 2.9-3.3 ms per full exchange of 2.56 GB = 3-5 % of a 1 M-word launch at 128 workers (profiles/r05_sessions/r05m_replicas8.json)",
             "bytes": 8 * V * D, "bytes_all_reduced_per_exchange": 8 * V * D,
             "device_ms": (sync_ms / sync_n) if sync_n else None,
             "device_ms_per_exchange": (sync_ms / sync_n) if sync_n else None,

@@ -67,13 +67,17 @@ typedef struct w2b_config {
    * accesses -- faster when ids are heavily skewed, but a hot row is then private to an XCD's L2 (or
    * a CU's L1) until it is evicted or the launch ends; see DESIGN.md section 4. */
   int32_t relaxed_coherence;
-  /* form (i) has two kernels.  Sentence-resident: the fp32 rows of the sliding context window stay in LDS
-   * while a worker walks a sentence (a row is read once when it enters the window and merged back once
-   * when it leaves).  Plain: every context row of every position is read from / written to memory.
-   * 0 = automatic = plain (round 4: the sentence-resident kernel keeps context rows private for up to 2 x window + 1 positions,
-   * which is up to 13 % off the reference's epoch loss on a held-out regime; rounds 2-3 chose it wherever it fitted),
-   * 1 = plain, 2 = sentence-resident whenever it fits (the faster kernel at short rows) -- for coherent rows: with relaxed_coherence or exact_reduction
-   * set the plain kernel runs whatever this field says (w2b_worker_kernel_info tells which one a trainer uses). */
+  /* form (i) has three kernels.  Plain: one workgroup per worker, one thread per column, every context row of every position
+   * read from / written to memory.  Row groups (round 5): a worker's rows spread over four groups of wavefronts, all targets of a
+   * centre word in flight at once, a producer wavefront one word ahead, an adder wavefront for the lossless context-row adds
+   * (rows of at most 1024 floats, window <= 16, negative <= 26; bit-identical to the plain kernel with one worker).
+   * Sentence-resident: the fp32 rows of the sliding context window stay in LDS while a worker walks a sentence.
+   * 0 = automatic: the row-group kernel for rows of at most 512 floats below a full device where the fidelity budget is not
+   *     already thin (DESIGN.md sections 0a, 3.3c), else the plain kernel; never the sentence-resident one (round 4: it keeps
+   *     context rows private for up to 2 x window + 1 positions, up to 13 % off the reference's epoch loss on a held-out regime);
+   * 1 = plain, 2 = sentence-resident whenever it fits, 3 = row groups whenever they fit -- for coherent rows: with
+   * relaxed_coherence or exact_reduction set the plain kernel runs whatever this field says (w2b_worker_kernel_info tells
+   * which one a trainer uses: *resident = 0 plain, 1 sentence-resident, 2 row groups). */
   int32_t plain_worker_kernel;
   /* 1: parity mode.  The dot product of ref :461-467 is accumulated serially in the reference's own order
    * (c = 0 .. layer1_size-1, product rounded, then added) instead of the wavefront reduction tree -- the one
@@ -283,17 +287,9 @@ int w2b_comm_count(w2b_trainer *t, int32_t *nranks_out);
  * by R as well).  The more often the replicas exchange, the fewer rows are saturated.  Measured in
  * tests/test_gpu_exchange.py.  Asynchronous (see above). */
 int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
-/* HOT TIER (round 4).  What costs a replicated run its epoch loss is how long the FREQUENT rows stay apart, not the
- * rare ones: a row that receives hundreds of updates per replica between two exchanges ends up as the mean of R models
- * that each saw 1/R of the data.  w2b_sync_hot_rows exchanges only the leading rows of both tables -- the rows that would
- * be saturated over `horizon_words` centre words per replica (the interval of the full exchanges), at most budget_bytes of
- * rows per table, a few MB where a full exchange is GBs -- with the rule of mode 2 evaluated over the SHORT interval since
- * the previous exchange: rows still saturated move by the mean of their contributors, the others by the sum.  Meant to be
- * called after every launch, with w2b_sync_replicas(mode 2) every N launches for the tail.  The next training launch
- * waits for it (it moves exactly the rows the per-XCD hot-row copies are folded into); a full exchange stays asynchronous. */
-int w2b_sync_hot_rows(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes);
-/* rows 1..*rows_u of u and 1..*rows_v of v that w2b_sync_hot_rows / w2b_exchange_begin_hot would exchange */
-int w2b_exchange_hot_rows(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes, int32_t *rows_u, int32_t *rows_v);
+/* (Round 4 also had a HOT TIER -- w2b_sync_hot_rows / w2b_exchange_begin_hot / w2b_exchange_hot_rows: the leading rows of both
+ * tables exchanged after every launch.  It measured no gain over the full exchanges alone -- the rows that are rare individually
+ * are a quarter of all draws and want the short interval as much as the frequent ones -- and was removed in round 5.) */
 /* exchanges since the last call and their summed device time (begin of the first chunk -> end of the last; waits for
  * the exchanges in flight); resets both */
 int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
@@ -310,9 +306,6 @@ int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
  * Chunks c and c + 1 use different staging buffers and streams, so a host may pipeline them. */
 int w2b_exchange_init(w2b_trainer *t);
 int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count /* or NULL */);
-/* the hot tier of w2b_sync_hot_rows in phases: the chunks that follow are the leading rows of u and of v */
-int w2b_exchange_begin_hot(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes, int64_t *n_chunks,
-                           int64_t *local_word_count /* or NULL */);
 int w2b_exchange_counts(w2b_trainer *t, void **buf_dev, int64_t *elems);
 int w2b_exchange_delta(w2b_trainer *t, int64_t chunk, void **buf_dev, int64_t *elems);
 int w2b_exchange_apply(w2b_trainer *t, int64_t chunk, float scale);

@@ -1,8 +1,9 @@
 """Measurement, not a test: training effect of the replica exchange on ONE GPU (R replicas in this process, the collective
 supplied through the phase API -- tests/test_gpu_exchange.py run_replicas) over launch length x exchange scheme.
   python tests/experiments/exchange_matrix.py [--positions 1024,256,64] [--replicas 2,4]
-Schemes per (R, positions): none (end of epoch only) | full every launch (mode 2) | two-tier: hot tier (B MB per table) after
-every launch + full every E launches.  Printed: epoch loss and its deviation from the single replica at the same positions."""
+Schemes per (R, positions): none (end of epoch only) | full every launch (mode 2) | full every E launches.  (Round 4's two-tier
+schemes -- a hot tier of B MB per table after every launch -- were removed with the hot tier in round 5.)
+Printed: epoch loss and its deviation from the single replica at the same positions."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +16,7 @@ from test_gpu_exchange import run_replicas
 ap = argparse.ArgumentParser()
 ap.add_argument("--positions", default="1024,256,64")
 ap.add_argument("--replicas", default="2,4")
-ap.add_argument("--tiers", default="8:4,8:16,32:16", help="E:B pairs: full exchange every E launches, hot tier of B MB per table")
+ap.add_argument("--every", default="8,32", help="full exchange every E launches")
 ap.add_argument("--sat", default="0", help="w2b_tuning.exchange_sat_updates values to sweep (0 = library default)")
 ap.add_argument("--modes", default="2", help="exchange modes for the 'full every launch' scheme (0 delta-sum, 2 contributor mean)")
 a = ap.parse_args()
@@ -31,9 +32,7 @@ for positions in [int(x) for x in a.positions.split(",")]:
     print("XM positions=%d workers=%d launches/epoch=%d: 1 replica loss %.0f  [%.1f s]" % (positions, workers, launches, one, time.time() - t0), flush=True)
     for R in [int(x) for x in a.replicas.split(",")]:
         schemes = [("none", dict(sync_every=0)), ("full every launch", dict(sync_every=1))]
-        for eb in a.tiers.split(","):
-            E, B = [int(x) for x in eb.split(":")]
-            schemes.append(("two-tier E=%d B=%dMB" % (E, B), dict(sync_every=E, hot_mb=B)))
+        for E in [int(x) for x in a.every.split(",")]:
             schemes.append(("full every %d only" % E, dict(sync_every=E)))
         seen = set()
         for sat in [int(x) for x in a.sat.split(",")]:

@@ -96,14 +96,11 @@ def test_size_one_communicator_runs_the_whole_exchange_and_changes_nothing(gpu):
     assert res[0][1:] == res[1][1:]
 
 
-def local_exchange(ts, mode=0, hot=None):
-    """the host-supplied collective of the phase API for replicas that live in this process: sum of the delta buffers.
-    hot = (horizon_words, budget_bytes): the hot tier (leading rows of both tables, rule of mode 2) instead of the model"""
+def local_exchange(ts, mode=0):
+    """the host-supplied collective of the phase API for replicas that live in this process: sum of the delta buffers"""
     import torch
-    begun = [t.exchange_begin() if hot is None else t.exchange_begin_hot(*hot) for t in ts]
+    begun = [t.exchange_begin() for t in ts]
     n_chunks = begun[0][0]
-    if hot is not None:
-        mode = 2
     scale = 1.0 / len(ts) if mode == 1 else 1.0
     if mode == 2:                                     # contributor average: how many replicas changed each row
         cnts = [t.device_tensor(*t.exchange_counts()) for t in ts]
@@ -164,48 +161,6 @@ def test_phase_api_arithmetic_two_replicas(gpu, mode):
         t.close()
 
 
-def test_hot_tier_arithmetic_two_replicas(gpu):
-    """w2b_exchange_begin_hot: only rows 0..hu of u and 0..hv of v travel (hu, hv from the word counts: the rows saturated
-    over the horizon, capped by the byte budget); among them the rows saturated since the LAST exchange move by the mean
-    of their contributors, the others by the sum; every other row of a replica keeps what the replica trained, and the
-    full exchange that follows brings the tail together."""
-    R, nw, V, D = 2, 4, 3000, 64
-    ts = [small_setup(nw, R * nw, r * nw, seed=3) for r in range(R)]
-    for t in ts:
-        t.exchange_init()
-        t.epoch_begin()
-    base = flat(ts[0])
-    horizon, budget = 8 * 150 * nw, 300 * D * 4            # at most 300 rows per table
-    hu, hv = ts[0].exchange_hot_rows(horizon, budget)
-    sat_h = saturated_rows(small_counts(3)[1], horizon, 5, 5)
-    assert hu == min(300, int(sat_h[:V].sum())) and hv == min(300, int(sat_h[V:].sum())) and 0 < hu and 0 < hv
-    in_tier = np.zeros(2 * V, bool)
-    in_tier[:hu + 1] = True
-    in_tier[V:V + hv + 1] = True
-    for rnd in range(2):
-        for t in ts:
-            t.train_step(150)
-        mine = [flat(t) for t in ts]
-        d = [m - base for m in mine]
-        c = sum((x.reshape(2 * V, D) != 0).any(1).astype(np.float32) for x in d)
-        sat = saturated_rows(small_counts(3)[1], 150 * nw, 5, 5)          # since the last exchange: one launch
-        a = np.where(sat, np.float32(1) / np.maximum(c, 1), np.float32(1)).astype(np.float32)
-        tier = in_tier[:, None].repeat(D, 1).ravel()
-        total = np.where(tier, a[:, None].repeat(D, 1).ravel() * (d[0] + d[1]), np.float32(0))
-        local_exchange(ts, hot=(horizon, budget))
-        got = [flat(t) for t in ts]
-        for r in range(R):
-            want = np.where(tier, mine[r] + (total - d[r]), mine[r])
-            assert np.abs(got[r] - want).max() <= 2e-6, (rnd, r)
-        assert np.abs(got[0] - got[1])[tier].max() <= 4e-6 and np.abs(got[0] - got[1])[~tier].max() > 0
-        base = base + total
-    local_exchange(ts, 2)                                # the full exchange: the replicas agree everywhere afterwards
-    got = [flat(t) for t in ts]
-    assert np.abs(got[0] - got[1]).max() <= 4e-6
-    for t in ts:
-        t.close()
-
-
 def test_exchange_needs_init(gpu):
     t = small_setup(2, 2, 0)
     with pytest.raises(w2b.W2bError) as e:
@@ -215,10 +170,9 @@ def test_exchange_needs_init(gpu):
 
 
 # ---------------------------------------------------------------------------------------------- training effect
-def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=True, mode=2, hot_mb=0, **tuning):
+def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=True, mode=2, **tuning):
     """one epoch over `corpus` with R replicas of workers_total / R workers each, exchanged every sync_every launches
-    and at the end (sync_every 0: at the end only); hot_mb > 0: the hot tier (at most hot_mb MB of leading rows per table)
-    after every other launch, as ./word2bits -gpus N does; returns the summed epoch loss"""
+    and at the end (sync_every 0: at the end only), as ./word2bits -gpus N does; returns the summed epoch loss"""
     per = workers_total // R
     starts, ov = corpus.shards(workers_total)
     tokens = corpus.tokens()
@@ -250,8 +204,6 @@ def run_replicas(corpus, R, workers_total, sync_every, positions, flags, slices=
         done = all(t.epoch_poll(0)[0] for t in ts)
         if R > 1 and (done or (sync_every > 0 and launches % sync_every == 0)):
             local_exchange(ts, mode)
-        elif R > 1 and hot_mb > 0:
-            local_exchange(ts, hot=(max(1, sync_every) * positions * per, hot_mb << 20))
         if done:
             break
     loss = sum(t.epoch_status()[3] for t in ts)
@@ -274,9 +226,9 @@ def test_training_effect_of_the_exchange_text8_size(gpu, tmp_path_factory):
     contributor-mean exchange (mode 2) after every launch keeps 2 replicas within 0.7-0.8 % and 4 within 1.4-1.6 % of the
     single replica, 2 and 6 points better than no exchange.  Asserted: within EXCHANGE_RTOL and at least 1 point better than
     exchanging at the end of the epoch only.  Printed for the record: the plain delta-sum (mode 0: over-shoots, -3 % / -9 %),
-    a full exchange every 8 launches only, and the same with the hot tier after every other launch (leading rows only:
-    measured no better than without it -- the rows that are rare individually are 28 % of all negative draws and 12 % of
-    all context positions, and they want the short interval as much as the frequent ones)."""
+    and a full exchange every 8 launches only.  (Round 4 also had a hot tier -- the leading rows only, after every other
+    launch: measured no better than without it, the rows that are rare individually are 28 % of all negative draws and 12 % of
+    all context positions and want the short interval as much as the frequent ones; removed in round 5.)"""
     from w2b_testlib import write_zipf_text_corpus
     d = tmp_path_factory.mktemp("xchg")
     path = write_zipf_text_corpus(str(d / "c.txt"))
@@ -292,8 +244,7 @@ def test_training_effect_of_the_exchange_text8_size(gpu, tmp_path_factory):
     dev = {}
     for R in (2, 4):
         for name, kw in (("none", dict(sync_every=0)), ("every launch, mode 2", dict(sync_every=1)),
-                         ("every launch, mode 0", dict(sync_every=1, mode=0)), ("every 8 launches", dict(sync_every=8)),
-                         ("every 8 + hot tier 16 MB", dict(sync_every=8, hot_mb=16))):
+                         ("every launch, mode 0", dict(sync_every=1, mode=0)), ("every 8 launches", dict(sync_every=8))):
             if R == 2 and name.startswith("every 8"):
                 continue
             loss, _ = run_replicas(corpus, R, workers, positions=positions, flags=flags, **kw)

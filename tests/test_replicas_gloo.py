@@ -114,11 +114,7 @@ class _FakeTrainer:
         self.rows, self.dim, self.chunk, self.words = rows, dim, chunk, words
         self.bufs, self.log, self.cnt, self.total = {}, [], None, None
 
-    hot_rows = 0
-
     def _span(self, c):
-        if self.hot_rows:
-            return 0, self.hot_rows * self.dim
         o = c * self.chunk
         return o, min(self.chunk, self.w.numel() - o)
 
@@ -126,13 +122,6 @@ class _FakeTrainer:
         self.log.append("begin")
         self.cnt = None
         return (self.w.numel() + self.chunk - 1) // self.chunk, self.words
-
-    def exchange_begin_hot(self, horizon_words, budget_bytes):
-        # the hot tier of the stand-in: the first `budget_bytes // (4 * dim)` rows as ONE chunk (the library: a prefix of u and one of v)
-        self.log.append("begin_hot")
-        self.cnt = None
-        self.hot_rows = budget_bytes // (4 * self.dim)
-        return 1, self.words
 
     def exchange_counts(self):
         self.log.append("counts")
@@ -161,7 +150,6 @@ class _FakeTrainer:
     def exchange_end(self, total):
         self.log.append("end")
         self.total = total
-        self.hot_rows = 0
 
     def device_tensor(self, ptr, n):
         assert self.bufs[ptr].numel() == n
@@ -184,14 +172,6 @@ def _phased_worker(rank, world, port, q):
             t = _FakeTrainer(model, base, rows, dim, chunk, words=1000 * (rank + 1))
             replicas.PhasedReplicaSync(dist, t, mode).sync()
             out[mode] = (t.w.numpy().copy(), t.base.numpy().copy(), t.total, list(t.log))
-        # hot tier: only the first 12 rows travel (rows 10 and 11 are changed by both replicas: mean; the others: sum)
-        model = base.clone()
-        mine = torch.zeros(rows, dim)
-        mine[rank * 10:rank * 10 + 15] = float(rank + 1)
-        model += mine.view(-1)
-        t = _FakeTrainer(model, base, rows, dim, chunk, words=1000 * (rank + 1))
-        replicas.PhasedReplicaSync(dist, t, 2).sync_hot(12345, 12 * 4 * dim)
-        out["hot"] = (t.w.numpy().copy(), t.base.numpy().copy(), t.total, list(t.log))
         # numpy arrays travel by value; torch tensors would travel as file descriptors served by THIS process, which may
         # have exited by the time the parent unpickles them (FileNotFoundError on the resource-sharer socket: a flaky test)
         q.put((rank, base.numpy().copy(), out))
@@ -233,10 +213,3 @@ def test_phased_replica_sync_over_gloo():
             phases = ["begin"] + (["counts"] if mode == 2 else []) + [x for c in range(4) for x in ("delta%d" % c, "apply%d" % c)] + ["end"]
             assert log == phases
     assert torch.equal(res[0][2][2][1], res[1][2][2][1])               # `base` is bit-identical across the ranks
-    # hot tier: rows 0..11 exchanged with the contributor mean, every other row of a replica still its own
-    hot = 12 * dim
-    for rank, _, out in res:
-        w, b, words, log = out["hot"]
-        assert log == ["begin_hot", "counts", "delta0", "apply0", "end"] and words == 3000
-        assert torch.allclose(w[:hot], want[2][:hot], atol=1e-6) and torch.allclose(b[:hot], want[2][:hot], atol=1e-6)
-        assert torch.equal(w[hot:], (base + deltas[rank])[hot:]) and torch.equal(b[hot:], base[hot:])

@@ -101,9 +101,6 @@ SIGNATURES = {
     "w2b_sync_stats": (C.c_int, [vp, i64p, f64p]),
     "w2b_exchange_init": (C.c_int, [vp]),
     "w2b_exchange_begin": (C.c_int, [vp, i64p, i64p]),
-    "w2b_exchange_begin_hot": (C.c_int, [vp, C.c_int64, C.c_int64, i64p, i64p]),
-    "w2b_exchange_hot_rows": (C.c_int, [vp, C.c_int64, C.c_int64, i32p, i32p]),
-    "w2b_sync_hot_rows": (C.c_int, [vp, C.c_int64, C.c_int64]),
     "w2b_exchange_counts": (C.c_int, [vp, C.POINTER(vp), i64p]),
     "w2b_exchange_delta": (C.c_int, [vp, C.c_int64, C.POINTER(vp), i64p]),
     "w2b_exchange_apply": (C.c_int, [vp, C.c_int64, C.c_float]),

@@ -97,10 +97,8 @@ struct w2b_trainer {
   float *xd[2] = {nullptr, nullptr}, *xsum[2] = {nullptr, nullptr};   // per slot: own delta / sum over the replicas
   struct XRange { long long off, len; };    // floats of [u || v]
   std::vector<XRange> x_ranges;             // the chunks of the exchange in progress (full: the whole model; hot tier: two prefixes)
-  bool x_hot = false, x_open = false;       // the exchange in progress is a hot-tier one / has begun and not ended
-  bool x_fence_next_launch = false;         // the next training launch waits for the exchange in flight (hot tier)
-  int x_hot_u = 0, x_hot_v = 0;             // rows 0..x_hot_* of u / v are the hot tier of the exchange in progress
-  long long x_words_full = 0;               // centre words since the previous FULL exchange
+  bool x_open = false;                      // the exchange in progress has begun and not ended
+  long long x_words_full = 0;               // centre words since the previous exchange
   hipEvent_t x_evd[2] = {nullptr, nullptr}, x_evs[2] = {nullptr, nullptr}, x_evc = nullptr;   // delta / sum of a slot complete; counts summed
   float *xcnt = nullptr;                    // [2 * vocab_size]: replicas that changed each row (contributor-average mode)
   bool x_use_cnt = false;                   // the exchange in progress damps the saturated rows' sums by xcnt
@@ -1148,7 +1146,6 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
       t->entry_floats = need;
     }
   }
-  if (t->x_fence_next_launch) if (int rc = xchg_fence(t)) return rc;   // a hot-tier exchange in flight (see xchg_end)
   W2bParams p = make_params(t);
   // per-XCD copies of the hottest rows: v only for the sentence-resident kernel (its context rows live in LDS)
   if (int rc = xhot_prepare(t, p, t->cfg.num_threads, radius < 0)) return rc;
@@ -1388,7 +1385,6 @@ static int xchg_fence(w2b_trainer *t) {
   if (!t->x_pending) return W2B_OK;
   for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->stream, t->x_done[k], 0));
   t->x_pending = false;
-  t->x_fence_next_launch = false;
   t->xhot_master_changed = true;
   return W2B_OK;
 }
@@ -1426,7 +1422,8 @@ extern "C" int w2b_comm_count(w2b_trainer *t, int32_t *nranks_out) {
 }
 
 // ---- one exchange = a list of RANGES of [u || v], each at most one staging buffer long.  A FULL exchange covers the whole
-// model in chunks; a HOT-TIER exchange (w2b_sync_hot_rows) covers the leading rows of both tables only.
+// model in chunks.  (Round 4's HOT-TIER exchange -- the leading rows of both tables only, after every launch -- measured no
+// gain over the full exchanges alone and was removed from the ABI in round 5: DESIGN.md Appendix A.)
 static long long xchg_chunks(const w2b_trainer *t) { return (long long)t->x_ranges.size(); }
 
 static void xchg_add_range(w2b_trainer *t, long long off, long long len) {
@@ -1466,17 +1463,6 @@ static void xchg_saturated_prefix(const w2b_trainer *t, long long words, int *sa
   *sat_v = prefix(true);
 }
 
-// Rows of the hot tier: the rows that would be saturated over `horizon_words` (the centre words a replica trains between
-// two FULL exchanges), at most budget_bytes of rows per table.
-static void xchg_hot_plan(const w2b_trainer *t, long long horizon_words, long long budget_bytes, int *hu, int *hv) {
-  xchg_saturated_prefix(t, horizon_words, hu, hv);
-  const long long row_bytes = (long long)t->cfg.layer1_size * (long long)sizeof(float);
-  long long cap = budget_bytes > 0 ? budget_bytes / row_bytes : 0;
-  if (cap > t->cfg.vocab_size - 1) cap = t->cfg.vocab_size - 1;
-  if (*hu > cap) *hu = (int)cap;
-  if (*hv > cap) *hv = (int)cap;
-}
-
 static void xchg_abort(w2b_trainer *t) {       // an exchange that failed between begin and end: forget its (begin, end) events
   if (t->x_open && t->x_ev.size() >= 2) {
     (void)hipEventDestroy(t->x_ev.back()); t->x_ev.pop_back();
@@ -1485,8 +1471,7 @@ static void xchg_abort(w2b_trainer *t) {       // an exchange that failed betwee
   t->x_open = false;
 }
 
-// hot_u / hot_v >= 0: a hot-tier exchange of rows 0..hot_u of u and 0..hot_v of v; -1: the whole model
-static int xchg_begin(w2b_trainer *t, int hot_u, int hot_v) {
+static int xchg_begin(w2b_trainer *t) {
   if (!t->base) return fail(W2B_ESTATE, "replica exchange: w2b_comm_init / w2b_exchange_init first (while all replicas "
                                         "still hold the same model)");
   if (t->x_open) return fail(W2B_ESTATE, "replica exchange: the previous exchange was not ended (w2b_exchange_end)");
@@ -1515,19 +1500,8 @@ static int xchg_begin(w2b_trainer *t, int hot_u, int hot_v) {
     if (e != hipSuccess) { xchg_abort(t); return fail(W2B_EHIP, std::string("replica exchange begin: ") + hipGetErrorString(e)); }
   }
   t->x_ranges.clear();
-  t->x_hot = hot_u >= 0;
-  const long long TE = t->table_elems, D = t->cfg.layer1_size;
-  if (t->x_hot) {
-    auto prefix = [&](long long rows) { long long m = ((rows + 1) * D + 3) & ~3ll; return m < TE ? m : TE; };
-    t->x_hot_u = hot_u;
-    t->x_hot_v = hot_v;
-    xchg_add_range(t, 0, prefix(hot_u));
-    xchg_add_range(t, TE, prefix(hot_v));
-    xchg_saturated_prefix(t, t->x_words, &t->x_sat_u, &t->x_sat_v);       // over the words since the last exchange of any kind
-  } else {
-    xchg_add_range(t, 0, 2 * TE);
-    xchg_saturated_prefix(t, t->x_words_full, &t->x_sat_u, &t->x_sat_v);  // over the words since the last FULL exchange
-  }
+  xchg_add_range(t, 0, 2 * t->table_elems);
+  xchg_saturated_prefix(t, t->x_words_full, &t->x_sat_u, &t->x_sat_v);    // over the words since the last exchange
   return W2B_OK;
 }
 static int xchg_delta(w2b_trainer *t, long long c) {
@@ -1543,18 +1517,14 @@ static int xchg_apply(w2b_trainer *t, long long c, float scale) {
                                r.off, t->cfg.layer1_size, t->cfg.vocab_size, t->x_sat_u, t->x_sat_v, t->xs[0]));
   return W2B_OK;
 }
-// per row of [u || v]: has this replica changed it since the last exchange?  A hot-tier exchange looks at its rows only.
+// per row of [u || v]: has this replica changed it since the last exchange?
 static int xchg_touched(w2b_trainer *t, hipStream_t s) {
   const long long V = t->cfg.vocab_size, D = t->cfg.layer1_size;
-  if (!t->x_hot) return w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, 2 * V, (int)D, s) == hipSuccess ? W2B_OK : fail(W2B_EHIP, "k_xchg_touched");
-  // (the host sums the whole count buffer over the replicas: the entries outside the tier must not carry old sums along)
-  hipError_t e = hipMemsetAsync(t->xcnt, 0, sizeof(float) * 2 * V, s);
-  if (e == hipSuccess) e = w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, t->x_hot_u + 1, (int)D, s);
-  if (e == hipSuccess) e = w2b_launch_xchg_touched(t->uv + t->table_elems, t->base + t->table_elems, t->xcnt + V, t->x_hot_v + 1, (int)D, s);
-  return e == hipSuccess ? W2B_OK : fail(W2B_EHIP, "k_xchg_touched");
+  return w2b_launch_xchg_touched(t->uv, t->base, t->xcnt, 2 * V, (int)D, s) == hipSuccess ? W2B_OK : fail(W2B_EHIP, "k_xchg_touched");
 }
+
 static int xchg_end(w2b_trainer *t) {
-  if (!t->x_hot) t->x_words_full = 0;
+  t->x_words_full = 0;
   t->x_words = 0;
   // x_ev.back() = the end of this exchange: the elementwise stream waits for the collective stream's last operation first
   HIPCHK(hipEventRecord(t->x_done[1], t->xs[1]));
@@ -1564,9 +1534,6 @@ static int xchg_end(w2b_trainer *t) {
   t->x_any_done = true;
   t->x_open = false;
   t->x_pending = true;
-  // a hot-tier exchange moves a few MB of exactly the rows the next launch's hot-row folds and merges work on: the next
-  // launch waits for it (a full exchange stays asynchronous)
-  if (t->x_hot) t->x_fence_next_launch = true;
   t->sync_count++;
   long long bytes = 0;
   for (const auto &r : t->x_ranges) bytes += r.len * (long long)sizeof(float);
@@ -1616,30 +1583,19 @@ extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
   NEED(t);
   if (!t->comm) return W2B_OK;             // a single replica without a communicator: nothing to exchange
   if (mode < 0 || mode > 2) return fail(W2B_EINVAL, "w2b_sync_replicas: unknown mode");
-  if (int rc = xchg_begin(t, -1, -1)) return rc;
+  if (int rc = xchg_begin(t)) return rc;
   if (int rc = xchg_run_rccl(t, mode)) { xchg_abort(t); return rc; }
   return xchg_end(t);
 }
 
-extern "C" int w2b_sync_hot_rows(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes) {
-  NEED(t);
-  if (!t->comm) return W2B_OK;
-  if (horizon_words <= 0 || budget_bytes <= 0) return fail(W2B_EINVAL, "w2b_sync_hot_rows: horizon_words and budget_bytes must be positive");
-  int hu = 0, hv = 0;
-  xchg_hot_plan(t, horizon_words, budget_bytes, &hu, &hv);
-  if (int rc = xchg_begin(t, hu, hv)) return rc;
-  if (int rc = xchg_run_rccl(t, 2)) { xchg_abort(t); return rc; }
-  return xchg_end(t);
-}
-
 // ---- the same exchange for a host that brings its own collective (MPI, torch.distributed over gloo / RCCL, ...):
-//   w2b_exchange_begin[_hot] -> (w2b_exchange_counts, <sum over the replicas>) -> for every chunk: w2b_exchange_delta,
+//   w2b_exchange_begin -> (w2b_exchange_counts, <sum over the replicas>) -> for every chunk: w2b_exchange_delta,
 //   <sum *buf over the replicas, in place>, w2b_exchange_apply -> w2b_exchange_end.  The buffer handed out is device
 // memory; the library's kernels run on its elementwise exchange stream, so w2b_exchange_delta returns after the delta is
 // complete (the host's collective may use any stream or the CPU) and w2b_exchange_apply expects the sum to be complete
 // when it is called.
-static int xchg_begin_host(w2b_trainer *t, int hu, int hv, int64_t *n_chunks, int64_t *local_word_count) {
-  if (int rc = xchg_begin(t, hu, hv)) return rc;
+static int xchg_begin_host(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count) {
+  if (int rc = xchg_begin(t)) return rc;
   t->x_use_cnt = false;
   if (n_chunks) *n_chunks = xchg_chunks(t);
   if (local_word_count) {
@@ -1654,23 +1610,7 @@ static int xchg_begin_host(w2b_trainer *t, int hu, int hv, int64_t *n_chunks, in
 }
 extern "C" int w2b_exchange_begin(w2b_trainer *t, int64_t *n_chunks, int64_t *local_word_count) {
   NEED(t);
-  return xchg_begin_host(t, -1, -1, n_chunks, local_word_count);
-}
-extern "C" int w2b_exchange_begin_hot(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes, int64_t *n_chunks,
-                                      int64_t *local_word_count) {
-  NEED(t);
-  if (horizon_words <= 0 || budget_bytes <= 0) return fail(W2B_EINVAL, "w2b_exchange_begin_hot: horizon_words and budget_bytes must be positive");
-  int hu = 0, hv = 0;
-  xchg_hot_plan(t, horizon_words, budget_bytes, &hu, &hv);
-  return xchg_begin_host(t, hu, hv, n_chunks, local_word_count);
-}
-extern "C" int w2b_exchange_hot_rows(w2b_trainer *t, int64_t horizon_words, int64_t budget_bytes, int32_t *rows_u, int32_t *rows_v) {
-  if (!t) return fail(W2B_EINVAL, "null trainer");
-  int hu = 0, hv = 0;
-  xchg_hot_plan(t, horizon_words, budget_bytes, &hu, &hv);
-  if (rows_u) *rows_u = hu;
-  if (rows_v) *rows_v = hv;
-  return W2B_OK;
+  return xchg_begin_host(t, n_chunks, local_word_count);
 }
 extern "C" int w2b_exchange_counts(w2b_trainer *t, void **buf_dev, int64_t *elems) {
   NEED(t);

@@ -6,7 +6,7 @@
 // happens: the corpus is tokenised once on the host (word2bits_corpus.h) and every epoch is a
 // sequence of GPU launches in which each of the -threads Hogwild workers is one workgroup.
 // GPU-only additions use new flag names: -gpus, -sync-every, -positions, -device, -table-size, -relaxed,
-// -window-cache, -exact, -eval, -hot-rows, -hot-period, -row-desc, -atomic-rank, -atomic-cap, -sync-hot-mb, ...
+// -window-cache, -exact, -eval, -hot-rows, -hot-period, -row-desc, -atomic-rank, -atomic-cap, -row-groups, -refresh-rows, ...
 #include <pthread.h>
 #include <unistd.h>
 
@@ -34,7 +34,6 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   long long sync_every = 1;            // -gpus > 1: launches between two replica exchanges (8 until round 4: the interval is what
                                        // costs epoch loss -- tests/test_gpu_exchange.py; keep -positions short with replicas)
   long long positions = 4096;          // sentence positions per worker per launch
-  long long sync_hot_mb = 0;           // -gpus > 1: MB of leading rows per table exchanged after every launch without a full exchange (w2b_sync_hot_rows; 0 = off, the default: measured no gain)
   long long table_size = W2B_UNIGRAM_TABLE_SIZE;
   int relaxed = 0;                     // 1: plain cached row accesses instead of agent-scope ones
   int window_cache = -1;               // -1 automatic, 0 plain worker kernel, 1 sentence-resident kernel
@@ -94,13 +93,13 @@ struct Replica {                        // one GPU
 
 // -gpus N in one process: the collectives of the N communicators must be issued concurrently, one host thread per
 // replica.  The threads live as long as the run (round 3 created and joined N threads per exchange) and take one
-// command at a time: 1 = full exchange (w2b_sync_replicas mode 2), 2 = hot tier (w2b_sync_hot_rows), 0 = exit.
+// command at a time: 1 = full exchange (w2b_sync_replicas mode 2), 0 = exit.
 struct ExchangeCrew {
   struct Slot { pthread_t th; w2b_trainer *t; ExchangeCrew *crew; };
   std::vector<Slot> slots;
   pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
   pthread_cond_t cv = PTHREAD_COND_INITIALIZER, done_cv = PTHREAD_COND_INITIALIZER;
-  long long generation = 0, horizon = 0, budget = 0;
+  long long generation = 0;
   int command = 0, remaining = 0;
   static void *run(void *p) {
     Slot *s = (Slot *)p;
@@ -111,11 +110,9 @@ struct ExchangeCrew {
       while (c->generation == seen) pthread_cond_wait(&c->cv, &c->mu);
       seen = c->generation;
       const int cmd = c->command;
-      const long long horizon = c->horizon, budget = c->budget;
       pthread_mutex_unlock(&c->mu);
       if (cmd == 0) return nullptr;
-      if (cmd == 1) CK(w2b_sync_replicas(s->t, 2));
-      else CK(w2b_sync_hot_rows(s->t, horizon, budget));
+      CK(w2b_sync_replicas(s->t, 2));
       pthread_mutex_lock(&c->mu);
       if (--c->remaining == 0) pthread_cond_signal(&c->done_cv);
       pthread_mutex_unlock(&c->mu);
@@ -129,11 +126,9 @@ struct ExchangeCrew {
       pthread_create(&slots[g].th, nullptr, run, &slots[g]);
     }
   }
-  void issue(int cmd, long long horizon_words = 0, long long budget_bytes = 0) {   // returns when every replica has issued its exchange
+  void issue(int cmd) {   // returns when every replica has issued its exchange
     pthread_mutex_lock(&mu);
     command = cmd;
-    horizon = horizon_words;
-    budget = budget_bytes;
     remaining = cmd == 0 ? 0 : (int)slots.size();
     generation++;
     pthread_cond_broadcast(&cv);
@@ -191,7 +186,6 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-device", argc, argv)) > 0) o.device = atoi(argv[i + 1]);
   if ((i = arg_pos("-sync-every", argc, argv)) > 0) o.sync_every = atoll(argv[i + 1]);
   if ((i = arg_pos("-positions", argc, argv)) > 0) o.positions = atoll(argv[i + 1]);
-  if ((i = arg_pos("-sync-hot-mb", argc, argv)) > 0) o.sync_hot_mb = atoll(argv[i + 1]);
   if ((i = arg_pos("-table-size", argc, argv)) > 0) o.table_size = atoll(argv[i + 1]);
   if ((i = arg_pos("-relaxed", argc, argv)) > 0) o.relaxed = atoi(argv[i + 1]);
   if ((i = arg_pos("-window-cache", argc, argv)) > 0) o.window_cache = atoi(argv[i + 1]);
@@ -420,13 +414,10 @@ int main(int argc, char **argv) {
       }
       launches++;
       if (o.gpus > 1) {
-        // replicas: two tiers.  Every sync_every launches (and always at the end of an epoch) an all-reduce of the deltas of
-        // the whole [u||v] over RCCL, every row's sum shared among the replicas that trained it (w2b_sync_replicas mode 2,
-        // asynchronous); after every other launch only the leading rows of both tables -- the rows that would be saturated
-        // over such an interval, at most -sync-hot-mb MB per table (w2b_sync_hot_rows).
+        // replicas: every sync_every launches (and always at the end of an epoch) an all-reduce of the deltas of the whole
+        // [u||v] over RCCL, every row's sum shared among the replicas that trained it (w2b_sync_replicas mode 2, asynchronous)
         const long long every = o.sync_every > 0 ? o.sync_every : 1;
         if (finished || launches % every == 0) crew.issue(1);
-        else if (o.sync_hot_mb > 0) crew.issue(2, every * o.positions * per_gpu, o.sync_hot_mb << 20);
       }
       if (o.debug_mode > 1) {                                 // progress line, ref :384-387
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

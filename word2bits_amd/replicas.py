@@ -8,7 +8,7 @@ their updates into one shared table.
 Three drivers of the same exchange:
   * the library's own RCCL communicator (w2b_comm_init / w2b_sync_replicas) -- used by the CLI
     and by bench.py on GPUs: asynchronous, chunked, overlapped with the training launches;
-  * `PhasedReplicaSync` below: the library's exchange kernels (w2b_exchange_begin[_hot] / delta / apply / end)
+  * `PhasedReplicaSync` below: the library's exchange kernels (w2b_exchange_begin / delta / apply / end)
     with a torch.distributed collective for the sum -- RCCL when every rank has a GPU, gloo when several
     ranks share one GPU (how the training effect of the exchange is tested on a one-GPU box);
   * `TorchReplicaSync`: the protocol restated on plain torch tensors -- it runs on CPU tensors over gloo,
@@ -98,15 +98,11 @@ class PhasedReplicaSync:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.on_device = dist.is_initialized() and dist.get_backend() == "nccl"
 
-    def sync_hot(self, horizon_words, budget_bytes=64 << 20):
-        """hot tier (w2b_sync_hot_rows in phases): the leading rows of both tables only, rule of mode 2"""
-        return self.sync(hot=(int(horizon_words), int(budget_bytes)))
-
-    def sync(self, hot=None):
+    def sync(self):
         import torch
-        n_chunks, words = self.t.exchange_begin() if hot is None else self.t.exchange_begin_hot(*hot)
-        scale = 1.0 / self.world if (self.mode == 1 and hot is None) else 1.0
-        if self.mode == 2 or hot is not None:                 # contributor average: who trained which row
+        n_chunks, words = self.t.exchange_begin()
+        scale = 1.0 / self.world if self.mode == 1 else 1.0
+        if self.mode == 2:                                    # contributor average: who trained which row
             self._reduce(self.t.device_tensor(*self.t.exchange_counts()))
         for c in range(n_chunks):
             ptr, n = self.t.exchange_delta(c)                 # complete on return

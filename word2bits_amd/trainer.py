@@ -351,21 +351,6 @@ class Trainer:
         check(lib().w2b_exchange_begin(self._h, C.byref(n), C.byref(w)))
         return n.value, w.value
 
-    def exchange_begin_hot(self, horizon_words, budget_bytes=64 << 20):
-        """hot tier: the chunks that follow are the leading rows of u and v (the rows saturated over horizon_words centre
-        words per replica, at most budget_bytes per table) -> (n_chunks, this replica's word_count_actual)"""
-        n, w = C.c_int64(0), C.c_int64(0)
-        check(lib().w2b_exchange_begin_hot(self._h, int(horizon_words), int(budget_bytes), C.byref(n), C.byref(w)))
-        return n.value, w.value
-
-    def exchange_hot_rows(self, horizon_words, budget_bytes=64 << 20):
-        a, b = C.c_int32(0), C.c_int32(0)
-        check(lib().w2b_exchange_hot_rows(self._h, int(horizon_words), int(budget_bytes), C.byref(a), C.byref(b)))
-        return a.value, b.value
-
-    def sync_hot_rows(self, horizon_words, budget_bytes=64 << 20):
-        check(lib().w2b_sync_hot_rows(self._h, int(horizon_words), int(budget_bytes)))
-
     def exchange_counts(self):
         """-> (device pointer, floats): 1 for every row of [u||v] this replica changed since the last exchange; sum it over
         the replicas in place and exchange_apply divides every row's summed delta by it (contributor average)"""
