@@ -341,7 +341,11 @@ def test_row_rules_copies_only_on_a_full_device_lossless_context_rows_below():
     prev = 0
     for workers in (8, 64, 256, 512, 767):
         p = _plan(cn, workers)
-        assert p["full_device"] == 0 and p["copies_u"] == 0 and p["copies_v"] == 0 and p["atomic_rank_v"] == 0
+        # (round 5: between the reference's scale and 2.5 workgroups per CU -- 257 .. 640 workers -- four target rows get copies
+        # that are merged every word; measured -0.05 % instead of +1.56 % at 512 workers)
+        mid = 256 < workers <= 640
+        assert p["full_device"] == 0 and p["copies_u"] == 0 and p["copies_v"] == (4 if mid else 0) and p["atomic_rank_v"] == 0
+        assert p["merge_period"] == 1
         want = int(np.sum(workers * 9 * share >= 0.25))                    # workers x (window + 1) x share of the tokens >= 1/4
         assert abs(p["atomic_rank_u"] - want) <= 1 and p["atomic_rank_u"] >= prev
         prev = p["atomic_rank_u"]
@@ -395,7 +399,7 @@ def test_row_rules_round5_kernel_choice_refreshed_copies_and_unsupported_shapes(
     assert _plan(cn, 256, D=200, refresh_rows_u=-1)["refresh_rows_u"] == 0
     assert _plan(cn, 256, D=200, refresh_rows_u=64)["refresh_rows_u"] == 64
     assert _plan(cn, 256, D=800)["row_group_kernel"] == 0                      # long rows: the plain kernel
-    assert _plan(cn, 512, D=200)["row_group_kernel"] == 0                      # 34 000 words per worker: shards too short
+    assert _plan(cn, 512, D=200)["row_group_kernel"] == 0                      # 34 000 words per worker: shards too short (and copies)
     assert _plan(cn, 256, D=200, negative=30)["row_group_kernel"] == 0         # more targets than the groups hold
     flat = np.full(2129, 30_000, np.int64)
     assert _plan(flat, 8, D=400)["row_group_kernel"] == 0                      # every row collides: the budget is thin

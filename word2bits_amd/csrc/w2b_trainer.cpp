@@ -791,6 +791,14 @@ static const double W2B_HOT_LOAD = 6400.0;
 static const int W2B_FULL_DEVICE_WG_PER_CU = 3;
 static const int W2B_HOT_PERIOD = 16;            // centre words between two merge events of a worker (xhot_prepare)
 static bool full_device(const w2b_trainer *t, long long workers) { return workers >= (long long)W2B_FULL_DEVICE_WG_PER_CU * t->num_cus; }
+// Round 5: BETWEEN the reference's own scale (256 threads: the most its bands exist for, and what -threads 0 stays at) and a full
+// device, explicit worker counts drifted on the benchmarked regime: +1.0 / +1.3 / +1.6 / +1.5 % of the reference's epoch loss
+// at 320 / 440 / 512 / 640 workers with every row shared.  Round 4 had measured "4 copies of v, merged every word" at -0.1 % for
+// 440 workers and not adopted it; round 5 measured the range (profiles/r05_sessions/r05q_mid_range.txt): -0.25 / -0.09 / -0.05 /
+// -0.45 % at 320 / 440 / 512 / 640, and on the held-out 60 M-token regime +0.18 -> -0.05 % (440) and +0.29 -> +0.03 % (600).  At
+// 767 workers it over-shoots (-1.5 % against +0.7 % shared), so the range ends at 2.5 workgroups per CU.  8 copies: -0.7 ... -1.2 %.
+static const int W2B_REFERENCE_SCALE = 256, W2B_MID_RANGE_COPIES_V = 4;
+static bool mid_range(const w2b_trainer *t, long long workers) { return workers > W2B_REFERENCE_SCALE && 2 * workers <= 5ll * t->num_cus; }
 
 static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int *nu, int *nv, bool legacy_u) {
   *nu = *nv = 0;
@@ -812,6 +820,10 @@ static void xhot_plan(const w2b_trainer *t, long long workers, bool with_u, int 
   const bool gated = with_u && !legacy_u && !full_device(t, workers);
   *nv = (t->tune.hot_rows_v < 0 && gated) ? 0 : pick(t->tune.hot_rows_v, t->rate_v);
   if (with_u) *nu = (t->tune.hot_rows_u < 0 && gated) ? 0 : pick(t->tune.hot_rows_u, t->rate_u);
+  if (gated && t->tune.hot_rows_v < 0 && t->tune.hot_rows_u < 0 && mid_range(t, workers)) {   // (see mid_range above)
+    const int n = pick(-1, t->rate_v);                   // never more rows than the load rule would take
+    *nv = n < W2B_MID_RANGE_COPIES_V ? n : W2B_MID_RANGE_COPIES_V;
+  }
 }
 
 // Rows 1..n (by count) whose updates are atomic adds at their master address (w2b_tuning.atomic_rank).  A load / modify /
@@ -1039,7 +1051,7 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   // period 32: -1.16 ... -1.38 % (literal) / +0.27 % (proxy); 16: -0.70 % / +0.67 %; 8: +0.32 % / +1.11 %; 64: -1.10 % / +0.47 %.
   // The longer the stream the further stale copies pull the epoch loss down, so the period that centres BOTH is the default;
   // it costs ~2 % of the headline throughput against 32.
-  if (t->tune.hot_period <= 0) p.hot_period = W2B_HOT_PERIOD;
+  if (t->tune.hot_period <= 0) p.hot_period = full_device(t, workers) ? W2B_HOT_PERIOD : 1;   // (mid range: every word)
   if (fresh) {         // copy == entry (== 0) everywhere: the fold below adopts the master rows
     HIPCHK(hipMemsetAsync(t->xhot, 0, sizeof(float) * need, t->stream));
     t->xhot_nu = nu;
@@ -1122,7 +1134,7 @@ extern "C" int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, cons
   out->atomic_rank_v = atomic_plan(&t, workers);
   out->atomic_rank_u = atomic_plan_u(&t, workers, out->atomic_rank_v);
   out->full_device = full_device(&t, workers) ? 1 : 0;
-  out->merge_period = t.tune.hot_period > 0 ? t.tune.hot_period : W2B_HOT_PERIOD;
+  out->merge_period = t.tune.hot_period > 0 ? t.tune.hot_period : (full_device(&t, workers) ? W2B_HOT_PERIOD : 1);
   t.cfg.num_threads = workers;
   t.table_elems = (long long)cfg->vocab_size * cfg->layer1_size;
   out->row_group_kernel = groups_plan(&t, workers) ? 1 : 0;
