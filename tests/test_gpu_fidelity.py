@@ -216,7 +216,7 @@ def headline(tmp_path_factory):
 def test_benchmarked_regime_matches_reference(gpu, headline, threads, ref_threads):
     """BASELINE configs[1] -- what bench.py times: V = 400 K, size 800, window 8, negative 24, bitlevel 1, -sample 0 -- on the
     22 M-token proxy file (the literal 100 M-token setting: test_benchmarked_setting_literally_100m_tokens).  `-threads 0` on
-    this file is 256 workers (not enough words for a full device); 1024 is what bench.py runs: a full device, per-XCD copies of
+    this file is 440 workers (50 000 words per worker; not enough words for a full device: the mid range below); 1024 is what bench.py runs: a full device, per-XCD copies of
     the hottest rows (the CLI warns about the short shards; the reference's band is its 256-thread one, the most the host runs
     at once).  The row policy is a step function of the worker count and round 4 left the counts next to its steps untested;
     round 5 measured them (profiles/r05_sessions/r05m_gpu_runs.txt, r05q_mid_range.txt).  With every row shared the epoch

@@ -360,12 +360,14 @@ def test_copies_only_on_a_full_device_and_lossless_context_rows_below_it(gpu):
     cn = np.maximum((2.0e7 / np.arange(1, V + 1)).astype(np.int64), 5)
     cn[0] = 1000
     tw = int(cn.sum())
-    for workers, want_copies in ((64, False), (2 * ncu, False), (3 * ncu, True), (4 * ncu, True)):
+    # (round 5: between the reference's scale and 2.5 workgroups per CU -- 257 .. 640 workers -- four target rows get copies,
+    # merged every word; 641 .. 767 stay shared)
+    for workers, want in ((64, 0), (ncu, 0), (2 * ncu, 4), (5 * ncu // 2 + 60, 0), (3 * ncu, 50), (4 * ncu, 50)):
         t = w2b.Trainer(V, D, 8, 24, 1, num_threads=workers, sample=0.0, train_words=tw, compute_loss=True)
         t.set_vocab_counts(cn, 0)
         resident, _, colb, per_cu, hot = t.worker_kernel_info()
         assert not resident and colb == 16 and per_cu == 4
-        assert (hot > 0) == want_copies, (workers, hot)
+        assert (hot == want) if want < 50 else (hot >= want), (workers, hot)
         t.close()
     t = w2b.Trainer(V, D, 8, 24, 1, num_threads=64, sample=0.0, train_words=tw, hot_rows_v=5, hot_rows_u=0)
     t.set_vocab_counts(cn, 0)
@@ -380,8 +382,18 @@ def test_copies_only_on_a_full_device_and_lossless_context_rows_below_it(gpu):
     p.set_vocab_counts(cn, 0)
     assert p.suggested_threads() == 10_000_000 // 50_000
     p.close()
-    # ... and between the reference's scale and a full device (here: 600 by the word count) it stays at 256 workers
+    # ... between the reference's scale and a full device (here: 600 by the word count): long rows take the mid range (round 5:
+    # four target rows with copies merged every word; round 4 stayed at 256), capped where it ends (2.5 workgroups per CU);
+    # short rows stay at 256 workers, where the row-group kernel runs
     p = w2b.Trainer(V, D, 8, 24, 1, num_threads=1, sample=0.0, train_words=30_000_000)
+    p.set_vocab_counts(cn, 0)
+    assert p.suggested_threads() == min(600, 5 * ncu // 2)
+    p.close()
+    p = w2b.Trainer(V, D, 8, 24, 1, num_threads=1, sample=0.0, train_words=36_000_000)
+    p.set_vocab_counts(cn, 0)
+    assert p.suggested_threads() == 5 * ncu // 2
+    p.close()
+    p = w2b.Trainer(V, 200, 8, 24, 1, num_threads=1, sample=0.0, train_words=30_000_000)
     p.set_vocab_counts(cn, 0)
     assert p.suggested_threads() == 256
     p.close()

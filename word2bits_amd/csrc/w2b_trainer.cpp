@@ -1085,10 +1085,21 @@ extern "C" int w2b_suggested_threads(w2b_trainer *t, int32_t *out) {
     const long long cap = t->cfg.train_words / (W2B_WORDS_PER_WORKER_MIN * (total > 0 ? total : 1));
     if (n > cap) n = cap > 1 ? cap : 1;
   }
-  // Plain kernel, not enough words for a full device: at most 256 workers.  Between the reference's own scale (its bands
-  // end at the 256 hardware threads of the host) and a full device the shared-row mode gains little speed (benchmark
-  // stream: 10.5 M words/s at 256 workers, 13.5 M at 512) and its epoch loss drifts (+0.8 % at 256, +1.3 ... +1.5 % at 440).
-  if (radius < 0 && n < (long long)W2B_FULL_DEVICE_WG_PER_CU * t->num_cus && n > 256) n = 256;
+  // Not enough words for a full device.  Round 4 stopped at 256 workers here, the reference's own scale: beyond it the
+  // shared-row mode drifted (+1.3 ... +1.5 % at 440 workers on the benchmarked regime).  Round 5:
+  //   * rows of at most 512 floats stay at 256 workers -- the row-group kernel runs there (22 M words/s at -size 200; with the
+  //     mid-range copies the plain kernel would run instead, at half of that);
+  //   * longer rows go on to the mid range (257 .. 640 workers, four target rows with copies merged every word: within 0.5 %
+  //     of the reference on the benchmarked regime and 35-45 % faster than 256 workers: 13.5 M words/s at 440, 14.3 M at 512-640
+  //     on the 22 M-token headline-shape file, where 256 workers run 9.9 M).
+  if (radius < 0 && n < (long long)W2B_FULL_DEVICE_WG_PER_CU * t->num_cus && n > W2B_REFERENCE_SCALE) {
+    const long long mid_top = 5ll * t->num_cus / 2;                      // where mid_range() ends
+    const bool short_rows = t->cfg.plain_worker_kernel != 1 && t->cfg.layer1_size <= W2B_GROUPS_AUTO_DIM;
+    n = short_rows ? W2B_REFERENCE_SCALE : (n < mid_top ? n : mid_top);
+    int nu = 0, nv = 0;
+    xhot_plan(t, n, true, &nu, &nv, false);
+    if (nv == 0) n = W2B_REFERENCE_SCALE;                                 // (no copies for this trainer -- relaxed rows, flat counts, ...: the reference's scale)
+  }
   *out = (int32_t)n;
   return W2B_OK;
 }
