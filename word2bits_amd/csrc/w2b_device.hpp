@@ -434,15 +434,15 @@ __device__ __forceinline__ void xhot_merge_row(float *tab, float *copy, float *e
   if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one merge event of a workgroup of the plain kernels: P.xhot_m rows of each table, rotating through the sets
-template <int MM>
+template <int MM, int TB = -1>
 __device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot &X, int &cursor, int col0, bool active) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int j = 0; j < P.xhot_m; j++) {
     const int i = cursor + j;
     if (X.nu > 0 && j < X.nu)
-      xhot_merge_row<MM, -1>(P.u, X.cu, X.eu, X.lu, i % X.nu, X.nu, P.dim, col0, active, wave, lane, P.tab_bytes, P.xhot_w);
+      xhot_merge_row<MM, TB>(P.u, X.cu, X.eu, X.lu, i % X.nu, X.nu, P.dim, col0, active, wave, lane, P.tab_bytes, P.xhot_w);
     if (X.nv > 0 && j < X.nv)
-      xhot_merge_row<MM, -1>(P.v, X.cv, X.ev, X.lv, i % X.nv, X.nv, P.dim, col0, active, wave, lane, P.tab_bytes, P.xhot_w);
+      xhot_merge_row<MM, TB>(P.v, X.cv, X.ev, X.lv, i % X.nv, X.nv, P.dim, col0, active, wave, lane, P.tab_bytes, P.xhot_w);
   }
   cursor += P.xhot_m;
 }
@@ -457,7 +457,10 @@ __device__ __forceinline__ void xhot_merge_event(const W2bParams &P, const XHot 
 // ATOM (16-byte columns only): which tables have rows that are updated with atomic adds -- 0 none, 1 u (context rows, phase
 // C), 2 u and v.  Instantiations of their own, so that the transposes of the atomic form cost the others no registers
 // (compiled into one kernel they spilled 7 more VGPRs: 77.9 % -> 73.2 % of the roofline at the headline shape).
-template <int QM, int VEC, bool LOSS, int MM, int ATOM = 0>
+// TB: how rows are addressed (load_col): -1 = decided at run time from P.tab_bytes, 0 = one buffer resource per table (tables
+// below 2 GiB: the worker kernel's 16-byte-column instantiations are compiled for it since round 5 -- the run-time form costs
+// ~20 scalar instructions per row access and SGPRs that the kernel, at exactly its register budget, spills)
+template <int QM, int VEC, bool LOSS, int MM, int ATOM = 0, int TB = -1>
 __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &L, const QParam &qp,
                                              const int cw, const int nt, const float alpha,
                                              double &loss_acc, const XHot &X) {
@@ -480,24 +483,24 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
   // row accesses: a hot row at this XCD's copy (VEC == 4 only), every other row at its master address
   auto ld_u = [&](int row) -> Col<VEC> {
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) return xhot_ld(X.cu, row - 1, nhu, dim, col0); }
-    return load_col<VEC, MM>(P.u, row, dim, col0, P.tab_bytes);
+    return load_col<VEC, MM, TB>(P.u, row, dim, col0, P.tab_bytes);
   };
   // row <- val (= old + d): a store (hot rows: to this XCD's copy), or an atomic add of d for rows 1..atomic_rank
   // (VEC == 4: only the ATOM instantiations look at the ranks; the 4-byte-column kernels decide at run time)
   const int atomic_rank = (VEC == 4 && ATOM < 2) ? 0 : P.atomic_rank, atomic_rank_u = (VEC == 4 && ATOM < 1) ? 0 : P.atomic_rank_u;
   auto up_u = [&](int row, const Col<VEC> &val, const Col<VEC> &d) {
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhu) { xhot_st(X.cu, row - 1, nhu, dim, col0, val); return; } }
-    if (row <= atomic_rank_u) add_col<VEC>(P.u, row, dim, col0, d, P.tab_bytes);
-    else store_col<VEC, MM>(P.u, row, dim, col0, val, P.tab_bytes);
+    if (row <= atomic_rank_u) add_col<VEC, TB>(P.u, row, dim, col0, d, P.tab_bytes);
+    else store_col<VEC, MM, TB>(P.u, row, dim, col0, val, P.tab_bytes);
   };
   auto ld_v = [&](int row) -> Col<VEC> {
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) return xhot_ld(X.cv, row - 1, nhv, dim, col0); }
-    return load_col<VEC, MM>(P.v, row, dim, col0, P.tab_bytes);
+    return load_col<VEC, MM, TB>(P.v, row, dim, col0, P.tab_bytes);
   };
   auto up_v = [&](int row, const Col<VEC> &val, const Col<VEC> &d) {
     if constexpr (VEC == 4) { if ((unsigned)(row - 1) < (unsigned)nhv) { xhot_st(X.cv, row - 1, nhv, dim, col0, val); return; } }
-    if (row <= atomic_rank) add_col<VEC>(P.v, row, dim, col0, d, P.tab_bytes);
-    else store_col<VEC, MM>(P.v, row, dim, col0, val, P.tab_bytes);
+    if (row <= atomic_rank) add_col<VEC, TB>(P.v, row, dim, col0, d, P.tab_bytes);
+    else store_col<VEC, MM, TB>(P.v, row, dim, col0, val, P.tab_bytes);
   };
   // one chunk of target rows
   auto load_targets = [&](bool zero) {
@@ -646,7 +649,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
           if (!by_add) up_v(rows[i], x[i], dl);
         }
         if constexpr (VEC == 4 && ATOM >= 2) {
-          if (by_add) add_col_contig<>(P.v, rows[i], dim, dl, P.tab_bytes);
+          if (by_add) add_col_contig<TB>(P.v, rows[i], dim, dl, P.tab_bytes);
         }
       }
     }
@@ -694,7 +697,7 @@ __device__ __forceinline__ void process_word(const W2bParams &P, const WordLds &
                   r[jj].e[e] = r[jj].e[e] + dl.e[e];
                 }
               }
-              if (by_add) add_col_contig<>(P.u, crow, dim, dl, P.tab_bytes);   // (every one of the m updates is an add of its own)
+              if (by_add) add_col_contig<TB>(P.u, crow, dim, dl, P.tab_bytes);   // (every one of the m updates is an add of its own)
             }
             if (!by_add && active) up_u(crow, r[jj], dl);
           }

@@ -5,7 +5,7 @@
 namespace {
 // ------------------------------------------------------------------------------------ form (i): workers
 
-template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM, int ATOM = 0>
+template <int QM, int VEC, bool LOSS, int MAXTHREADS, int MM, int ATOM = 0, int TB = -1>
 __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES : 1)) k_train_workers(const W2bParams P, const long long max_positions) {
   extern __shared__ int smem[];
   WordLds L = carve_word_lds(smem, P.window, P.negative, VEC);
@@ -116,11 +116,11 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
     if constexpr (VEC == 1 && MAXTHREADS == 1024) wide = P.wide != 0;
     if (cw > 0) {
       if (wide) { if constexpr (VEC == 1 && MAXTHREADS == 1024) process_word_wide<QM, LOSS, MM>(P, L, qp, cw, nt, alpha, loss_acc); }
-      else process_word<QM, VEC, LOSS, MM, ATOM>(P, L, qp, cw, nt, alpha, loss_acc, XH);
+      else process_word<QM, VEC, LOSS, MM, ATOM, TB>(P, L, qp, cw, nt, alpha, loss_acc, XH);
     } else __syncthreads();
     if (VEC == 4 && hot && ++since_merge >= P.hot_period) {
       since_merge = 0;
-      xhot_merge_event<MM>(P, XH, merge_cursor, tid * VEC, tid * VEC < P.dim);
+      xhot_merge_event<MM, TB>(P, XH, merge_cursor, tid * VEC, tid * VEC < P.dim);
     }
   }
   // save the worker
@@ -171,12 +171,16 @@ hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool 
 #define W2B_LAUNCH_W(VEC, LOSS) \
     do { if (threads <= 256) hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 256, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); \
          else hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 1024, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); } while (0)
-    if constexpr (MM == 0) {          // rows updated with atomic adds (w2b_tuning.atomic_rank*): the ATOM instantiations (16-byte columns)
+    if constexpr (MM == 0) {          // coherent rows, 16-byte columns, at most 256 threads: the instantiations with the row addressing
+      // fixed at compile time (TB) and, where rows are updated with atomic adds (w2b_tuning.atomic_rank*), the ATOM ones
       const int atom = p.atomic_rank > 0 ? 2 : (p.atomic_rank_u > 0 ? 1 : 0);
-      if (atom && vec == 4 && threads <= 256) {
-#define W2B_LAUNCH_A(LOSS, ATOM) hipLaunchKernelGGL((k_train_workers<QM, 4, LOSS, 256, 0, ATOM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions)
-        if (atom == 2) { if (loss) W2B_LAUNCH_A(true, 2); else W2B_LAUNCH_A(false, 2); }
-        else { if (loss) W2B_LAUNCH_A(true, 1); else W2B_LAUNCH_A(false, 1); }
+      if (vec == 4 && threads <= 256 && (atom || p.tab_bytes != 0)) {
+#define W2B_LAUNCH_A(LOSS, ATOM, TB) hipLaunchKernelGGL((k_train_workers<QM, 4, LOSS, 256, 0, ATOM, TB>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions)
+#define W2B_LAUNCH_AT(LOSS, ATOM) do { if (p.tab_bytes != 0) W2B_LAUNCH_A(LOSS, ATOM, 0); else W2B_LAUNCH_A(LOSS, ATOM, -1); } while (0)
+        if (atom == 2) { if (loss) W2B_LAUNCH_AT(true, 2); else W2B_LAUNCH_AT(false, 2); }
+        else if (atom == 1) { if (loss) W2B_LAUNCH_AT(true, 1); else W2B_LAUNCH_AT(false, 1); }
+        else { if (loss) W2B_LAUNCH_A(true, 0, 0); else W2B_LAUNCH_A(false, 0, 0); }
+#undef W2B_LAUNCH_AT
 #undef W2B_LAUNCH_A
         return hipGetLastError();
       }
