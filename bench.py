@@ -23,13 +23,17 @@ The headline runs WITH the loss bookkeeping (--loss 1): the instantiation ./word
 
 Prints ONE JSON line on rank 0 (contract in the task description) with extra objects:
   roofline     -- algorithmic HBM bytes per launch / hipEvent-measured launch duration vs 8 TB/s, min / median / max per
-                  launch, and the HBM bytes of the calibrated rocprofv3 counters (profiles/r04_pmc_worker.json)
+                  launch, and the HBM bytes of the calibrated rocprofv3 counters (quoted from profiles/r05_pmc_worker.json:
+                  traffic_measured_in_this_run = false)
   cpu_baseline -- the reference CPU program (oracle/_ref/word2bits_stock, built from the unmodified reference sources)
                   on all host threads, training phase of a whole epoch over a bounded corpus of the same shape;
                   cpu_baseline_1thread (the same with -threads 1, a 20 s sample), cpu_baseline_configs0 (BASELINE
                   configs[0]: size 200, -threads 1)
-  legs         -- without_loss_bookkeeping, bitlevel2, relaxed_coherence, other_shapes (tuples, configs[4] shape, size 200,
-                  size 400: automatic kernel and the explicit sentence-resident one), e2e (quoted from profiles/)
+  legs         -- without_loss_bookkeeping, bitlevel2, relaxed_coherence, other_shapes (tuples; configs[4] shape at bitlevel 1 and 0;
+                  size 200 and size 400 / 2 bits with the automatic kernel -- the row-group kernel since round 5 -- and with the
+                  plain kernel beside it; partial_device = the headline shape on a 22 M-token stream; the explicit
+                  sentence-resident kernel), e2e (./word2bits end to end, measured in this run; the reference's side quoted
+                  from profiles/), us_per_word_per_worker
 """
 import argparse
 import json
