@@ -179,7 +179,7 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
       unsigned long long rng = S->rng;
       long long cursor = S->cursor, wc = S->wc, last_wc = S->last_wc;
       int sen_len = S->sen_len, sen_pos = S->sen_pos, ovr = S->override_, eof = S->eof;
-      int done = 0, cw = 0, nt = 0, ndup = 0;
+      int done = 0, cw = 0, nt = 0;
       // (requested first, used last: its round trip runs beside the unigram-table draws'.  The schedule below may store a new
       // alpha in this very pass -- only every 10000 words of this worker, and the other workers' stores land at any time anyway)
       const float alpha_now = __hip_atomic_load(&P.shared->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -240,41 +240,6 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
             nt = 1 + __popcll(m);
             rng = ja_k * rng + jc_k;
             alpha = alpha_own ? alpha_set : alpha_now;                // (a worker sees the alpha it has just stored, as the plain kernel's load after the store does)
-            if (lane < W2G_TMAX) O->own[lane] = -1;
-            W2B_WAVE_SYNC();
-            // duplicates among the targets: occurrence number and first occurrence of every row
-            const int me = (lane < nt) ? O->tgt[lane] : (-1 - lane);
-            int occ = 0, root = lane;
-            for (int j = 0; j < nt; j++) {
-              const int tj = __builtin_amdgcn_readlane(me, j);
-              const bool hit = (tj == me) && (j < lane);
-              occ += hit ? 1 : 0;
-              root = (hit && j < root) ? j : root;
-            }
-            const bool first = (lane < nt) && (occ == 0);
-            const unsigned long long mf = __ballot(first);
-            const int n = __popcll(mf & lane_lt_mask(lane));            // number of this row among the distinct rows
-            if (first) O->own[(n % G) * TC + n / G] = lane;
-            const int nroot = __builtin_amdgcn_ds_bpermute(root << 2, n);
-            const bool isdup = (lane < nt) && (occ > 0);
-            const unsigned long long md = __ballot(isdup);
-            if (isdup) {
-              const int dpos = __popcll(md & lane_lt_mask(lane));
-              O->dup_i[dpos] = lane;
-              O->dup_g[dpos] = nroot % G;
-            }
-            ndup = __popcll(md);
-            // context rows: multiplicity at the first occurrence, 0 at later ones (a row that occurs m times in the window
-            // is updated m times, ref :494-503)
-            const int mc = (lane < cw) ? O->ctx[lane] : (-1 - lane);
-            bool cfirst = true;
-            int mult = 0;
-            for (int j = 0; j < cw; j++) {
-              const int cj = __builtin_amdgcn_readlane(mc, j);
-              cfirst = cfirst && !(j < lane && cj == mc);
-              mult += (j >= lane && cj == mc) ? 1 : 0;
-            }
-            if (lane < cw) O->umult[lane] = cfirst ? mult : 0;
           }
           sen_pos++;                                                    // ref :505-509
           if (sen_pos >= sen_len) sen_len = 0;
@@ -292,11 +257,60 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
         S->sen_len = sen_len; S->sen_pos = sen_pos; S->override_ = ovr; S->eof = eof;
         if (done) S->done = 1;
         O->stop = (done || last) ? 1 : 0;
-        O->cw = cw; O->nt = nt; O->npass = 1 + ndup; O->n_dup = ndup; O->alpha = alpha;
+        O->cw = cw; O->nt = nt; O->npass = 1; O->n_dup = 0; O->alpha = alpha;       // (npass / n_dup: prepare(), below)
         O->rc_n = (P.rc_rows > 0 && __builtin_nontemporal_load(&P.rc_flags[16 + xcd]) != 0) ? P.rc_rows : 0;
       }
     };
+    // second half of a pass: the bookkeeping of the lists produce() has written -- which group holds which distinct target row,
+    // the repetitions, the context rows' multiplicities.  A pass of its own so that the producer's work spreads over two barrier
+    // intervals of the data wavefronts (produce: under their wait for the target rows; prepare: under their error sum) instead
+    // of holding one barrier up (phase timers: 3 K of 20 K cycles per word were spent waiting for the producer at B3).
+    auto prepare = [&](W2G_LDS GLists *O) {
+      W2B_WAVE_SYNC();
+      const int cw = __builtin_amdgcn_readfirstlane(O->cw), nt = __builtin_amdgcn_readfirstlane(O->nt);
+      if (cw <= 0) return;
+      int ndup = 0;
+      {
+        if (lane < W2G_TMAX) O->own[lane] = -1;
+        W2B_WAVE_SYNC();
+        // duplicates among the targets: occurrence number and first occurrence of every row
+        const int me = (lane < nt) ? O->tgt[lane] : (-1 - lane);
+        int occ = 0, root = lane;
+        for (int j = 0; j < nt; j++) {
+          const int tj = __builtin_amdgcn_readlane(me, j);
+          const bool hit = (tj == me) && (j < lane);
+          occ += hit ? 1 : 0;
+          root = (hit && j < root) ? j : root;
+        }
+        const bool first = (lane < nt) && (occ == 0);
+        const unsigned long long mf = __ballot(first);
+        const int n = __popcll(mf & lane_lt_mask(lane));            // number of this row among the distinct rows
+        if (first) O->own[(n % G) * TC + n / G] = lane;
+        const int nroot = __builtin_amdgcn_ds_bpermute(root << 2, n);
+        const bool isdup = (lane < nt) && (occ > 0);
+        const unsigned long long md = __ballot(isdup);
+        if (isdup) {
+          const int dpos = __popcll(md & lane_lt_mask(lane));
+          O->dup_i[dpos] = lane;
+          O->dup_g[dpos] = nroot % G;
+        }
+        ndup = __popcll(md);
+        // context rows: multiplicity at the first occurrence, 0 at later ones (a row that occurs m times in the window
+        // is updated m times, ref :494-503)
+        const int mc = (lane < cw) ? O->ctx[lane] : (-1 - lane);
+        bool cfirst = true;
+        int mult = 0;
+        for (int j = 0; j < cw; j++) {
+          const int cj = __builtin_amdgcn_readlane(mc, j);
+          cfirst = cfirst && !(j < lane && cj == mc);
+          mult += (j >= lane && cj == mc) ? 1 : 0;
+        }
+        if (lane < cw) O->umult[lane] = cfirst ? mult : 0;
+      }
+      if (lane == 0) { O->npass = 1 + ndup; O->n_dup = ndup; }
+    };
     produce(&F->lists[0], max_positions <= 0);
+    prepare(&F->lists[0]);
     __syncthreads();                                                    // B0
     for (long long it = 0;; ++it) {
       const W2G_LDS GLists *const L = &F->lists[it & 1];
@@ -309,8 +323,11 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
       if (cw > 0) {
         if (RW > 1) for (int ps = 0; ps < npass; ps++) __syncthreads();
         __syncthreads();                                                // B3
+        W2G_TICK(1);
+        prepare(&F->lists[(it + 1) & 1]);                               // (under the data wavefronts' error sum)
+        W2G_TICK(0);
         __syncthreads();                                                // B4
-      }
+      } else prepare(&F->lists[(it + 1) & 1]);
       __syncthreads();                                                  // B0
     }
   } else if (wave == NDW + 1) {
