@@ -719,7 +719,12 @@ __global__ void __launch_bounds__(256) k_refresh_rows(const W2bParams P) {
     if (sweep == 0 && tid == 0) __builtin_nontemporal_store(1, &P.rc_flags[16 + xcd]);       // the copies of this XCD are filled
     const int done = __hip_atomic_load(&P.shared->launch_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done >= P.num_threads) break;
-    if (__builtin_readcyclecounter() - t_start > 240000000000ull) break;     // (100 s of shader clock: never spin forever)
+    if (__builtin_readcyclecounter() - t_start > 240000000000ull) {          // (100 s of shader clock: never spin forever)
+      // a launch this long outlives its refresher: the XCD's workers go back to the master rows instead of reading copies
+      // that nobody re-fills any more
+      if (tid == 0) __builtin_nontemporal_store(0, &P.rc_flags[16 + xcd]);
+      break;
+    }
   }
 }
 
