@@ -128,13 +128,12 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
   constexpr int NDW = G * RW, NTHR = (NDW + 2) * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nrf = 0;
   const bool rc_on = P.rc_rows > 0;                                    // a refresher kernel runs beside this launch (k_refresh_rows)
   // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): the XCD this workgroup runs on
   const int xcd = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (W2B_NXCD - 1);
   const unsigned rc_bytes = (unsigned)(P.rc_rows * dim * 4);
   float *const rc_copy = P.rc + (long long)xcd * P.rc_rows * dim;
-  const int wid = (int)blockIdx.x - nrf;
+  const int wid = (int)blockIdx.x;
   W2bWorker *const Gw = P.workers + (wid < P.num_threads ? wid : 0);
   if (wid >= P.num_threads || Gw->done) {
     if (rc_on && tid == 0 && wid < P.num_threads) atomicAdd(&P.shared->launch_done, 1);
