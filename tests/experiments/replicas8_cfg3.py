@@ -37,6 +37,7 @@ def timed(fn):
 def exchange(ts, mode, cost):
     begun = [t.exchange_begin() for t in ts]
     n_chunks = begun[0][0]
+    scale = 1.0 / len(ts) if mode == 1 else 1.0          # mode 0 delta-sum, 1 average, 2 contributor mean of the saturated rows
     if mode == 2:
         cnts = [t.device_tensor(*t.exchange_counts()) for t in ts]
         total = torch.stack(cnts).sum(0)
@@ -58,9 +59,9 @@ def exchange(ts, mode, cost):
         torch.cuda.synchronize()
         for i, t in enumerate(ts):
             if i == 0:
-                cost["apply_ms"] += timed(lambda: t.exchange_apply(c, 1.0))
+                cost["apply_ms"] += timed(lambda: t.exchange_apply(c, scale))
             else:
-                t.exchange_apply(c, 1.0)
+                t.exchange_apply(c, scale)
     cost["exchanges"] += 1
     words = sum(b[1] for b in begun)
     for t in ts:
