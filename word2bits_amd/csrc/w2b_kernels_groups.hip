@@ -9,14 +9,16 @@
 // (vmcnt is in order on gfx9): 26 us per centre word where one thread of the reference takes 5.7 us.  Here
 //   * the rows of a centre word are spread over G ROW GROUPS (a group = RW wavefronts = one thread per 16-byte column, as
 //     in the plain kernel): group g loads the context rows at window positions g, g + G, ... and the distinct target rows
-//     number g, g + G, ... -- ALL negative + 1 targets are in flight at once, ONE memory round trip per centre word;
+//     number g, g + G, ... -- ALL negative + 1 targets are in flight at once: two memory round trips per centre word (context
+//     rows, then -- on purpose only then -- target rows, so that a racy shared target row is open for one round trip);
 //   * what crosses groups goes through LDS: the raw context rows (window average, ref :431-449, summed by every thread in
 //     window order; the same values feed phase C), the quantized target rows and their gradient scalars (error
 //     accumulation, ref :486-488, summed by every thread in TARGET ORDER) -- so every element sees the reference's
 //     order of operations exactly as in the plain kernel, and the dot product uses the plain kernel's tree: one worker is
 //     bit-identical to the plain kernel (tests/test_gpu_groups.py);
 //   * a PRODUCER wavefront runs the scalar side (sentence reader, window draw, unigram-table draws, alpha schedule,
-//     duplicate bookkeeping; ref :379-460) one centre word ahead into double-buffered lists, and the sigmoid table
+//     duplicate bookkeeping; ref :379-460) one centre word ahead into double-buffered lists -- in two passes, produce() under
+//     the data wavefronts' wait for the target rows and prepare() under their error sum --, and the sigmoid table
 //     (ref :614-618) sits in LDS -- no memory latency of the scalar side is left on the data wavefronts' path;
 //   * an ADDER wavefront issues the lossless adds of the accumulated error to the frequent context rows
 //     (`u[c] += e[c]` on the current value, ref :500-502; rows 1..atomic_rank_u) from a copy of the error vector in LDS,
@@ -25,8 +27,11 @@
 //     longer in front of the data wavefronts' next loads;
 //   * a target row that repeats inside a centre word is taken again, after its first update, by the group that owns
 //     it (same threads, program order), one extra pass per repetition -- the CPU's sequential semantics.
+//   * the very hottest context rows (P.rc_rows of them) are READ at a copy per XCD that k_refresh_rows, a small kernel on a
+//     stream of its own, keeps re-filling from the master rows while the launch runs; their updates stay lossless adds at the
+//     master address (a read of a line that the memory side is adding to waits for the adds: DESIGN.md section 3.3c).
 // Shapes: -size a multiple of 4 up to 1024 (RW = 1 / 2 / 4 wavefronts per row), window <= 16, negative + 1 <= G * TC,
-// tables below 4 GiB, coherent rows, no per-XCD copies; everything else runs the plain kernel.
+// tables below 2 GiB, coherent rows, no per-XCD consensus copies; everything else runs the plain kernel.
 #include "w2b_device.hpp"
 
 #define W2G_LDS __attribute__((address_space(3)))
