@@ -301,6 +301,11 @@ HELDOUT = {
 HELDOUT_BIG = {
     "heldout_k5_big": dict(corpus=dict(vocab=100_000, n_tokens=60_000_000, s=1.0, every=5, seed=43),
                            flags=dict(bitlevel=1, size=300, window=5, negative=5, iter=1, sample=0)),
+    # round 6 (asked for by the round-5 review, recorded BEFORE any constant of the full-device mode was touched again): a second
+    # held-out full-device long-stream regime -- a vocabulary of a million words, a steeper distribution, another row length,
+    # window and number of negatives than anything the merge period / weight / number of copies were ever measured on
+    "heldout_v1m": dict(corpus=dict(vocab=1_000_000, n_tokens=80_000_000, s=1.1, every=5, seed=44),
+                        flags=dict(bitlevel=1, size=512, window=5, negative=10, iter=1, sample=0)),
 }
 
 

@@ -58,6 +58,7 @@ int main() {
       run<2, 16>("nt+sc1", row, G, 400, sl);     // L1-bypassing L2-cached loads, write-through stores
       run<0, 16>("pl+sc1", row, G, 400, sl);     // plain loads, write-through stores
       run<16, 0>("sc1+pl", row, G, 400, sl);
+      run<2, 0>("nt+pl", row, G, 400, sl);       // round 6: L1-bypassing loads, plain write-back stores (what an XCD's copies of the hot rows use)
     }
   }
   // fine-grained / uncached allocations with plain accesses

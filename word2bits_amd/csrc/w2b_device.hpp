@@ -90,9 +90,17 @@ template <int VEC> struct Col { float e[VEC]; };
 #define W2B_EXACT_COLS 256    // columns whose products sit in LDS at a time in the exact mode
 // MM 5 (W2B_MM_XCD) = nt loads + nt stores: past the CU's L1, served by and kept in the XCD's L2 -- the per-XCD copies
 // of the hottest rows (XHot below)
+// MM 6 = nt loads + PLAIN (write-back) stores.  Round 6: what the per-XCD copies of the hot rows are stored with.  On gfx950 an
+// nt store is written through to memory (round-5 counters: the copies took 19 GB of reads per launch off the fabric and only
+// 2 GB of writes); a plain store leaves the line dirty in the XCD's L2 -- the only cache that serves a copy during a launch
+// (the loads stay nt: past the CU's L1) -- and it reaches memory when it is evicted or the kernel ends (k_xhot_fold runs
+// behind a kernel boundary).  W2B_XCD_STORE_AUX=2 builds the round-5 policy for same-box A/Bs.
+#ifndef W2B_XCD_STORE_AUX
+#define W2B_XCD_STORE_AUX 2   // (until the same-box A/B of round 6 says otherwise)
+#endif
 template <int MM> struct Aux {
-  static constexpr int load = (MM == 0 || MM == W2B_MM_EXACT) ? 16 : ((MM == 2 || MM == 5) ? 2 : 0);
-  static constexpr int store = (MM == 1) ? 0 : ((MM == 5) ? 2 : 16);
+  static constexpr int load = (MM == 0 || MM == W2B_MM_EXACT) ? 16 : ((MM == 2 || MM == 5 || MM == 6) ? 2 : 0);
+  static constexpr int store = (MM == 1) ? 0 : ((MM == 5) ? 2 : ((MM == 6) ? W2B_XCD_STORE_AUX : 16));
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -372,6 +380,7 @@ __device__ __forceinline__ void add_col_contig(float *tab, long long row, int di
 // k_xhot_fold (w2b_kernels_misc.hip) applies the same rule for all eight copies before and after every launch, so
 // between launches the master rows are complete and copy == entry == master.  16-byte columns only (VEC == 4).
 #define W2B_MM_XCD 5          // Aux<>: nt loads + nt stores (XCD scope)
+#define W2B_MM_XHOT_ST 6      // Aux<>: nt loads + W2B_XCD_STORE_AUX stores: the hot-row copies' stores (round 6: plain write-back)
 struct XHot {
   float *cu, *cv, *eu, *ev;    // this XCD's copies of the hot rows of u / v, and their entry values
   unsigned *lu, *lv;           // merge locks [row][W2B_MAXW]
@@ -397,7 +406,7 @@ __device__ __forceinline__ Col<4> xhot_ld(const float *rows, int k, int n, int d
   return load_col<4, W2B_MM_XCD, 0>(rows, k, dim, col0, (unsigned)(n * dim * 4));
 }
 __device__ __forceinline__ void xhot_st(float *rows, int k, int n, int dim, int col0, const Col<4> &c) {
-  store_col<4, W2B_MM_XCD, 0>(rows, k, dim, col0, c, (unsigned)(n * dim * 4));
+  store_col<4, W2B_MM_XHOT_ST, 0>(rows, k, dim, col0, c, (unsigned)(n * dim * 4));
 }
 // hot row k (master row k + 1 of `tab`) of this XCD meets memory: this wavefront's segment of the row.
 // MM / TB: how the master rows are accessed; w: weight of this XCD's copy in the consensus.

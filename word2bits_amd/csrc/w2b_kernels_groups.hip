@@ -697,15 +697,16 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
 // over and over until every worker workgroup of the launch has finished.  Nobody waits for a refresher: while an XCD's
 // copies are not filled its workers read the master rows.
 __global__ void __launch_bounds__(256) k_refresh_rows(const W2bParams P) {
-  __shared__ int claim;
+  __shared__ int claim, stop;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, dim = P.dim;
   const int xcd = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (W2B_NXCD - 1);
-  if (tid == 0) claim = (atomicCAS(&P.rc_flags[xcd], 0, 1) == 0) ? 1 : 0;
+  if (tid == 0) { claim = (atomicCAS(&P.rc_flags[xcd], 0, 1) == 0) ? 1 : 0; stop = 0; }
   __syncthreads();
   if (!claim) return;
   const unsigned rc_bytes = (unsigned)(P.rc_rows * dim * 4);
   float *const rc_copy = P.rc + (long long)xcd * P.rc_rows * dim;
-  const unsigned long long t_start = __builtin_readcyclecounter();
+  // wall_clock64(): s_memrealtime, a constant 100 MHz on gfx9 whatever the shader clock does
+  const unsigned long long t_start = wall_clock64(), t_limit = 100ull * 100000000ull;     // 100 s: never spin forever
   for (long long sweep = 0;; ++sweep) {
     for (int r0 = wave; r0 < P.rc_rows; r0 += 16) {                  // four rows of this wavefront in flight at a time
       for (int c = lane * 4; c < dim; c += 256) {
@@ -720,15 +721,21 @@ __global__ void __launch_bounds__(256) k_refresh_rows(const W2bParams P) {
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (sweep == 0 && tid == 0) __builtin_nontemporal_store(1, &P.rc_flags[16 + xcd]);       // the copies of this XCD are filled
-    const int done = __hip_atomic_load(&P.shared->launch_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (done >= P.num_threads) break;
-    if (__builtin_readcyclecounter() - t_start > 240000000000ull) {          // (100 s of shader clock: never spin forever)
-      // a launch this long outlives its refresher: the XCD's workers go back to the master rows instead of reading copies
-      // that nobody re-fills any more
-      if (tid == 0) __builtin_nontemporal_store(0, &P.rc_flags[16 + xcd]);
-      break;
+    // ONE thread reads the workers' counter and the clock and publishes the decision: every wavefront takes the same branch
+    // (round 5 let every thread load `done` for itself, so wavefronts could disagree about leaving the loop: advisor finding)
+    if (tid == 0) {
+      if (sweep == 0) __builtin_nontemporal_store(1, &P.rc_flags[16 + xcd]);                  // the copies of this XCD are filled
+      const int done = __hip_atomic_load(&P.shared->launch_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done >= P.num_threads) stop = 1;
+      else if (wall_clock64() - t_start > t_limit) {
+        // a launch this long outlives its refresher: the XCD's workers go back to the master rows instead of reading copies
+        // that nobody re-fills any more
+        __builtin_nontemporal_store(0, &P.rc_flags[16 + xcd]);
+        stop = 1;
+      }
     }
+    __syncthreads();
+    if (stop) break;
   }
 }
 

@@ -1180,13 +1180,19 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   if (radius >= 0) HIPCHK(w2b_launch_resident(p, max_positions, radius, t->cfg.compute_loss != 0, t->stream, t->debug));
   else if (groups_plan(t, t->cfg.num_threads) && w2b_groups_ok(p)) {
     if (int rc = rc_prepare(t, p, t->cfg.num_threads)) return rc;
-    if (p.rc_rows > 0) {               // the refresher runs beside the launch on its own stream and ends when the workers have
-      HIPCHK(hipEventRecord(t->rc_go, t->stream));
+    // The refresher runs beside the launch on a stream of its own and ends when the workers have.  Order (advisor, round 5):
+    // rc_go (flags and counter of this launch cleared) -> the WORKERS on the training stream -> the refresher on its stream,
+    // waiting for rc_go only.  Wherever the two kernels cannot run side by side (streams sharing a hardware queue, serialised
+    // launches for debugging) the refresher then starts after the workers, finds launch_done == num_threads, does one sweep
+    // and exits -- round 5 launched it first, where it would have spun until its time-out with the workers queued behind it.
+    // A failed worker launch returns before the refresher is enqueued.
+    if (p.rc_rows > 0) HIPCHK(hipEventRecord(t->rc_go, t->stream));
+    HIPCHK(w2b_launch_groups(p, max_positions, t->cfg.compute_loss != 0, t->stream));
+    if (p.rc_rows > 0) {
       HIPCHK(hipStreamWaitEvent(t->rc_stream, t->rc_go, 0));
       HIPCHK(w2b_launch_refresher(p, t->rc_stream));
       HIPCHK(hipEventRecord(t->rc_end, t->rc_stream));
     }
-    HIPCHK(w2b_launch_groups(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   }
   else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));

@@ -152,13 +152,13 @@ class Trainer:
     def get_tuning(self):
         tn = _lib.Tuning()
         check(lib().w2b_get_tuning(self._h, C.byref(tn)))
-        return {k: getattr(tn, k) for k, _ in _lib.Tuning._fields_ if k not in ("struct_size", "reserved")}
+        return {k: getattr(tn, k) for k, _ in _lib.Tuning._fields_ if k != "struct_size"}
 
     def set_tuning(self, **kw):
         tn = _lib.Tuning()
         check(lib().w2b_get_tuning(self._h, C.byref(tn)))
         for k, v in kw.items():
-            if k in ("struct_size", "reserved") or not hasattr(tn, k):
+            if k == "struct_size" or not hasattr(tn, k):
                 raise TypeError("unknown tuning knob %r" % k)
             setattr(tn, k, int(v))
         check(lib().w2b_set_tuning(self._h, C.byref(tn)))
