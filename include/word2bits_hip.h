@@ -157,6 +157,16 @@ typedef struct w2b_tuning {
    * what bounds the shared-row mode: DESIGN.md section 3.3c).  0 = the library decides from the word counts and the number
    * of workers (none for a few workers), -1 = none, > 0 = rows 1..N (at most 64, and never beyond the rows with lossless adds). */
   int32_t refresh_rows_u;
+  /* round 6 (the struct grew by 16 bytes: struct_size tells the versions apart).  Replica exchange, mode 2: how the deltas of the
+   * c replicas that changed a row are combined.  exchange_rule 0 (default) = continuous saturation: the SUM of the deltas times
+   *     k = (1 - exp(-c n / tau)) / (c (1 - exp(-n / tau))),   n = expected updates of the row per replica since the last exchange
+   * (from the word counts), i.e. the sum for rarely updated rows, the mean for rows every replica has saturated and everything in
+   * between; exchange_tau_u / exchange_tau_v = tau for rows of u / v in updates (0 = the library's defaults).  exchange_rule 1 =
+   * the hard threshold of rounds 4-5 (mean for rows with n >= exchange_sat_updates, sum otherwise). */
+  int32_t exchange_rule;
+  int32_t exchange_tau_u;
+  int32_t exchange_tau_v;
+  int32_t reserved_r6;     /* must be zero */
 } w2b_tuning;
 /* What the library decides for a launch of the automatic worker kernel with `workers` concurrent workers on a GPU with `num_cus`
  * compute units, from the word counts alone (pure host arithmetic: usable -- and tested -- without a GPU): per-XCD copies

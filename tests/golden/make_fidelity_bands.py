@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--cfg1", default="256x1", help="threads x runs for job cfg1_100m: BASELINE configs[1] LITERALLY -- the 100 M-token stream "
                                                     "bench.py times (every word 5x + 98 M Zipf(1) tokens), ~13 minutes of a 256-thread host per run")
     ap.add_argument("--heldout-big", default="256x1", help="threads x runs for job heldout_k5_big (60 M tokens, ~5.5 minutes per run)")
+    ap.add_argument("--reuse-corpus", default="", help="HELDOUT_BIG jobs: an existing corpus file (written by write_heldout_corpus for one of "
+                                                       "the jobs named) is used as it is and left in place -- a session that runs ./word2bits on the same file "
+                                                       "writes it once")
     ap.add_argument("--tmp", default="/tmp/w2b_bands")
     a = ap.parse_args()
     os.makedirs(a.tmp, exist_ok=True)
@@ -157,7 +160,7 @@ def main():
         os.remove(corpus)
     for name in HELDOUT_BIG:              # round 4 recorded ONE run of this; round 5 adds to it
         if name in jobs:
-            corpus = write_heldout_corpus(os.path.join(a.tmp, name + ".txt"), name)
+            corpus = a.reuse_corpus or write_heldout_corpus(os.path.join(a.tmp, name + ".txt"), name)
             fl = HELDOUT_BIG[name]["flags"]
             flags = sum((["-" + k, str(v)] for k, v in fl.items()), []) + ["-min-count", "5", "-binary", "1"]
             job = {"corpus": "write_heldout_corpus(%r): %r" % (name, HELDOUT_BIG[name]["corpus"]), "flags": fl, "runs": []}
@@ -165,7 +168,8 @@ def main():
             for th, runs in spec(a.heldout_big):
                 job["runs"] += run_many(corpus, flags, th, runs, a.tmp, serial=True)
                 flush()
-            os.remove(corpus)
+            if not a.reuse_corpus:
+                os.remove(corpus)
     flush()
 
 

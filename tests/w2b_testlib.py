@@ -306,6 +306,13 @@ HELDOUT_BIG = {
     # window and number of negatives than anything the merge period / weight / number of copies were ever measured on
     "heldout_v1m": dict(corpus=dict(vocab=1_000_000, n_tokens=80_000_000, s=1.1, every=5, seed=44),
                         flags=dict(bitlevel=1, size=512, window=5, negative=10, iter=1, sample=0)),
+    # round 6 (review, weak 1d): the row lengths at which the row-group kernel is the automatic choice (BASELINE configs[0] /
+    # configs[2]) on a LONG stream -- 100 M tokens over the text8-sized vocabulary, the reference's default sub-sampling;
+    # round 5 had only ever checked that kernel on corpora of at most 17 M tokens
+    "long_d200": dict(corpus=dict(vocab=70_000, n_tokens=100_000_000, s=1.0, every=0, seed=45),
+                      flags=dict(bitlevel=1, size=200, window=8, negative=24, iter=1)),
+    "long_d400b2": dict(corpus=dict(vocab=70_000, n_tokens=100_000_000, s=1.0, every=0, seed=45),
+                        flags=dict(bitlevel=2, size=400, window=8, negative=24, iter=1)),
 }
 
 

@@ -94,32 +94,18 @@ __global__ void k_xchg_delta(float *w, const float *__restrict__ base, float *__
 // s now holds the sum over all replicas.  What the OTHER replicas added, a * s - d (a = 1: delta-sum, a = 1 / replicas:
 // average of the deltas), goes on top of the rows as they are NOW -- whatever this replica has trained since the delta
 // was taken stays -- and base becomes the common state base + a * s.  Elements nobody else touched are not written.
-// cnt (optional): per ROW of [u || v], how many replicas have changed the row since the last exchange.  Rows 1..sat_u of
-// u and 1..sat_v of v -- the rows that have received so many updates in every replica since the last exchange that each
-// replica's delta is already most of the way to where the row wants to be (w2b_trainer.cpp, xchg_saturated) -- take
-// a / cnt of the summed delta, the mean over the replicas that changed the row: the sum of c such deltas over-shoots
-// c-fold (measured on the text8-sized corpus, one exchange per launch: 2 replicas -11 % of the epoch loss, 4 replicas
-// diverge; a / sqrt(cnt): -2.5 % and -17 %; the mean: -2.5 % and -6.8 %).  Every other row keeps the sum: few updates,
-// no saturation, and the sum of the replicas' deltas is what one shared model would have received -- in particular a
-// row that only one replica saw keeps that replica's whole update, which a plain average (mode 1) divides by R.
-// first = index of w[0] in [u || v]; V = rows per table.
+// fac (optional): per ROW of [u || v] a factor on the summed delta (k_xchg_factor below: 1 for a row that only one replica
+// changed, towards 1 / contributors for a row that every replica has saturated).  first = index of w[0] in [u || v].
 __global__ void k_xchg_apply(float *w, float *__restrict__ base, const float *__restrict__ d, const float *__restrict__ s,
-                             float a, long long n, const float *__restrict__ cnt, long long first, int dim, long long V,
-                             int sat_u, int sat_v) {
+                             float a, long long n, const float *__restrict__ fac, long long first, int dim) {
   const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (int)(n * 4), 0x27000);
   w2b_f4 *b4 = reinterpret_cast<w2b_f4 *>(base);
   const w2b_f4 *d4 = reinterpret_cast<const w2b_f4 *>(d), *s4 = reinterpret_cast<const w2b_f4 *>(s);
-  auto scale = [&](long long i) -> float {          // i: float index inside this chunk
-    if (!cnt) return a;
-    const long long g = (first + i) / dim, r = g >= V ? g - V : g;
-    if (r < 1 || r > (g >= V ? sat_v : sat_u)) return a;
-    const float c = cnt[g];
-    return c > 1.f ? a / c : a;
-  };
+  auto scale = [&](long long i) -> float { return fac ? a * fac[(first + i) / dim] : a; };   // i: float index inside this chunk
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     w2b_f4 sum = s4[i];
-    if (!cnt) sum = sum * a;
+    if (!fac) sum = sum * a;
     else { sum.x *= scale(4 * i); sum.y *= scale(4 * i + 1); sum.z *= scale(4 * i + 2); sum.w *= scale(4 * i + 3); }
     const w2b_f4 others = sum - d4[i];
     b4[i] = b4[i] + sum;
@@ -132,6 +118,39 @@ __global__ void k_xchg_apply(float *w, float *__restrict__ base, const float *__
       const float x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (int)(i * 4), 0, 16)) + others;
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rw, (int)(i * 4), 0, 16);
     }
+  }
+}
+// The combination rule of mode 2, per ROW of [u || v]: cnt[g] (in) = number of replicas that changed row g since the last
+// exchange, (out) = the factor k on the SUM of their deltas.
+//   rule 0 (round 6, default) -- continuous saturation.  A row that has received n updates in a replica since the last
+//     exchange has contracted towards where those updates pull it by rho = 1 - exp(-n / tau) (alpha = 0.05: a few dozen
+//     updates move a row most of the way).  c replicas' updates applied one after the other -- what the reference's threads
+//     do to one shared row, ref :489-491,:500-502 -- would have contracted it by 1 - (1 - rho)^c; the sum of the c deltas is
+//     c * rho.  So
+//         k = (1 - exp(-c n / tau)) / (c (1 - exp(-n / tau)))       -> 1 for n << tau (the sum), -> 1 / c for n >> tau (the mean)
+//     with n = rate[g] * words (expected updates of the row per trained centre word, from the word counts, times the centre
+//     words a replica has trained since the last exchange) and tau = tau_u for rows of u, tau_v for rows of v.
+//   rule 1 (rounds 4-5) -- hard threshold: k = 1 / c for rows 1..sat_u of u / 1..sat_v of v (n >= 32), 1 otherwise.  On a
+//     Zipf vocabulary the rows within a factor of a few of ANY threshold carry the same share of all updates whatever the
+//     interval -- the 8-replica run of round 5 ended 9 % off the single replica at 131 K and at 16 K words alike.
+__global__ void k_xchg_factor(float *__restrict__ cnt, const float *__restrict__ rate, float words, float tau_u, float tau_v,
+                              long long V, int rule, int sat_u, int sat_v) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < 2 * V; g += stride) {
+    const float c = cnt[g];
+    float k = 1.f;
+    if (c > 1.f) {
+      const bool is_v = g >= V;
+      if (rule == 1) {
+        const long long r = is_v ? g - V : g;
+        if (r >= 1 && r <= (is_v ? sat_v : sat_u)) k = 1.f / c;
+      } else if (rate) {
+        const float x = rate[g] * words / (is_v ? tau_v : tau_u);
+        if (x > 1e-6f) k = expm1f(-c * x) / (c * expm1f(-x));
+        k = fminf(1.f, fmaxf(k, 1.f / c));
+      }
+    }
+    cnt[g] = k;
   }
 }
 // cnt[r] = 1 if row r of [u || v] differs from base (this replica has trained it since the last exchange), else 0.
@@ -267,8 +286,13 @@ hipError_t w2b_launch_xchg_delta(float *w, const float *base, float *d, float *s
   return hipGetLastError();
 }
 hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n,
-                                 const float *cnt, long long first, int dim, long long V, int hot_u, int hot_v, hipStream_t s) {
-  hipLaunchKernelGGL(k_xchg_apply, dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n, cnt, first, dim, V, hot_u, hot_v);
+                                 const float *fac, long long first, int dim, hipStream_t s) {
+  hipLaunchKernelGGL(k_xchg_apply, dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n, fac, first, dim);
+  return hipGetLastError();
+}
+hipError_t w2b_launch_xchg_factor(float *cnt, const float *rate, float words, float tau_u, float tau_v, long long V, int rule,
+                                  int sat_u, int sat_v, hipStream_t s) {
+  hipLaunchKernelGGL(k_xchg_factor, dim3(512), dim3(256), 0, s, cnt, rate, words, tau_u, tau_v, V, rule, sat_u, sat_v);
   return hipGetLastError();
 }
 hipError_t w2b_launch_xchg_touched(const float *w, const float *base, float *cnt, long long rows, int dim, hipStream_t s) {

@@ -100,9 +100,12 @@ struct w2b_trainer {
   bool x_open = false;                      // the exchange in progress has begun and not ended
   long long x_words_full = 0;               // centre words since the previous exchange
   hipEvent_t x_evd[2] = {nullptr, nullptr}, x_evs[2] = {nullptr, nullptr}, x_evc = nullptr;   // delta / sum of a slot complete; counts summed
-  float *xcnt = nullptr;                    // [2 * vocab_size]: replicas that changed each row (contributor-average mode)
+  float *xcnt = nullptr;                    // [2 * vocab_size]: replicas that changed each row, then the row's factor on the summed delta (mode 2)
+  float *xrate = nullptr;                   // [2 * vocab_size]: expected updates of every row of [u || v] per trained centre word (from the word counts)
+  bool x_fac_pending = false;               // xcnt holds contributor counts that k_xchg_factor has not yet turned into factors
   bool x_use_cnt = false;                   // the exchange in progress damps the saturated rows' sums by xcnt
   int x_sat_u = 0, x_sat_v = 0;             // rows 1..x_sat_* of u / v count as saturated in the exchange in progress
+  long long x_words_sync = 0;               // x_words_full at the begin of the exchange in progress (the n of the combination rule)
   long long x_words = 0;                    // centre words this replica can have trained since the previous exchange (launches x
                                             // positions x workers: the same number on every replica of a symmetric job)
   long long xchunk = 0;                     // floats per chunk
@@ -384,6 +387,8 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
   if (in->hot_weight_permille < 1 || in->hot_weight_permille > 1000)
     return fail(W2B_EINVAL, "w2b_set_tuning: hot_weight_permille must be 1..1000");
   if (in->refresh_rows_u < -1 || in->refresh_rows_u > W2B_RC_MAX) return fail(W2B_EINVAL, "w2b_set_tuning: refresh_rows_u must be -1 .. 64");
+  if (in->exchange_rule < 0 || in->exchange_rule > 1 || in->exchange_tau_u < 0 || in->exchange_tau_v < 0 || in->reserved_r6 != 0)
+    return fail(W2B_EINVAL, "w2b_set_tuning: exchange_rule must be 0 or 1, exchange_tau_* >= 0, reserved_r6 == 0");
   t->tune = *in;
   return W2B_OK;
 }
@@ -562,6 +567,8 @@ static void word_rates(w2b_trainer *t, const int64_t *cn, const std::vector<floa
   }
 }
 
+static int xchg_upload_rates(w2b_trainer *t);   // per-row update rates for the replica exchange's combination rule (below)
+
 extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t table_size) {
   NEED(t);
   if (!cn) return fail(W2B_EINVAL, "w2b_set_vocab_counts: null counts");
@@ -571,6 +578,7 @@ extern "C" int w2b_set_vocab_counts(w2b_trainer *t, const int64_t *cn, int64_t t
   if (!t->keep) HIPCHK(hipMalloc(&t->keep, sizeof(float) * V));
   HIPCHK(hipMemcpy(t->keep, keep.data(), sizeof(float) * V, hipMemcpyHostToDevice));
   word_rates(t, cn, keep);
+  if (int rc = xchg_upload_rates(t)) return rc;
   if (table_size > 0) {
     std::vector<int32_t> tab((size_t)table_size);
     int rc = w2b_build_unigram_table(cn, V, tab.data(), table_size);
@@ -1375,9 +1383,30 @@ static void xchg_teardown(w2b_trainer *t) {
   t->x_train = t->x_evc = nullptr;
   t->x_any_done = false;
   if (t->xcnt) (void)hipFree(t->xcnt);
+  if (t->xrate) (void)hipFree(t->xrate);
   if (t->base) (void)hipFree(t->base);
   t->xcnt = nullptr;
+  t->xrate = nullptr;
   t->base = nullptr;
+}
+
+// Expected updates of every row of [u || v] per trained centre word, from the word counts (what word_rates computes for the
+// leading rows, for all of them): a context row (u) is updated once per window it is in -- window + 1 windows per kept
+// occurrence on average --, a target row (v) once per draw from the unigram table (ref :112-128, 455-458: raw
+// counts; row 0 is remapped, never drawn) and once as the centre word.  "Kept": what survives sub-sampling (ref :403-406).
+static int xchg_upload_rates(w2b_trainer *t) {
+  if (!t->xrate || t->counts.empty() || t->counts_tot_kept <= 0 || t->counts_pw <= 0) return W2B_OK;
+  const long long V = t->cfg.vocab_size;
+  const double st = (double)t->cfg.sample * (double)t->cfg.train_words;
+  auto kept = [&](double c) { return (t->cfg.sample > 0 && st > 0) ? (c < sqrt(c * st) + st ? c : sqrt(c * st) + st) : c; };
+  std::vector<float> r((size_t)(2 * V), 0.f);
+  for (long long a = 1; a < V; a++) {
+    const double c = (double)t->counts[(size_t)a], k = kept(c) / t->counts_tot_kept;
+    r[(size_t)a] = (float)((t->cfg.window + 1) * k);
+    r[(size_t)(V + a)] = (float)(t->cfg.negative * pow(c, 0.75) / t->counts_pw + k);
+  }
+  HIPCHK(hipMemcpy(t->xrate, r.data(), sizeof(float) * 2 * V, hipMemcpyHostToDevice));
+  return W2B_OK;
 }
 
 static int xchg_setup(w2b_trainer *t) {
@@ -1398,6 +1427,8 @@ static int xchg_setup(w2b_trainer *t) {
   if (e == hipSuccess && !t->wca_buf) e = hipMalloc(&t->wca_buf, 2 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc(&t->xcnt, sizeof(float) * 2 * t->cfg.vocab_size);
   if (e == hipSuccess) e = hipMemsetAsync(t->xcnt, 0, sizeof(float) * 2 * t->cfg.vocab_size, t->stream);
+  if (e == hipSuccess) e = hipMalloc(&t->xrate, sizeof(float) * 2 * t->cfg.vocab_size);
+  if (e == hipSuccess) e = hipMemsetAsync(t->xrate, 0, sizeof(float) * 2 * t->cfg.vocab_size, t->stream);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_train, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&t->x_evc, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMemcpyAsync(t->base, t->uv, sizeof(float) * n, hipMemcpyDeviceToDevice, t->stream);
@@ -1406,6 +1437,7 @@ static int xchg_setup(w2b_trainer *t) {
     xchg_teardown(t);                          // everything or nothing: a retry starts from scratch
     return fail(W2B_EHIP, std::string("replica exchange setup: ") + hipGetErrorString(e));
   }
+  if (int rc = xchg_upload_rates(t)) { xchg_teardown(t); return rc; }   // (word counts given later: w2b_set_vocab_counts uploads them)
   return W2B_OK;
 }
 
@@ -1531,6 +1563,8 @@ static int xchg_begin(w2b_trainer *t) {
   t->x_ranges.clear();
   xchg_add_range(t, 0, 2 * t->table_elems);
   xchg_saturated_prefix(t, t->x_words_full, &t->x_sat_u, &t->x_sat_v);    // over the words since the last exchange
+  t->x_words_sync = t->x_words_full;
+  t->x_fac_pending = false;
   return W2B_OK;
 }
 static int xchg_delta(w2b_trainer *t, long long c) {
@@ -1539,11 +1573,24 @@ static int xchg_delta(w2b_trainer *t, long long c) {
   HIPCHK(w2b_launch_xchg_delta(t->uv + r.off, t->base + r.off, t->xd[k], t->xsum[k], r.len, t->xs[0]));
   return W2B_OK;
 }
+// contributor counts in xcnt -> factors on the summed delta (k_xchg_factor), once per exchange, on stream q
+static const double W2B_XCHG_TAU_U = 32.0, W2B_XCHG_TAU_V = 32.0;   // updates that move a row most of the way (see k_xchg_factor)
+static int xchg_factor(w2b_trainer *t, hipStream_t q) {
+  if (!t->x_fac_pending) return W2B_OK;
+  const int rule = t->tune.exchange_rule;
+  const float tau_u = t->tune.exchange_tau_u > 0 ? (float)t->tune.exchange_tau_u : (float)W2B_XCHG_TAU_U;
+  const float tau_v = t->tune.exchange_tau_v > 0 ? (float)t->tune.exchange_tau_v : (float)W2B_XCHG_TAU_V;
+  HIPCHK(w2b_launch_xchg_factor(t->xcnt, t->counts.empty() ? nullptr : t->xrate, (float)t->x_words_sync, tau_u, tau_v, t->cfg.vocab_size,
+                                rule, t->x_sat_u, t->x_sat_v, q));
+  t->x_fac_pending = false;
+  return W2B_OK;
+}
 static int xchg_apply(w2b_trainer *t, long long c, float scale) {
   const auto &r = t->x_ranges[(size_t)c];
   const int k = (int)(c & 1);
+  if (t->x_use_cnt) if (int rc = xchg_factor(t, t->xs[0])) return rc;
   HIPCHK(w2b_launch_xchg_apply(t->uv + r.off, t->base + r.off, t->xd[k], t->xsum[k], scale, r.len, t->x_use_cnt ? t->xcnt : nullptr,
-                               r.off, t->cfg.layer1_size, t->cfg.vocab_size, t->x_sat_u, t->x_sat_v, t->xs[0]));
+                               r.off, t->cfg.layer1_size, t->xs[0]));
   return W2B_OK;
 }
 // per row of [u || v]: has this replica changed it since the last exchange?
@@ -1586,6 +1633,8 @@ static int xchg_run_rccl(w2b_trainer *t, int32_t mode) {
   if (mode == 2) {          // who has trained which row since the last exchange (2 V floats), before the first apply
     if (int rc = xchg_touched(t, Cs)) return rc;
     NCCLCHK(ncclAllReduce(t->xcnt, t->xcnt, (size_t)(2 * t->cfg.vocab_size), ncclFloat, ncclSum, t->comm, Cs));
+    t->x_fac_pending = true;
+    if (int rc = xchg_factor(t, Cs)) return rc;
     HIPCHK(hipEventRecord(t->x_evc, Cs));
     HIPCHK(hipStreamWaitEvent(E, t->x_evc, 0));
   }
@@ -1648,6 +1697,7 @@ extern "C" int w2b_exchange_counts(w2b_trainer *t, void **buf_dev, int64_t *elem
   if (int rc = xchg_touched(t, t->xs[0])) return rc;
   HIPCHK(hipStreamSynchronize(t->xs[0]));
   t->x_use_cnt = true;
+  t->x_fac_pending = true;                   // (the host sums the counts; the first w2b_exchange_apply turns them into factors)
   *buf_dev = t->xcnt;
   *elems = 2 * t->cfg.vocab_size;
   return W2B_OK;
