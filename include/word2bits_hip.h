@@ -92,6 +92,7 @@ typedef struct w2b_config {
 const char *w2b_version(void);
 const char *w2b_last_error(void);       /* thread-local text of the last failure */
 int w2b_device_count(void);             /* number of visible HIP devices (0 when none) */
+int w2b_device_compute_units(int32_t device);   /* compute units of that device (what w2b_plan_rows takes as num_cus); <= 0: no such device */
 
 /* ---- host-side tables of the reference (pure host code, usable without a GPU) ---------- */
 /* expTable, ref src/word2bits.cpp:614-618; out[1000] */

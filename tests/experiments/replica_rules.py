@@ -39,6 +39,7 @@ ap.add_argument("--negative", type=int, default=24)
 ap.add_argument("--window", type=int, default=8)
 ap.add_argument("--bitlevel", type=int, default=1)
 ap.add_argument("--single", type=float, default=0.0, help="epoch loss of the single replica (skips that run)")
+ap.add_argument("--single-validation", type=float, default=0.0)
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -71,6 +72,21 @@ def row_factor(rule, words):
         tau = torch.where(is_v, torch.full_like(n, float(rule[2])), torch.full_like(n, float(rule[1])))
         x = (n / tau).double().clamp_min(1e-9)
         return ((1 - torch.exp(-R * x)) / (R * (1 - torch.exp(-x)))).float()
+    if kind == "table":
+        # measured curves (tests/experiments/replica_truth.py): per table k(log2 n) piecewise linear, times a multiplier by the
+        # row's rate log2(n / words), and a constant for the rows the single replica would give per-XCD copies (rate >= hot)
+        spec = json.load(open(rule[1]))
+        nn = n.double().clamp_min(2.0 ** -20).log2().cpu().numpy()
+        rr = rate_dev.double().clamp_min(2.0 ** -40).log2().cpu().numpy()
+        k = np.ones(2 * V)
+        for tab, sl in (("u", slice(0, V)), ("v", slice(V, 2 * V))):
+            t = spec[tab]
+            kk = np.interp(nn[sl], [p[0] for p in t["k"]], [p[1] for p in t["k"]])
+            kk = kk * np.interp(rr[sl], [p[0] for p in t["rate"]], [p[1] for p in t["rate"]])
+            kk = np.where(rr[sl] >= t["hot_log2r"], t["hot_k"], kk)
+            k[sl] = kk
+        scale = float(rule[2]) if len(rule) > 2 else 1.0
+        return torch.tensor(np.clip(k * scale, 0.0, 1.0), dtype=torch.float32, device=dev)
     return None
 
 
@@ -153,6 +169,30 @@ def sync_points(spec):
                 yield False, k
 
 
+_val = {}
+
+
+def validation_loss(t):
+    """log-likelihood of a FIXED sample of (centre, 9 context words, 24 negatives) tuples under the trainer's final model:
+    w2b_train_tuples with alpha = 0 computes the loss terms of ref :480-483 and changes nothing (g = 0).  What the replicas'
+    final model is worth beside the single replica's, without the staleness that the on-line epoch loss also counts."""
+    if not _val:
+        rng = np.random.default_rng(99)
+        nv = 200_000
+        cdf = np.cumsum(c64[1:] / c64[1:].sum())
+        draw = lambda m: (np.searchsorted(cdf, rng.random(m)) + 1).clip(1, V - 1).astype(np.int32)
+        pw = c64[1:] ** 0.75
+        cdfn = np.cumsum(pw / pw.sum())
+        _val["center"] = draw(nv)
+        _val["ctx"] = draw(nv * 9)
+        _val["off"] = (np.arange(nv + 1) * 9).astype(np.int32)
+        neg = (np.searchsorted(cdfn, rng.random(nv * a.negative)) + 1).clip(1, V - 1).astype(np.int32).reshape(nv, a.negative)
+        neg[neg == _val["center"][:, None]] = -1
+        _val["neg"] = neg
+    t.synchronize()
+    return t.train_tuples(_val["center"], _val["off"], _val["ctx"], _val["neg"], 0.0)
+
+
 def run(Rn, rule, bf16=False):
     per = a.workers // Rn
     starts, ov = corpus.shards(a.workers)
@@ -189,17 +229,21 @@ def run(Rn, rule, bf16=False):
         if done:
             break
     loss = sum(t.epoch_status()[3] for t in ts)
+    val = validation_loss(ts[0])
     for t in ts:
         t.close()
-    return loss, launches, exchanges
+    return loss, launches, exchanges, val
 
 
 if a.single:
     one = a.single
+    if a.single_validation:
+        res["single_replica_validation"] = a.single_validation
 else:
     t0 = time.time()
-    one, l1, _ = run(1, ("sum",))
-    print("RR 1 replica x %d workers: loss %.0f, %d launches  [%.0f s]" % (a.workers, one, l1, time.time() - t0), flush=True)
+    one, l1, _, val1 = run(1, ("sum",))
+    print("RR 1 replica x %d workers: loss %.0f, validation %.0f, %d launches  [%.0f s]" % (a.workers, one, val1, l1, time.time() - t0), flush=True)
+    res["single_replica_validation"] = val1
 res["single_replica_loss"] = one
 for spec in a.rules.split(";"):
     spec = spec.strip()
@@ -210,16 +254,17 @@ for spec in a.rules.split(";"):
     t0 = time.time()
     stats.clear()
     try:
-        loss, launches, exchanges = run(R, rule, bf16)
+        loss, launches, exchanges, val = run(R, rule, bf16)
     except Exception as e:                                  # keep sweeping
         print("RR rule %s failed: %r" % (spec, e), flush=True)
         continue
     dev_pct = 100 * (loss - one) / abs(one)
-    rec = {"rule": spec, "loss": loss, "deviation_pct": dev_pct, "launches": launches, "exchanges": exchanges,
+    rec = {"rule": spec, "loss": loss, "deviation_pct": dev_pct, "validation": val, "launches": launches, "exchanges": exchanges,
            "words_per_replica_per_launch": a.positions * (a.workers // R), **stats}
     res["runs"].append(rec)
-    print("RR %d replicas, sync %-12s positions %5d, rule %-22s: loss %.0f (%+.2f %% vs 1 replica), %d launches, %d exchanges %s [%.0f s]" % (
-        R, a.sync, a.positions, spec, loss, dev_pct, launches, exchanges, json.dumps(stats), time.time() - t0), flush=True)
+    vdev = 100 * (val - res["single_replica_validation"]) / abs(res["single_replica_validation"]) if res.get("single_replica_validation") else float("nan")
+    print("RR %d replicas, sync %-12s positions %5d, rule %-26s: loss %.0f (%+.2f %% vs 1 replica), final model on a fixed sample %.0f (%+.2f %%), %d launches, %d exchanges %s [%.0f s]" % (
+        R, a.sync, a.positions, spec, loss, dev_pct, val, vdev, launches, exchanges, json.dumps(stats), time.time() - t0), flush=True)
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
 corpus.close()

@@ -61,6 +61,7 @@ SIGNATURES = {
     "w2b_version": (C.c_char_p, []),
     "w2b_last_error": (C.c_char_p, []),
     "w2b_device_count": (C.c_int, []),
+    "w2b_device_compute_units": (C.c_int, [C.c_int32]),
     "w2b_build_exp_table": (None, [f32p]),
     "w2b_build_unigram_table": (C.c_int, [i64p, C.c_int64, i32p, C.c_int64]),
     "w2b_build_keep_prob": (None, [i64p, C.c_int64, C.c_float, C.c_int64, f32p]),

@@ -34,6 +34,15 @@
 // tables below 2 GiB, coherent rows, no per-XCD consensus copies; everything else runs the plain kernel.
 #include "w2b_device.hpp"
 
+// W2B_GROUPS_DRAIN: a row stored by one row group in word n may be loaded by another group (another wavefront) in word n + 1.
+// __syncthreads() on gfx950 does not wait for outstanding vector-memory operations, so without a drain that read-after-write
+// across wavefronts relies on the CU issuing its vector memory operations to the memory system in order (what the bit-identity
+// tests of tests/test_gpu_groups.py check on every word of a Zipf stream).  1: every data wavefront waits for its stores
+// (s_waitcnt vmcnt(0)) before the barrier that ends a word; 2: the adder wavefront waits for its atomic adds as well.  Measured
+// in round 6 (profiles/r06_sessions/): see DESIGN.md section 3.3c for what each level costs and which one ships.
+#ifndef W2B_GROUPS_DRAIN
+#define W2B_GROUPS_DRAIN 0
+#endif
 #define W2G_LDS __attribute__((address_space(3)))
 #define W2G_CMAX 32      // context rows of a centre word (window <= 16)
 #define W2G_TMAX 32      // targets of a centre word (negative + 1 <= G * TC <= 32)
@@ -387,6 +396,9 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
         }
         W2G_TICK(2);
       }
+#if W2B_GROUPS_DRAIN >= 2
+      __builtin_amdgcn_s_waitcnt(0);                                    // ... and the adder's lossless adds have returned
+#endif
       __syncthreads();                                                  // B0
     }
   } else {
@@ -595,40 +607,56 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
         W2G_TICK(6);
         __syncthreads();                                                // B3
         W2G_TICK(7);
-        // ---- error accumulation in target order (ref :486-488)
-        Col<4> err;
-#pragma unroll
-        for (int e = 0; e < 4; e++) err.e[e] = 0.f;
+        // ---- error accumulation in target order (ref :486-488).  Round 5 let every row group sum all nt quantized target rows
+        // for its own copy of the columns -- G times the same 25-row LDS sum (3.5 K of a word's 20 K cycles).  Round 6: the
+        // columns are split over ALL data wavefronts of the worker, one thread per EC consecutive floats, every element still
+        // summed by one thread in target order (same bits); the vector goes to LDS once, where the adder wavefront wanted it
+        // anyway, and every thread reads its 16-byte column back after B4.
         {
+          constexpr int EC = (RW == 4) ? 2 : 1;                         // NDW * 64 threads cover 256 / 512 / 1024 floats
+          const int ecol = (wave * 64 + lane) * EC;
+          const bool eact = ecol < dim;
           const float gv = (lane < nt) ? F->gs[lane] : 0.f;             // lane i: g of target i (negative + 1 <= 32)
+          float er[EC];
+#pragma unroll
+          for (int e = 0; e < EC; e++) er[e] = 0.f;
           int i0 = 0;
           for (; i0 + LE <= nt; i0 += LE) {                             // whole trips: straight-line code, LDS reads LE rows ahead
-            Col<4> c[LE];
+            float c[LE][EC];
 #pragma unroll
             for (int ii = 0; ii < LE; ii++)
-              if (active) c[ii] = lds_ld4(xq + (i0 + ii) * dim + col0);
+              if (eact) {
+#pragma unroll
+                for (int e = 0; e < EC; e++) c[ii][e] = xq[(i0 + ii) * dim + ecol + e];
+              }
 #pragma unroll
             for (int ii = 0; ii < LE; ii++) {
               const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), i0 + ii));
-              if (active) {
+              if (eact) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) err.e[e] += gi * c[ii].e[e];
+                for (int e = 0; e < EC; e++) er[e] += gi * c[ii][e];
               }
             }
           }
           for (; i0 < nt; i0++) {
             const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gv), i0));
-            if (active) {
-              const Col<4> c = lds_ld4(xq + i0 * dim + col0);
+            if (eact) {
 #pragma unroll
-              for (int e = 0; e < 4; e++) err.e[e] += gi * c.e[e];
+              for (int e = 0; e < EC; e++) er[e] += gi * xq[i0 * dim + ecol + e];
             }
           }
+          if (eact) {
+#pragma unroll
+            for (int e = 0; e < EC; e++) errbuf[ecol + e] = er[e];
+          }
         }
-        if (g == 0 && active) lds_st4(errbuf + col0, err);
         W2G_TICK(8);
         __syncthreads();                                                // B4
         W2G_TICK(9);
+        Col<4> err;
+#pragma unroll
+        for (int e = 0; e < 4; e++) err.e[e] = 0.f;
+        if (active) err = lds_ld4(errbuf + col0);
         // ---- phase C: u[ctx_j] += context_avge - 2*alpha*reg*u[ctx_j]   (ref :494-503); the adder wavefront takes the rows
         // that get lossless adds (reg == 0: their delta is the error vector itself)
 #pragma unroll
@@ -666,6 +694,9 @@ __global__ void __launch_bounds__((G * RW + 2) * 64, (RW == 4 ? 4 : 3)) k_train_
         W2G_TICK(10);
         W2G_COUNT(12);
       }
+#if W2B_GROUPS_DRAIN >= 1
+      __builtin_amdgcn_s_waitcnt(0);                                    // this wavefront's row stores have been acknowledged (see W2B_GROUPS_DRAIN)
+#endif
       __syncthreads();                                                  // B0
       W2G_TICK(11);
     }

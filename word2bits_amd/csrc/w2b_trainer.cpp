@@ -128,6 +128,14 @@ extern "C" int w2b_device_count(void) {
   return n;
 }
 
+extern "C" int w2b_device_compute_units(int32_t device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+  return prop.multiProcessorCount;
+}
+
 // ref src/word2bits.cpp:614-618 -- float expf of the host libm, exactly as the reference builds it
 extern "C" void w2b_build_exp_table(float *out) {
   for (int i = 0; i < W2B_EXP_TABLE_SIZE; i++) {

@@ -53,6 +53,8 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int refresh_rows_u = 0;              // -refresh-rows N: w2b_tuning.refresh_rows_u (0 = the library decides, -1 = none)
   std::string packed_file;             // -packed FILE: also write the final vectors bit-packed (-bitlevel 1 / 2; word2bits_corpus.h)
   int row_desc = 0;                    // -row-desc 1: the row addressing of tables >= 2 GiB on any table (w2b_tuning.force_row_desc)
+  int threads_literal = 0;             // -threads-literal 1: keep an explicit -threads N even where the library would rather fill the device
+  int xchg_rule = 0, xchg_tau_u = 0, xchg_tau_v = 0;   // -exchange-rule / -exchange-tau-u / -exchange-tau-v: w2b_tuning.exchange_* (replicas)
 };
 
 // w2b_config.plain_worker_kernel from -window-cache / -row-groups: 0 automatic, 1 plain, 2 sentence-resident, 3 row groups
@@ -206,6 +208,10 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-refresh-rows", argc, argv)) > 0) o.refresh_rows_u = atoi(argv[i + 1]);
   if ((i = arg_pos("-hot-weight", argc, argv)) > 0) o.hot_weight = atoi(argv[i + 1]);
   if ((i = arg_pos("-window-refresh", argc, argv)) > 0) o.window_refresh = atoi(argv[i + 1]);
+  if ((i = arg_pos("-threads-literal", argc, argv)) > 0) o.threads_literal = atoi(argv[i + 1]);
+  if ((i = arg_pos("-exchange-rule", argc, argv)) > 0) o.xchg_rule = atoi(argv[i + 1]);
+  if ((i = arg_pos("-exchange-tau-u", argc, argv)) > 0) o.xchg_tau_u = atoi(argv[i + 1]);
+  if ((i = arg_pos("-exchange-tau-v", argc, argv)) > 0) o.xchg_tau_v = atoi(argv[i + 1]);
 
   // ---- TrainModel, ref :518-577
   printf("Starting training using file %s\n", o.train_file.c_str());
@@ -233,15 +239,6 @@ int main(int argc, char **argv) {
                     "rate schedule (re-computed per worker every 10000 words) hardly runs, and -threads 0 keeps 50000: it picks at most "
                     "%lld workers for this file\n", o.num_threads, train_words / o.num_threads,
             train_words / 50000 > 1 ? train_words / 50000 : 1);
-  // Between the reference's own scale and a full device every row is shared by all workers (lossless context rows); on a long
-  // stream that mode drifts with the worker count (BASELINE configs[1] literally, 100 M tokens: -0.5 / -0.8 / -3.6 / -11 % of the
-  // reference's epoch loss at 64 / 128 / 256 / 512 workers; -threads 0 = a full device with per-XCD copies: -0.6 %;
-  // profiles/r05_sessions/r05o_long_stream.txt).  An explicit count in that range on a corpus that could fill the device is
-  // accepted with a warning.
-  if (o.num_threads >= 192 && o.num_threads < 768 && train_words / 50000 >= 768)
-    fprintf(stderr, "word2bits: warning: -threads %d on %lld words: below a full device all workers share every row, which "
-                    "drifts on long streams (measured -3.6 %% of the reference's epoch loss at 256 workers on a 100 M-token "
-                    "stream); -threads 0 fills the device for this file and stays within 1 %%\n", o.num_threads, train_words);
   int ndev = w2b_device_count();
   if (ndev <= 0) {
     fprintf(stderr, "word2bits: no HIP device visible; this build has no CPU path\n");
@@ -252,13 +249,14 @@ int main(int argc, char **argv) {
     fprintf(stderr, "word2bits: -gpus %d requested but %d visible\n", o.gpus, ndev);
     return 2;
   }
-  if (o.num_threads < 1) {                                   // GPU extension: -threads 0 = fill the device(s)
+  {
+    // What the library itself would run for this file (-threads 0): a probe trainer with the real vocabulary and its counts --
+    // which worker kernel runs, and with it how many workers fill the device, depends on how much of the text the most
+    // frequent words are.
     w2b_config probe_cfg;
     memset(&probe_cfg, 0, sizeof probe_cfg);
     probe_cfg.train_words = w2b_corpus_train_words(corpus);   // (with total_threads = replicas below: caps workers on small corpora)
     probe_cfg.total_threads = o.gpus;
-    // (the real vocabulary and its counts: which worker kernel runs -- and with it how many workers fill the device --
-    // depends on how much of the text the most frequent words are)
     probe_cfg.vocab_size = V; probe_cfg.layer1_size = (int32_t)o.layer1_size; probe_cfg.window = o.window;
     probe_cfg.sample = o.sample;
     probe_cfg.negative = o.negative; probe_cfg.bitlevel = o.bitlevel; probe_cfg.num_threads = 1;
@@ -272,8 +270,43 @@ int main(int argc, char **argv) {
     CK(w2b_set_vocab_counts(probe, w2b_corpus_counts(corpus), 0));
     CK(w2b_suggested_threads(probe, &per_gpu));               // workgroups resident at once on one GPU
     w2b_trainer_destroy(probe);
-    o.num_threads = per_gpu * o.gpus;
-    if (o.debug_mode > 0) printf("Hogwild workers (workgroups): %d\n", o.num_threads);
+    const int32_t cus = w2b_device_compute_units(o.device);
+    bool picked = false;                                      // the library chose the number of workers: say which
+    if (o.num_threads < 1) {                                  // GPU extension: -threads 0 = what the library picks
+      o.num_threads = per_gpu * o.gpus;
+      picked = true;
+    } else if (cus > 0 && !o.exact && !o.relaxed) {
+      // An explicit count BETWEEN the reference's own scale and a full device, on a corpus that could fill the device.  In
+      // that range every row is shared by all workers (lossless context rows), and on a long stream that mode drifts with the
+      // worker count: BASELINE configs[1] literally (100 M tokens) ends -0.5 / -0.8 / -3.6 / -11 % off the reference's epoch
+      // loss at 64 / 128 / 256 / 512 workers, where the full-device mode (per-XCD copies, consensus merges) is -0.6 %
+      // (profiles/r05_sessions/r05o_long_stream.txt).  The reference's -threads is a speed knob -- its own results do not
+      // depend on it (0.3 % between 1 and 256 threads) -- so the faithful reading of `-threads 256` on such a corpus is "train
+      // this file", not "use the mode that drifts": the library's own choice runs, with a notice (round 5 only warned).
+      // -threads-literal 1 keeps the count.  Thresholds from the device (advisor, round 5): a full device is 3 workgroups per
+      // compute unit; the drift passes the 1.5 % gate between 128 and 256 workers (a quarter of that and more is taken).
+      w2b_row_plan plan_n, plan_auto;
+      const int32_t n_per = o.num_threads / o.gpus > 0 ? o.num_threads / o.gpus : 1;
+      CK(w2b_plan_rows(&probe_cfg, nullptr, w2b_corpus_counts(corpus), cus, n_per, &plan_n));
+      CK(w2b_plan_rows(&probe_cfg, nullptr, w2b_corpus_counts(corpus), cus, per_gpu, &plan_auto));
+      // (not where the row-group kernel runs the explicit count: rows of at most 512 floats -- round 6 checked that kernel on 100 M-token
+      // streams at 256 workers: +0.1 % at -size 200, -0.6 % at -size 400 / 2 bits, tests/test_gpu_fidelity.py)
+      if (!plan_n.full_device && plan_auto.full_device && 4 * n_per >= 3 * cus && !plan_n.row_group_kernel) {
+        if (o.threads_literal)
+          fprintf(stderr, "word2bits: warning: -threads %d on %lld words: below a full device all workers share every row, which "
+                          "drifts on long streams (measured -3.6 %% of the reference's epoch loss at 256 workers on a 100 M-token "
+                          "stream); -threads 0 fills the device for this file and stays within 1 %%\n", o.num_threads, train_words);
+        else {
+          fprintf(stderr, "word2bits: notice: -threads %d on %lld words is between the reference's scale and a full device, where "
+                          "shared rows drift on long streams; running %d workers (what -threads 0 picks for this file; "
+                          "-threads-literal 1 keeps %d)\n", o.num_threads, train_words, per_gpu * o.gpus, o.num_threads);
+          o.num_threads = per_gpu * o.gpus;
+          picked = true;
+        }
+      }
+    }
+    if (o.debug_mode > 0 && picked)
+      printf("Hogwild workers (workgroups): %d\n", o.num_threads);
   }
   if (o.gpus > 1 && o.num_threads % o.gpus != 0) {
     fprintf(stderr, "word2bits: -threads must be a multiple of -gpus\n");
@@ -331,6 +364,9 @@ int main(int argc, char **argv) {
       if (o.atomic_rank_u != 0) tn.atomic_rank_u = o.atomic_rank_u;
       if (o.fresh_rank_u != 0) tn.fresh_rank_u = o.fresh_rank_u;
       if (o.refresh_rows_u != 0) tn.refresh_rows_u = o.refresh_rows_u;
+      if (o.xchg_rule > 0) tn.exchange_rule = o.xchg_rule;
+      if (o.xchg_tau_u > 0) tn.exchange_tau_u = o.xchg_tau_u;
+      if (o.xchg_tau_v > 0) tn.exchange_tau_v = o.xchg_tau_v;
       CK(w2b_set_tuning(a->r->t, &tn));
     }
     CK(w2b_init_net(a->r->t));                              // ref :528
