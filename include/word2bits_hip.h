@@ -159,11 +159,16 @@ typedef struct w2b_tuning {
    * of workers (none for a few workers), -1 = none, > 0 = rows 1..N (at most 64, and never beyond the rows with lossless adds). */
   int32_t refresh_rows_u;
   /* round 6 (the struct grew by 16 bytes: struct_size tells the versions apart).  Replica exchange, mode 2: how the deltas of the
-   * c replicas that changed a row are combined.  exchange_rule 0 (default) = continuous saturation: the SUM of the deltas times
-   *     k = (1 - exp(-c n / tau)) / (c (1 - exp(-n / tau))),   n = expected updates of the row per replica since the last exchange
-   * (from the word counts), i.e. the sum for rarely updated rows, the mean for rows every replica has saturated and everything in
-   * between; exchange_tau_u / exchange_tau_v = tau for rows of u / v in updates (0 = the library's defaults).  exchange_rule 1 =
-   * the hard threshold of rounds 4-5 (mean for rows with n >= exchange_sat_updates, sum otherwise). */
+   * c replicas that changed a row are combined.
+   *   exchange_rule 2 = exponential saturation, a per-row factor on the SUM: k = (1 - exp(-c n / tau)) / (c (1 - exp(-n / tau))),
+   *     n = expected updates of the row per replica since the last exchange (from the word counts): the sum for rarely updated
+   *     rows, the mean for rows every replica has saturated, everything in between; exchange_tau_u / exchange_tau_v = tau for rows
+   *     of u / v in updates (0 = the library's default, 64);
+   *   exchange_rule 0 (default) = the same, and per ELEMENT the whole sum wherever it lands in the same quantization cell as that
+   *     safe step (the same sign at -bitlevel 1): the forward values of the safe rule, the fp32 masters' inertia of one shared
+   *     model (-bitlevel 0 has no cells: rule 2);
+   *   exchange_rule 1 = the hard threshold of rounds 4-5 (mean for rows with n >= exchange_sat_updates, sum otherwise).
+   * What was measured, including a rule that looked optimal and diverged: DESIGN.md section 3.5. */
   int32_t exchange_rule;
   int32_t exchange_tau_u;
   int32_t exchange_tau_v;

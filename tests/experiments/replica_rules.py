@@ -72,6 +72,17 @@ def row_factor(rule, words):
         tau = torch.where(is_v, torch.full_like(n, float(rule[2])), torch.full_like(n, float(rule[1])))
         x = (n / tau).double().clamp_min(1e-9)
         return ((1 - torch.exp(-R * x)) / (R * (1 - torch.exp(-x)))).float()
+    if kind in ("smoothx", "signsafe"):
+        # smoothx:TU:TV:FLOOR:HOTK -- the exponential saturation curve, never below FLOOR, and HOTK for the rows the single replica
+        # would keep per-XCD copies of (rate >= 2^-7 per centre word at 1024 workers x 800 floats); signsafe uses it as its safe value
+        tau = torch.where(is_v, torch.full_like(n, float(rule[2])), torch.full_like(n, float(rule[1])))
+        x = (n / tau).double().clamp_min(1e-9)
+        k = ((1 - torch.exp(-R * x)) / (R * (1 - torch.exp(-x)))).float()
+        k = torch.maximum(k, torch.full_like(k, float(rule[3])))
+        hotk = float(rule[4])
+        if hotk > 0:
+            k = torch.where(rate_dev >= 2.0 ** -7, torch.full_like(k, hotk), k)
+        return k
     if kind == "table":
         # measured curves (tests/experiments/replica_truth.py): per table k(log2 n) piecewise linear, times a multiplier by the
         # row's rate log2(n / words), and a constant for the rows the single replica would give per-XCD copies (rate >= hot)
@@ -128,7 +139,20 @@ def exchange(ts, rule, words, bf16, first):
             s = st.sum(0)
             if first and c == 0:
                 stats["elements_touched_by_one_replica_chunk0"] = float((bufs[0] != 0).float().mean())
-            if k_rows is not None:
+            if rule[0] == "signsafe":
+                # per ELEMENT: the safe step (smoothx factor) decides the quantized value; where the big step (BIG x sum) lands in the
+                # same quantization cell -- the same sign at one bit -- it is taken instead: the master keeps the inertia a single
+                # shared model would have accumulated, the forward values are the safe rule's
+                big = float(rule[5])
+                base_c = ts[0].model_tensor()[c * XCHUNK: c * XCHUNK + s.numel()] - bufs[0]
+                safe = s * chunk_factor(k_rows, c * XCHUNK, s.numel())
+                bigs = s * big
+                same = torch.signbit(base_c + safe) == torch.signbit(base_c + bigs)
+                if first and c == 0:
+                    stats["elements_taking_the_big_step_chunk0"] = float(same.float().mean())
+                s = torch.where(same, bigs, safe)
+                del base_c, safe, bigs, same
+            elif k_rows is not None:
                 s.mul_(chunk_factor(k_rows, c * XCHUNK, s.numel()))
             elif rule[0] == "agree":
                 absum = st.abs().sum(0).clamp_min(1e-30)

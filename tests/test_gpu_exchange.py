@@ -122,7 +122,7 @@ def local_exchange(ts, mode=0):
     return words
 
 
-def smooth_factors(counts, words, window, negative, c, tau_u=32.0, tau_v=32.0):
+def smooth_factors(counts, words, window, negative, c, tau_u=64.0, tau_v=64.0):
     """the library's default combination rule of mode 2 restated (w2b_kernels_misc.hip k_xchg_factor, w2b_trainer.cpp
     xchg_upload_rates; -sample 0): per row of [u || v], with n = expected updates per replica since the last exchange and c =
     replicas that changed the row,  k = (1 - exp(-c n / tau)) / (c (1 - exp(-n / tau)))  for c > 1, else 1"""
@@ -140,16 +140,17 @@ def smooth_factors(counts, words, window, negative, c, tau_u=32.0, tau_v=32.0):
     return np.clip(k, 1.0 / np.maximum(c, 1), 1.0)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, "2 hard threshold"])
+@pytest.mark.parametrize("mode", [0, 1, 2, "2 saturation only", "2 hard threshold"])
 def test_phase_api_arithmetic_two_replicas(gpu, mode):
-    """W_r += a * sum - d_r on top of the CURRENT rows, base += a * sum (a = 1; 1/R; mode 2: the per-row factor of the
-    continuous saturation rule -- round 6 -- or, with exchange_rule = 1, rounds 4-5's 1 / number of replicas that changed the row
-    for the saturated rows and 1 for the others): against host arithmetic on copies of both replicas."""
+    """W_r += comb - d_r on top of the CURRENT rows, base += comb, against host arithmetic on copies of both replicas.
+    comb = a * sum with a = 1 (mode 0) / 1/R (mode 1); mode 2: a per-row factor k on the sum -- exponential saturation
+    (exchange_rule 2), or rounds 4-5's 1 / contributors for the saturated rows (exchange_rule 1) -- and, by default (exchange_rule
+    0), per element the whole sum wherever base + sum has the sign of base + k * sum (one bit: the quantization cell)."""
     R, nw = 2, 4
-    legacy = mode == "2 hard threshold"
-    if legacy:
+    rule = {"2 saturation only": 2, "2 hard threshold": 1}.get(mode, 0)
+    if isinstance(mode, str):
         mode = 2
-    ts = [small_setup(nw, R * nw, r * nw, seed=3, **(dict(exchange_rule=1) if legacy else {})) for r in range(R)]
+    ts = [small_setup(nw, R * nw, r * nw, seed=3, **(dict(exchange_rule=rule) if rule else {})) for r in range(R)]
     for t in ts:
         t.exchange_init()
         t.epoch_begin()
@@ -162,28 +163,41 @@ def test_phase_api_arithmetic_two_replicas(gpu, mode):
                 t.train_step(150)
         mine = [flat(t) for t in ts]
         d = [m - base for m in mine]
+        S = d[0] + d[1]
+        alt = None                                                          # the other admissible value where a sign is decided by rounding
         if mode == 2:
             c = sum((x.reshape(V2, D) != 0).any(1).astype(np.float32) for x in d)
-            words = 3 * 150 * nw                                            # 3 launches x 150 positions x nw workers
-            if legacy:
-                sat = saturated_rows(small_counts(3)[1], words, 5, 5)
+            nwords = 3 * 150 * nw                                           # 3 launches x 150 positions x nw workers
+            if rule == 1:
+                sat = saturated_rows(small_counts(3)[1], nwords, 5, 5)
                 assert sat.any() and not sat.all() and c[sat].max() == 2
                 k = np.where(sat, np.float32(1) / np.maximum(c, 1), np.float32(1))
             else:
-                k = smooth_factors(small_counts(3)[1], words, 5, 5, c)
+                k = smooth_factors(small_counts(3)[1], nwords, 5, 5, c)
                 both = c == 2
                 assert both.any() and k[both].min() < 0.55 and k[both].max() > 0.95   # from the mean to the sum, and in between
                 assert ((k[both] > 0.6) & (k[both] < 0.9)).any()
                 assert (k[~both] == 1).all()
-            a = k.astype(np.float32)[:, None].repeat(D, 1).ravel()
+            safe = k.astype(np.float32)[:, None].repeat(D, 1).ravel() * S
+            if rule == 0:
+                same = ((base + safe) < 0) == ((base + S) < 0)
+                assert 0.5 < same.mean() < 1.0 and (~same).sum() > 100              # both branches are exercised
+                total, alt = np.where(same, S, safe), np.where(same, safe, S)
+            else:
+                total = safe
         else:
-            a = np.float32(1.0 if mode == 0 else 1.0 / R)
-        total = a * (d[0] + d[1])
+            total = np.float32(1.0 if mode == 0 else 1.0 / R) * S
         words = local_exchange(ts, mode)
         got = [flat(t) for t in ts]
+        tol = 2e-6 + 1e-5 * np.abs(S).max() * (mode == 2 and rule != 1)
         for r in range(R):
-            want = mine[r] + (total - d[r])
-            assert np.abs(got[r] - want).max() <= 2e-6 + 1e-5 * np.abs(d[0] + d[1]).max() * (mode == 2 and not legacy), (rnd, r)
+            err = np.abs(got[r] - (mine[r] + (total - d[r])))
+            if alt is not None:                                             # (an element whose sign hangs on the last bit of k may take the other branch)
+                bad = err > tol
+                assert bad.mean() < 1e-4, (rnd, r, bad.mean())
+                err = np.where(bad, np.abs(got[r] - (mine[r] + (alt - d[r]))), err)
+                total = np.where(bad, alt, total) if r == 0 else total
+            assert err.max() <= tol, (rnd, r, err.max())
             assert np.abs(got[r] - mine[r]).max() > 0            # the other replica's work arrived
         base = base + total
         assert words == sum(t.epoch_status(want_loss=False)[1] for t in ts)
@@ -294,17 +308,20 @@ def test_training_effect_of_the_exchange_text8_size(gpu, tmp_path_factory):
 EXCHANGE_RTOL = {2: 0.015, 4: 0.03}
 
 
-def test_eight_replicas_at_the_configs3_shape_recorded(gpu, tmp_path):
+EIGHT_REPLICAS_RTOL = 0.04
+
+
+def test_eight_replicas_at_the_configs3_shape(gpu, tmp_path):
     """BASELINE configs[3] on ONE GPU through the phase API: 8 replicas at the configs[1] shape (V = 400 K, size 800, negative
-    24, bitlevel 1), 128 workers each, on the 22 M-token proxy file, against the single replica with the same 1024 workers.
-    This is a RECORD of where the design stands, with bounds loose enough to hold and tight enough to notice a change
-    (profiles/r05_sessions/r05p_replicas8_22m.txt, r05m_replicas8.txt): without an exchange before the end of the epoch the
-    8 replicas end 24-25 % off; a full exchange (contributor mean) after every launch of 131 K centre words per replica: -9 %;
-    after every 16 K words: -10 % (no better); after every 1 M words -- all that 2.56 GB per exchange over xGMI allows beside a
-    40 ms launch, DESIGN.md section 3.5 -- it is WORSE than none (-29 %; on the literal 100 M-token stream -12.6 % against
-    -11.6 %).  Two replicas of this code are within 0.8 % and four within 1.6 % (text8-sized corpus, above); eight at this shape
-    are not within any gate, whatever the interval: the multi-GPU path is built and exercised, not faithful yet.
-    The exchange's elementwise kernels cost 2 + 3 ms per full exchange of the 2.56 GB model."""
+    24, bitlevel 1), 128 workers each, on the 22 M-token proxy file, against the single replica with the same 1024 workers; a full
+    exchange after every launch of 131 K centre words per replica (what `./word2bits -gpus 8` picks for this file: ~21 exchanges
+    per epoch).  Round 5 RECORDED this at -9 % (mean of the contributors for saturated rows) and called the path "built, not
+    faithful".  Round 6 (profiles/r06_sessions/): the exponential saturation factor alone -7.6 %; the
+    per-row least-squares factor measured against a truth run -18 % (diverges in closed loop); the shipped rule -- saturation
+    decides every element's quantized value, the whole sum is taken wherever it stays in that quantization cell -- -2.9 %, where a
+    PERFECT rule (every replica adopts the single replica's model at every exchange) ends -4.9 %: what is left is the interval
+    itself, not the rule.  Gate: within EIGHT_REPLICAS_RTOL of the single replica, and >= 15 points better than meeting at the end
+    of the epoch only (-24 %).  The literal 100 M-token stream at the 1 M-word interval: test_eight_replicas_literal_stream."""
     from w2b_testlib import write_headline_corpus
     path = write_headline_corpus(str(tmp_path / "c.txt"))
     corpus = w2b.Corpus(path, 5)
@@ -317,9 +334,32 @@ def test_eight_replicas_at_the_configs3_shape_recorded(gpu, tmp_path):
         d_none, d_every = (none - one) / abs(one), (every - one) / abs(one)
         print("EXCHANGE configs[3] shape, 8 replicas x 128 workers, %d launches: 1 replica %.0f | end of epoch only %+.2f %% | "
               "after every launch of 131 K words %+.2f %%" % (launches, one, 100 * d_none, 100 * d_every))
-        assert -0.35 <= d_none <= -0.15 and -0.15 <= d_every <= -0.03
-        assert d_every - d_none >= 0.10                            # the exchange is worth at least 10 points here
+        assert -0.35 <= d_none <= -0.15
+        assert abs(d_every) <= EIGHT_REPLICAS_RTOL, d_every
+        assert d_every - d_none >= 0.15
     finally:
         corpus.close()
         os.remove(path)
 
+
+def test_eight_replicas_literal_stream(gpu, tmp_path):
+    """The same 8 replicas on BASELINE configs[1] LITERALLY per job (100 M tokens; 12.5 M words per replica), a full exchange after
+    every launch of 1 M centre words per replica -- the interval at which one exchange of the whole 2.56 GB model per launch fits the
+    xGMI links (a launch of 1 M words is 38 ms on a full device; ring over one link 29 ms, reduce-scatter + all-gather over all
+    seven 4 ms).  Measured in round 6: -0.5 % of the single replica's epoch loss (round 5's rule: -12.6 %, worse than not
+    exchanging at all).  Gate: 3 %."""
+    from w2b_testlib import write_headline_corpus
+    path = write_headline_corpus(str(tmp_path / "c.txt"), n_zipf=98_000_000)
+    corpus = w2b.Corpus(path, 5)
+    flags = dict(bitlevel=1, size=800, window=8, negative=24)
+    try:
+        positions = 8192                                           # 1 M centre words per replica and launch
+        one, launches = run_replicas(corpus, 1, 1024, 1, positions, flags, sample=0.0)
+        every, _ = run_replicas(corpus, 8, 1024, 1, positions, flags, sample=0.0)
+        d_every = (every - one) / abs(one)
+        print("EXCHANGE configs[1] literally, 8 replicas x 128 workers, %d launches of 1 M words per replica: 1 replica %.0f | "
+              "8 replicas %+.2f %%" % (launches, one, 100 * d_every))
+        assert abs(d_every) <= 0.03, d_every
+    finally:
+        corpus.close()
+        os.remove(path)

@@ -147,8 +147,10 @@ hipError_t w2b_launch_wca_unpack(W2bShared *sh, const unsigned long long *buf, h
 hipError_t w2b_launch_xchg_delta(float *w, const float *base, float *d, float *s_, long long n, hipStream_t s);
 hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n,
                                  const float *fac /* per-row factors on the sum (k_xchg_factor) or nullptr */, long long first, int dim,
+                                 int bitlevel, int cells /* 1: per element the whole sum where it stays in the safe step's quantization cell */,
                                  hipStream_t s);
-// cnt[2 V]: contributors per row (in) -> factor on the summed delta (out); rule 0 continuous saturation, 1 hard threshold
+// cnt[2 V]: contributors per row (in) -> factor on the summed delta (out); rule 0 exponential saturation (rate = expected updates
+// per centre word), 1 hard threshold
 hipError_t w2b_launch_xchg_factor(float *cnt, const float *rate, float words, float tau_u, float tau_v, long long V, int rule,
                                   int sat_u, int sat_v, hipStream_t s);
 hipError_t w2b_launch_xchg_touched(const float *w, const float *base, float *cnt, long long rows, int dim, hipStream_t s);

@@ -91,29 +91,45 @@ __global__ void k_xchg_delta(float *w, const float *__restrict__ base, float *__
     s[i] = x;
   }
 }
-// s now holds the sum over all replicas.  What the OTHER replicas added, a * s - d (a = 1: delta-sum, a = 1 / replicas:
-// average of the deltas), goes on top of the rows as they are NOW -- whatever this replica has trained since the delta
-// was taken stays -- and base becomes the common state base + a * s.  Elements nobody else touched are not written.
-// fac (optional): per ROW of [u || v] a factor on the summed delta (k_xchg_factor below: 1 for a row that only one replica
-// changed, towards 1 / contributors for a row that every replica has saturated).  first = index of w[0] in [u || v].
+// s now holds the sum over all replicas.  What the OTHER replicas added, comb - d, goes on top of the rows as they are NOW --
+// whatever this replica has trained since the delta was taken stays -- and base becomes the common state base + comb.  Elements
+// nobody else touched are not written.  comb:
+//   fac == nullptr:  a * s                      (a = 1: delta-sum, a = 1 / replicas: average of the deltas)
+//   fac != nullptr:  per ROW of [u || v] a factor on the summed delta (k_xchg_factor below: 1 for a row that only one replica
+//                    changed, towards 1 / contributors for a row that every replica has saturated): safe = a * fac[row] * s;
+//   ... and CELL (round 6, mode 2's default): per ELEMENT, where the whole sum a * s lands in the same quantization cell as the
+//                    safe step -- the same sign at one bit; quantize(base + a s) == quantize(base + safe), ref :73-108 -- the
+//                    whole sum is taken.  The forward values (all any dot product ever sees, ref :439,:464) are then exactly the
+//                    safe rule's, while the fp32 master keeps the inertia that ONE shared model would have accumulated from the
+//                    same updates: with the safe step alone the masters of frequent rows grow c times too slowly and their signs
+//                    flip c times too easily (8 replicas: -7.6 % of the single replica's epoch loss; with the cells: -2.9 % at
+//                    131 K words per replica between exchanges, -0.5 % on the literal configs[1] stream at 1 M).
+// first = index of w[0] in [u || v].  base is identical on every replica and so is s: every replica computes the same comb.
+template <int QM, bool CELL>
 __global__ void k_xchg_apply(float *w, float *__restrict__ base, const float *__restrict__ d, const float *__restrict__ s,
-                             float a, long long n, const float *__restrict__ fac, long long first, int dim) {
+                             float a, long long n, const float *__restrict__ fac, long long first, int dim, QParam qp) {
   const long long stride = (long long)gridDim.x * blockDim.x, n4 = n >> 2;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (int)(n * 4), 0x27000);
   w2b_f4 *b4 = reinterpret_cast<w2b_f4 *>(base);
   const w2b_f4 *d4 = reinterpret_cast<const w2b_f4 *>(d), *s4 = reinterpret_cast<const w2b_f4 *>(s);
-  auto scale = [&](long long i) -> float { return fac ? a * fac[(first + i) / dim] : a; };   // i: float index inside this chunk
+  auto comb = [&](long long i, float sum, float b) -> float {      // i: float index inside this chunk
+    const float big = sum * a;
+    if (!fac) return big;
+    const float safe = sum * (a * fac[(first + i) / dim]);
+    if (!CELL) return safe;
+    return __float_as_uint(quant<QM>(b + safe, qp)) == __float_as_uint(quant<QM>(b + big, qp)) ? big : safe;
+  };
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    w2b_f4 sum = s4[i];
-    if (!fac) sum = sum * a;
-    else { sum.x *= scale(4 * i); sum.y *= scale(4 * i + 1); sum.z *= scale(4 * i + 2); sum.w *= scale(4 * i + 3); }
-    const w2b_f4 others = sum - d4[i];
-    b4[i] = b4[i] + sum;
+    const w2b_f4 sum = s4[i], b = b4[i];
+    w2b_f4 c;
+    c.x = comb(4 * i, sum.x, b.x); c.y = comb(4 * i + 1, sum.y, b.y); c.z = comb(4 * i + 2, sum.z, b.z); c.w = comb(4 * i + 3, sum.w, b.w);
+    const w2b_f4 others = c - d4[i];
+    b4[i] = b + c;
     if (others.x != 0.f || others.y != 0.f || others.z != 0.f || others.w != 0.f) xchg_st_sc1(rw, i, xchg_ld_sc1(rw, i) + others);
   }
   for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float sum = s[i] * scale(i), others = sum - d[i];
-    base[i] += sum;
+    const float c = comb(i, s[i], base[i]), others = c - d[i];
+    base[i] += c;
     if (others != 0.f) {
       const float x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, (int)(i * 4), 0, 16)) + others;
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rw, (int)(i * 4), 0, 16);
@@ -121,18 +137,18 @@ __global__ void k_xchg_apply(float *w, float *__restrict__ base, const float *__
   }
 }
 // The combination rule of mode 2, per ROW of [u || v]: cnt[g] (in) = number of replicas that changed row g since the last
-// exchange, (out) = the factor k on the SUM of their deltas.
-//   rule 0 (round 6, default) -- continuous saturation.  A row that has received n updates in a replica since the last
-//     exchange has contracted towards where those updates pull it by rho = 1 - exp(-n / tau) (alpha = 0.05: a few dozen
-//     updates move a row most of the way).  c replicas' updates applied one after the other -- what the reference's threads
-//     do to one shared row, ref :489-491,:500-502 -- would have contracted it by 1 - (1 - rho)^c; the sum of the c deltas is
-//     c * rho.  So
+// exchange, (out) = the factor k on the SUM of their deltas (w2b_trainer.cpp "the combination rule of mode 2" has what was measured).
+//   rules 0 and 2 (round 6; 0 = the default, with the per-element cells of k_xchg_apply on top; 2 = without) -- exponential
+//     saturation.  A row that has received n updates in a replica since the last exchange
+//     has contracted towards where those updates pull it by rho = 1 - exp(-n / tau); c replicas' updates applied one after the
+//     other -- what the reference's threads do to one shared row, ref :489-491,:500-502 -- would have contracted it by
+//     1 - (1 - rho)^c, and the sum of the c deltas is c * rho, so
 //         k = (1 - exp(-c n / tau)) / (c (1 - exp(-n / tau)))       -> 1 for n << tau (the sum), -> 1 / c for n >> tau (the mean)
 //     with n = rate[g] * words (expected updates of the row per trained centre word, from the word counts, times the centre
 //     words a replica has trained since the last exchange) and tau = tau_u for rows of u, tau_v for rows of v.
 //   rule 1 (rounds 4-5) -- hard threshold: k = 1 / c for rows 1..sat_u of u / 1..sat_v of v (n >= 32), 1 otherwise.  On a
 //     Zipf vocabulary the rows within a factor of a few of ANY threshold carry the same share of all updates whatever the
-//     interval -- the 8-replica run of round 5 ended 9 % off the single replica at 131 K and at 16 K words alike.
+//     interval, and on one side of it they move c times too far.
 __global__ void k_xchg_factor(float *__restrict__ cnt, const float *__restrict__ rate, float words, float tau_u, float tau_v,
                               long long V, int rule, int sat_u, int sat_v) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -286,9 +302,20 @@ hipError_t w2b_launch_xchg_delta(float *w, const float *base, float *d, float *s
   return hipGetLastError();
 }
 hipError_t w2b_launch_xchg_apply(float *w, float *base, const float *d, const float *s_, float a, long long n,
-                                 const float *fac, long long first, int dim, hipStream_t s) {
-  hipLaunchKernelGGL(k_xchg_apply, dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n, fac, first, dim);
-  return hipGetLastError();
+                                 const float *fac, long long first, int dim, int bitlevel, int cells, hipStream_t s) {
+  QParam qp;
+  qp.bitlevel = bitlevel;
+  qp.steps_i = (bitlevel >= 4) ? (1 << (bitlevel - 1)) : 1;
+  qp.steps_f = (float)qp.steps_i;
+  if (!fac || !cells || bitlevel == 0) {      // (no quantization: every value is a cell of its own -- the safe step)
+    hipLaunchKernelGGL((k_xchg_apply<0, false>), dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n, fac, first, dim, qp);
+    return hipGetLastError();
+  }
+  return dispatch_q(bitlevel, [&](auto qm) -> hipError_t {
+    constexpr int QM = decltype(qm)::value;
+    hipLaunchKernelGGL((k_xchg_apply<QM, true>), dim3(1024), dim3(256), 0, s, w, base, d, s_, a, n, fac, first, dim, qp);
+    return hipGetLastError();
+  });
 }
 hipError_t w2b_launch_xchg_factor(float *cnt, const float *rate, float words, float tau_u, float tau_v, long long V, int rule,
                                   int sat_u, int sat_v, hipStream_t s) {

@@ -102,6 +102,7 @@ struct w2b_trainer {
   hipEvent_t x_evd[2] = {nullptr, nullptr}, x_evs[2] = {nullptr, nullptr}, x_evc = nullptr;   // delta / sum of a slot complete; counts summed
   float *xcnt = nullptr;                    // [2 * vocab_size]: replicas that changed each row, then the row's factor on the summed delta (mode 2)
   float *xrate = nullptr;                   // [2 * vocab_size]: expected updates of every row of [u || v] per trained centre word (from the word counts)
+  std::vector<float> xrate_host;            // (host copy: empty = no word counts yet)
   bool x_fac_pending = false;               // xcnt holds contributor counts that k_xchg_factor has not yet turned into factors
   bool x_use_cnt = false;                   // the exchange in progress damps the saturated rows' sums by xcnt
   int x_sat_u = 0, x_sat_v = 0;             // rows 1..x_sat_* of u / v count as saturated in the exchange in progress
@@ -395,8 +396,8 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
   if (in->hot_weight_permille < 1 || in->hot_weight_permille > 1000)
     return fail(W2B_EINVAL, "w2b_set_tuning: hot_weight_permille must be 1..1000");
   if (in->refresh_rows_u < -1 || in->refresh_rows_u > W2B_RC_MAX) return fail(W2B_EINVAL, "w2b_set_tuning: refresh_rows_u must be -1 .. 64");
-  if (in->exchange_rule < 0 || in->exchange_rule > 1 || in->exchange_tau_u < 0 || in->exchange_tau_v < 0 || in->reserved_r6 != 0)
-    return fail(W2B_EINVAL, "w2b_set_tuning: exchange_rule must be 0 or 1, exchange_tau_* >= 0, reserved_r6 == 0");
+  if (in->exchange_rule < 0 || in->exchange_rule > 2 || in->exchange_tau_u < 0 || in->exchange_tau_v < 0 || in->reserved_r6 != 0)
+    return fail(W2B_EINVAL, "w2b_set_tuning: exchange_rule must be 0, 1 or 2, exchange_tau_* >= 0, reserved_r6 == 0");
   t->tune = *in;
   return W2B_OK;
 }
@@ -1068,6 +1069,13 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
   // The longer the stream the further stale copies pull the epoch loss down, so the period that centres BOTH is the default;
   // it costs ~2 % of the headline throughput against 32.
   if (t->tune.hot_period <= 0) p.hot_period = full_device(t, workers) ? W2B_HOT_PERIOD : 1;   // (mid range: every word)
+  // The sentence-resident kernel (an explicit choice; its context rows are private in LDS, only target rows have copies) keeps
+  // round 4's period of 32.  Round 5's line above gave it the mid-range value -- a resident launch has 2 workgroups per CU, never
+  // "a full device" by the 3-per-CU rule -- i.e. a merge after EVERY word: that, not the move from 32 to 16, is what took the
+  // cfg5 shape's sentence-resident leg from 0.889 to 0.776 of the roofline between the round-4 and round-5 driver runs (same-box
+  // A/B in round 6: 36.9-37.2 M words/s as shipped in round 5, 41.4 M with 32, 38.4 M for the round-4 library;
+  // profiles/r06_sessions/r06b_cfg5_ab.txt, r06c_cfg5_resident_period.txt).
+  if (t->tune.hot_period <= 0 && !with_u) p.hot_period = 2 * W2B_HOT_PERIOD;
   if (fresh) {         // copy == entry (== 0) everywhere: the fold below adopts the master rows
     HIPCHK(hipMemsetAsync(t->xhot, 0, sizeof(float) * need, t->stream));
     t->xhot_nu = nu;
@@ -1414,6 +1422,7 @@ static int xchg_upload_rates(w2b_trainer *t) {
     r[(size_t)(V + a)] = (float)(t->cfg.negative * pow(c, 0.75) / t->counts_pw + k);
   }
   HIPCHK(hipMemcpy(t->xrate, r.data(), sizeof(float) * 2 * V, hipMemcpyHostToDevice));
+  t->xrate_host.swap(r);
   return W2B_OK;
 }
 
@@ -1581,14 +1590,28 @@ static int xchg_delta(w2b_trainer *t, long long c) {
   HIPCHK(w2b_launch_xchg_delta(t->uv + r.off, t->base + r.off, t->xd[k], t->xsum[k], r.len, t->xs[0]));
   return W2B_OK;
 }
+// ---- the combination rule of mode 2: a per-row factor on the SUM of the replicas' deltas (k_xchg_factor has the formulas).
+// Round 6 measured three families on 8 replicas x 128 workers against the single replica with the same 1024 workers
+// (tests/experiments/replica_rules.py, replica_truth.py; profiles/r06_sessions/):
+//   * the hard threshold of rounds 4-5 (mean of the contributors from 32 expected updates on, sum below): -9.0 % of the single
+//     replica's epoch loss at 131 K words per replica between two exchanges, -9.9 % at 16 K;
+//   * exponential saturation (rule 2): -7.4 % (tau = 64; 8: -14 %, 32: -8.1 %, 128: -7.7 %, 256: -9.1 %);
+//   * the per-row least-squares factor of a truth run's delta on the replicas' summed delta (0.75 at one update, falling only
+//     logarithmically: 0.45 at 256 updates) -- optimal for ONE interval from a common model, and divergent in closed loop: -18 %,
+//     the final model worthless.  It is dominated by the drift of the fp32 masters (which no forward value sees) and over-relaxes the
+//     elements near a sign flip (which every forward value sees).  Not shipped; the measurement stays in the experiment scripts.
+//   * rule 0, the default: exponential saturation decides every element's QUANTIZED value, and where the whole sum lands in the
+//     same quantization cell it is taken instead (k_xchg_apply) -- the forward values of the stable rule, the masters' inertia of a
+//     shared model: -2.9 % at 131 K words per replica on the 22 M-token proxy (-0.3 % with doubling intervals), -0.5 % on the
+//     literal configs[1] stream at 1 M words.
 // contributor counts in xcnt -> factors on the summed delta (k_xchg_factor), once per exchange, on stream q
-static const double W2B_XCHG_TAU_U = 32.0, W2B_XCHG_TAU_V = 32.0;   // updates that move a row most of the way (see k_xchg_factor)
+static const double W2B_XCHG_TAU_U = 64.0, W2B_XCHG_TAU_V = 64.0;   // updates that move a row most of the way
 static int xchg_factor(w2b_trainer *t, hipStream_t q) {
   if (!t->x_fac_pending) return W2B_OK;
   const int rule = t->tune.exchange_rule;
   const float tau_u = t->tune.exchange_tau_u > 0 ? (float)t->tune.exchange_tau_u : (float)W2B_XCHG_TAU_U;
   const float tau_v = t->tune.exchange_tau_v > 0 ? (float)t->tune.exchange_tau_v : (float)W2B_XCHG_TAU_V;
-  HIPCHK(w2b_launch_xchg_factor(t->xcnt, t->counts.empty() ? nullptr : t->xrate, (float)t->x_words_sync, tau_u, tau_v, t->cfg.vocab_size,
+  HIPCHK(w2b_launch_xchg_factor(t->xcnt, t->xrate_host.empty() ? nullptr : t->xrate, (float)t->x_words_sync, tau_u, tau_v, t->cfg.vocab_size,
                                 rule, t->x_sat_u, t->x_sat_v, q));
   t->x_fac_pending = false;
   return W2B_OK;
@@ -1598,7 +1621,7 @@ static int xchg_apply(w2b_trainer *t, long long c, float scale) {
   const int k = (int)(c & 1);
   if (t->x_use_cnt) if (int rc = xchg_factor(t, t->xs[0])) return rc;
   HIPCHK(w2b_launch_xchg_apply(t->uv + r.off, t->base + r.off, t->xd[k], t->xsum[k], scale, r.len, t->x_use_cnt ? t->xcnt : nullptr,
-                               r.off, t->cfg.layer1_size, t->xs[0]));
+                               r.off, t->cfg.layer1_size, t->cfg.bitlevel, t->tune.exchange_rule == 0 ? 1 : 0, t->xs[0]));
   return W2B_OK;
 }
 // per row of [u || v]: has this replica changed it since the last exchange?
