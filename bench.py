@@ -16,7 +16,7 @@ CBOW/negative-sampling update kernel over one batch of centre words:
 All inputs are resident in HBM before the timed region.  N>1: one process per GPU
 (torch.distributed.run), each rank trains its own shard (weak scaling) on its own replica and
 the replicas are combined every --sync-every steps by an RCCL all-reduce of [u||v] (--sync-mode,
-default 2: contributor average), inside the timed region.  `--gpus N` launched without a rendezvous
+default 2: saturation + quantization cells), inside the timed region.  `--gpus N` launched without a rendezvous
 starts the N ranks itself (torch.distributed.run); with a rendezvous of another size it exits 2.
 
 The headline runs WITH the loss bookkeeping (--loss 1): the instantiation ./word2bits runs (it prints "Epoch Loss").
@@ -76,7 +76,7 @@ def parse():
                     help="N>1: steps between two full replica exchanges (1 = after every step, what ./word2bits -gpus N does: the "
                          "interval is what costs epoch loss, tests/test_gpu_exchange.py; 16 until round 4)")
     ap.add_argument("--sync-mode", type=int, default=2,
-                    help="0 delta-sum, 1 average, 2 contributor average (what ./word2bits -gpus N uses)")
+                    help="0 delta-sum, 1 average, 2 saturation per row + quantization cells per element (what ./word2bits -gpus N uses)")
     ap.add_argument("--sync-impl", choices=["lib", "torch"], default="lib",
                     help="replica exchange: lib = the library's own RCCL communicator (w2b_comm_init / "
                          "w2b_sync_replicas: what the CLI uses; falls back to torch if its initialisation fails on any "
@@ -796,7 +796,7 @@ def main():
                    "bitlevel": args.bitlevel, "words_per_step_per_gpu": words_per_step, "ids": args.ids,
                    "row_coherence": "relaxed (plain cached accesses)" if args.relaxed else
                                     "agent scope (sc1): Hogwild coherent across the 8 XCD L2s",
-                   "replica_sync": ("%s every %d steps, mode %d (0 delta-sum, 1 average, 2 contributor average)" %
+                   "replica_sync": ("%s every %d steps, mode %d (0 delta-sum, 1 average, 2 saturation + quantization cells)" %
                                     (sync_impl, args.sync_every, args.sync_mode)) if world > 1 else sync_impl,
                    "exchanges_in_timed_region": n_syncs[0],
                    "worker_kernel": (dict(zip(("sentence_resident", "radius", "column_bytes", "workers_per_cu",
@@ -839,14 +839,24 @@ def main():
         except Exception:
             pass
     if world > 1:
+        words_between = words_per_step * args.sync_every
+        xbytes = 8 * V * D
         result["replica_exchange"] = {
-            "every_steps": args.sync_every, "mode": ["delta-sum", "average", "contributor average"][args.sync_mode],
+            "every_steps": args.sync_every, "centre_words_per_replica_between_exchanges": words_between,
+            "mode": ["delta-sum", "average", "mode 2: exponential saturation per row decides every element's quantized value, the whole "
+                     "sum where it stays in that quantization cell (round 6, DESIGN.md 3.5)"][args.sync_mode],
             "implementation": sync_impl, "exchanges": n_syncs[0],
-            # one full exchange moves the model through k_xchg_delta (4 model-sized passes) and k_xchg_apply (6): measured on one
-            # GPU through the phase API at this shape (8 replicas, tests/experiments/replicas8_cfg3.py, profiles/r05_sessions/
-            # r05m_replicas8.json): 2.2-7.2 ms + 2.9-3.3 ms per exchange beside a training launch of 202 ms per replica
+            "bytes": xbytes, "bytes_all_reduced_per_exchange": xbytes,
+            # cost model of one full exchange over xGMI beside the launches of one interval: a ring all-reduce is bound
+            # by one ~153 GB/s link (2 (R-1)/R S bytes), a direct reduce-scatter + all-gather uses all R-1 links (2 S / R per link)
+            "link_model_ms": {"ring_one_link": 2 * (world - 1) / world * xbytes / 153e9 * 1e3,
+                              "direct_all_links": 2 * xbytes / world / 153e9 * 1e3,
+                              "interval_ms": dt / args.steps * 1e3 * args.sync_every},
+            # measured on one GPU through the phase API at this shape (8 replicas x 128 workers, tests/experiments/replica_rules.py,
+            # tests/test_gpu_exchange.py; profiles/r06_sessions/): epoch loss against the single replica with the same 1024 workers
+            "fidelity_measured_on_one_gpu": "8 replicas x 128 workers vs 1 replica x 1024: -0.5 % on the literal configs[1] stream at 1 M words "
+                                            "per replica between exchanges, -2.9 % on the 22 M-token proxy at 131 K (round 5's rule: -12.6 % / -9.0 %)",
             "elementwise_cost_measured_on_one_gpu": "k_xchg_delta 2.2-7.2 ms + k_xchg_apply 2.9-3.3 ms per full exchange of 2.56 GB = 3-5 % of a 1 M-word launch at 128 workers (profiles/r05_sessions/r05m_replicas8.json)",
-            "bytes": 8 * V * D, "bytes_all_reduced_per_exchange": 8 * V * D,
             "device_ms": (sync_ms / sync_n) if sync_n else None,
             "device_ms_per_exchange": (sync_ms / sync_n) if sync_n else None,
             # the library's own communicator runs the exchange on its own streams next to the training launches; with a

@@ -41,7 +41,7 @@
 // (s_waitcnt vmcnt(0)) before the barrier that ends a word; 2: the adder wavefront waits for its atomic adds as well.  Measured
 // in round 6 (profiles/r06_sessions/): see DESIGN.md section 3.3c for what each level costs and which one ships.
 #ifndef W2B_GROUPS_DRAIN
-#define W2B_GROUPS_DRAIN 0
+#define W2B_GROUPS_DRAIN 1
 #endif
 #define W2G_LDS __attribute__((address_space(3)))
 #define W2G_CMAX 32      // context rows of a centre word (window <= 16)

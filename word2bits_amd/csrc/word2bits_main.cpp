@@ -324,14 +324,16 @@ int main(int argc, char **argv) {
   if (o.gpus > 1 && (o.sync_words > 0 || arg_pos("-sync-every", argc, argv) <= 0)) {
     // The interval between two exchanges, in centre words per replica.  What it costs is measured: while
     // a replica trains alone it misses what the others learn -- with a PERFECT combination rule 8 replicas end 1.5 / 4.9 / 16.8 %
-    // off the single replica on the 22 M-token file at 16 K / 131 K / 1 M words per replica (3 exchanges in the epoch), and the
-    // loss falls with the corpus (literal configs[1] stream, 1 M words: -0.5 % with the shipped rule).  Automatic: about 21
-    // exchanges per epoch, between 131 072 words and the 1 048 576 that one full exchange of a 2.56 GB model per launch over
-    // xGMI allows; -sync-words N sets it, -sync-every / -positions keep their old meaning when given.
+    // off the single replica on the 22 M-token file at 16 K / 131 K / 1 M words per replica -- while the shipped rule errs the other
+    // way at short intervals (+5 % at 131 K words on the literal 100 M-token stream).  The two meet near 1 / 24 of a replica's epoch:
+    // 22 M tokens: +0.8 / -2.7 / -8 % at 65 K / 131 K / 262 K words; 100 M tokens: +5.0 / +2.0 / +0.2 / -2.1 % at 131 K / 262 K /
+    // 524 K / 1 M.  Automatic: 1 / 24 of the replica's words per epoch, between 65 536 words and the 1 048 576 at which one full
+    // exchange of a 2.56 GB model per launch fits the xGMI links; -sync-words N sets it, -sync-every / -positions keep their
+    // old meaning when given.
     long long words = o.sync_words;
     if (words <= 0) {
-      words = train_words / o.gpus / 21;
-      if (words < 131072) words = 131072;
+      words = train_words / o.gpus / 24;
+      if (words < 65536) words = 65536;
       if (words > 1048576) words = 1048576;
     }
     long long pos = words / (per_gpu > 0 ? per_gpu : 1);
