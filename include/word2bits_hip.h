@@ -149,7 +149,7 @@ typedef struct w2b_tuning {
   int32_t fresh_rank_u;    /* plain worker / tuple kernels: context rows 1..N are read again right before their update (phase C)
                             * instead of taken from the LDS stash of phase A, so that the update lands on the row's CURRENT value
                             * as the reference's `u[c] += e[c]` does (ref :500-502); 0 = the library decides, -1 = none */
-  int32_t exchange_sat_updates;  /* replica exchange, mode 2 / hot tier: a row counts as SATURATED (moves by the mean of its
+  int32_t exchange_sat_updates;  /* replica exchange, mode 2 with exchange_rule 1 (rounds 4-5): a row counts as SATURATED (moves by the mean of its
                                   * contributors' deltas instead of their sum) when every replica has updated it at least this
                                   * often since the last exchange; 0 = the library's default */
   /* round 5 (the last reserved field; struct_size unchanged): row-group worker kernel -- context rows 1..N are READ at a copy
@@ -295,13 +295,13 @@ int w2b_comm_init(w2b_trainer *t, int32_t nranks, int32_t rank, const void *id12
 /* ranks of the RCCL communicator this trainer exchanges over, asked of RCCL itself (ncclCommCount): 0 = no communicator.
  * What bench.py prints as `rccl_ranks`, so that a line claiming N GPUs can be checked against the collective that ran. */
 int w2b_comm_count(w2b_trainer *t, int32_t *nranks_out);
-/* mode 0: delta-sum (a = 1);  mode 1: average of the deltas (a = 1/R);  mode 2 (what ./word2bits -gpus N uses): delta-sum,
- * except that SATURATED rows -- rows that have been updated more than a few dozen times in every replica since the last
- * exchange, so that each replica's delta is already most of the way -- move by the MEAN of the deltas of the c replicas
- * that changed them (the sum of c such deltas over-shoots c-fold: mode 0 diverges with 4 replicas on the text8-sized
- * corpus), while every other row, in particular a row that only one replica saw, keeps the full sum (mode 1 divides that
- * by R as well).  The more often the replicas exchange, the fewer rows are saturated.  Measured in
- * tests/test_gpu_exchange.py.  Asynchronous (see above). */
+/* mode 0: delta-sum (a = 1);  mode 1: average of the deltas (a = 1/R);  mode 2 (what ./word2bits -gpus N uses; round 6): a
+ * per-row factor on the summed delta from the row's expected number of updates per replica since the last exchange -- the sum
+ * for rarely updated rows, towards the mean of the c replicas that changed it for rows every replica has saturated -- decides
+ * every element's QUANTIZED value, and the whole sum is taken wherever it lands in the same quantization cell (w2b_tuning.
+ * exchange_rule; a row that only one replica saw keeps that replica's whole update, which mode 1 divides by R; mode 0 diverges
+ * from 4 replicas on).  Measured in tests/test_gpu_exchange.py: 2 / 4 / 8 replicas on one GPU through the phase API below.
+ * Asynchronous (see above). */
 int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
 /* (Round 4 also had a HOT TIER -- w2b_sync_hot_rows / w2b_exchange_begin_hot / w2b_exchange_hot_rows: the leading rows of both
  * tables exchanged after every launch.  It measured no gain over the full exchanges alone -- the rows that are rare individually
@@ -314,7 +314,8 @@ int w2b_sync_stats(w2b_trainer *t, int64_t *exchanges, double *device_ms);
  *   w2b_exchange_init once, while all replicas hold the same model; then per exchange
  *   w2b_exchange_begin(&n_chunks, &my_words)
  *   (mode 2 only) w2b_exchange_counts(&cnt, &m): cnt[0..m) = 1 for every row of [u||v] this replica changed;
- *                            the host sums cnt over the replicas in place; w2b_exchange_apply then damps the saturated rows with it
+ *                            the host sums cnt over the replicas in place; the first w2b_exchange_apply turns the sums into the
+ *                            per-row factors of w2b_tuning.exchange_rule and applies them (scale = 1)
  *   for c in [0, n_chunks): w2b_exchange_delta(c, &buf, &n)   -- buf[0..n) = this replica's delta (device memory, complete
  *                            on return);  the host sums buf over all replicas IN PLACE with its collective;
  *                           w2b_exchange_apply(c, a)          -- expects the sum to be complete
