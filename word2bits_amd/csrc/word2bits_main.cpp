@@ -325,15 +325,17 @@ int main(int argc, char **argv) {
     // The interval between two exchanges, in centre words per replica.  What it costs is measured: while
     // a replica trains alone it misses what the others learn -- with a PERFECT combination rule 8 replicas end 1.5 / 4.9 / 16.8 %
     // off the single replica on the 22 M-token file at 16 K / 131 K / 1 M words per replica -- while the shipped rule errs the other
-    // way at short intervals (+5 % at 131 K words on the literal 100 M-token stream).  The two meet near 1 / 24 of a replica's epoch:
-    // 22 M tokens: +0.8 / -2.7 / -8 % at 65 K / 131 K / 262 K words; 100 M tokens: +5.0 / +2.0 / +0.2 / -2.1 % at 131 K / 262 K /
-    // 524 K / 1 M.  Automatic: 1 / 24 of the replica's words per epoch, between 65 536 words and the 1 048 576 at which one full
-    // exchange of a 2.56 GB model per launch fits the xGMI links; -sync-words N sets it, -sync-every / -positions keep their
-    // old meaning when given.
+    // way at short intervals (+5 % at 131 K words on the literal 100 M-token stream).  Where the two meet, 8 replicas against one,
+    // as a fraction of a replica's words per epoch: 1/34 (22 M tokens at the configs[1] shape: +0.8 / -2.7 / -8 % at 65 K / 131 K /
+    // 262 K words), 1/23 (100 M tokens: +5.0 / +2.0 / +0.2 / -2.1 % at 131 K / 262 K / 524 K / 1 M), 1/26 (heldout_v1m, 85 M words:
+    // +2.5 / -0.3 / -7.2 % at 221 K / 442 K / 1 M) and below 1/66 (text8-sized corpus, 32 workers per replica: -1.8 / -4.2 / -8.4 %
+    // at 32 K / 65 K / 131 K).  Automatic: 1 / 32 of the replica's words per epoch, between 32 768 words and the 1 048 576 at which
+    // one full exchange of a 2.56 GB model per launch fits the xGMI links; -sync-words N sets it, -sync-every / -positions keep
+    // their old meaning when given.
     long long words = o.sync_words;
     if (words <= 0) {
-      words = train_words / o.gpus / 24;
-      if (words < 65536) words = 65536;
+      words = train_words / o.gpus / 32;
+      if (words < 32768) words = 32768;
       if (words > 1048576) words = 1048576;
     }
     long long pos = words / (per_gpu > 0 ? per_gpu : 1);
