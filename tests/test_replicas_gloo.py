@@ -56,7 +56,30 @@ def _worker(rank, world, port, q):
         expect2 = base + sum((torch.zeros(4096).index_fill_(0, torch.arange(r * 100, (r + 1) * 100 + 50), float(r + 1))
                               for r in range(world))) / world
         ok_avg = torch.allclose(m2, expect2, atol=1e-6)
-        q.put((rank, gathered, ok_delta, ok_avg))
+        # mode 2 (round 6): saturation factor per row + quantization cells per element, against a single-process restatement
+        V, D = 64, 8
+        gg = torch.Generator().manual_seed(1)
+        b3 = (torch.rand(2 * V * D, generator=gg) - 0.5)
+        rate = torch.cat([torch.linspace(0.5, 1e-4, V), torch.linspace(0.2, 1e-4, V)])
+        ds = []
+        for r in range(world):
+            gr = torch.Generator().manual_seed(10 + r)
+            dr = (torch.rand(2 * V * D, generator=gr) - 0.5) * 2.0
+            rows = torch.rand(2 * V, generator=gr) < (0.7 if r == 0 else 0.5)        # every replica touches its own subset of rows
+            ds.append(dr * rows.to(dr.dtype).repeat_interleave(D))
+        m3 = b3 + ds[rank]
+        base3 = b3.clone()
+        replicas.TorchReplicaSync(dist, mode=2, rate=rate, dim=D, bitlevel=1).sync(m3, base3, words=400)
+        S = sum(ds)
+        cnt = sum(((x.view(-1, D) != 0).any(1)).float() for x in ds)
+        k = replicas.saturation_factors(rate, 400, cnt)
+        safe = S * k.repeat_interleave(D)
+        want = b3 + torch.where(((b3 + safe) < 0) == ((b3 + S) < 0), S, safe)
+        both = cnt == 2
+        ok_cells = (torch.allclose(m3, want, atol=1e-6) and torch.equal(m3, base3) and bool(both.any()) and bool((~both).any())
+                    and float(k[both].min()) < 0.6 and bool((k[~both] == 1).all())
+                    and 0.01 < float((((b3 + safe) < 0) != ((b3 + S) < 0)).float().mean()) < 0.5)
+        q.put((rank, gathered, ok_delta, ok_avg and ok_cells))
     finally:
         dist.destroy_process_group()
 

@@ -61,18 +61,54 @@ def exchange_unique_id(dist, rank, make_id):
     return box[0]
 
 
+def saturation_factors(rate, words, contributors, tau_u=64.0, tau_v=64.0, vocab_size=None):
+    """The per-row factor on the summed delta of mode 2 (w2b_kernels_misc.hip k_xchg_factor, rules 0 and 2) on torch tensors:
+    k = (1 - exp(-c n / tau)) / (c (1 - exp(-n / tau))) with n = rate * words expected updates of the row per replica since the
+    last exchange and c replicas that changed it; 1 for c <= 1.  rate: [2 V] (rows of u, then rows of v)."""
+    import torch
+    V = vocab_size if vocab_size is not None else rate.numel() // 2
+    tau = torch.cat([torch.full((V,), float(tau_u)), torch.full((rate.numel() - V,), float(tau_v))]).to(rate)
+    x = (rate.double() * float(words) / tau.double()).clamp_min(1e-12)
+    c = contributors.double().clamp_min(1.0)
+    k = torch.expm1(-c * x) / (c * torch.expm1(-x))
+    k = torch.minimum(torch.ones_like(k), torch.maximum(k, 1.0 / c))
+    return torch.where((contributors > 1) & (x > 1e-6), k, torch.ones_like(k)).to(rate.dtype)
+
+
+def quantization_cell(x, bitlevel):
+    """an integer label of the quantization cell of every element (quantize(), ref src/word2bits.cpp:73-108): two values with the
+    same label have the same forward value"""
+    import torch
+    neg = (x < 0).to(torch.int64)
+    if bitlevel == 1 or bitlevel == 3:
+        return neg
+    mag = x.abs()
+    if bitlevel == 2:
+        return neg * 2 + (~(mag <= 0.5)).to(torch.int64)
+    steps = 1 << (bitlevel - 1)
+    k = torch.clamp((mag * steps + 0.5).to(torch.int64), max=steps)
+    return torch.where(k == 0, torch.zeros_like(k), neg * (steps + 1) + k)   # (+0 and -0 are one forward value)
+
+
 class TorchReplicaSync:
-    """Delta-sum (mode 0) / average (mode 1) replica exchange on torch tensors.
+    """The replica exchange on torch tensors (CPU tensors over gloo: how the N > 1 arithmetic is tested without a GPU).
 
-    `model` is the flat [u || v] tensor of this rank, `base` the snapshot taken at the previous
-    exchange.  With world size 1 both modes leave `model` bit-identical (no arithmetic is done)."""
+    `model` is the flat [u || v] tensor of this rank, `base` the snapshot taken at the previous exchange.
+      mode 0: delta-sum;  mode 1: average;
+      mode 2: the library's default rule -- per row the saturation factor on the summed delta decides every
+              element's quantized value, and the whole sum is taken wherever it lands in the same quantization cell.  Needs
+              `rate` ([2 V] expected updates per centre word), `dim`, `bitlevel`, and per call `words` (centre words per replica
+              since the last exchange).
+    With world size 1 every mode leaves `model` bit-identical (no arithmetic is done)."""
 
-    def __init__(self, dist, mode=0):
+    def __init__(self, dist, mode=0, rate=None, dim=None, bitlevel=1, tau_u=64.0, tau_v=64.0, cells=True):
         self.dist = dist
         self.mode = mode
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rate, self.dim, self.bitlevel, self.tau, self.cells = rate, dim, bitlevel, (tau_u, tau_v), cells
 
-    def sync(self, model, base):
+    def sync(self, model, base, words=0):
+        import torch
         if self.world == 1:
             return model
         if self.mode == 0:
@@ -84,6 +120,20 @@ class TorchReplicaSync:
             self.dist.all_reduce(model)
             model.mul_(1.0 / self.world)
             base.copy_(model)
+        elif self.mode == 2:
+            d = model - base
+            touched = (d.view(-1, self.dim) != 0).any(1).to(d.dtype)      # rows this replica changed (k_xchg_touched)
+            self.dist.all_reduce(touched)
+            self.dist.all_reduce(d)                                        # S
+            k = saturation_factors(self.rate, words, touched, *self.tau)
+            safe = d * k.repeat_interleave(self.dim)
+            if self.cells and self.bitlevel != 0:
+                same = quantization_cell(base + safe, self.bitlevel) == quantization_cell(base + d, self.bitlevel)
+                comb = torch.where(same, d, safe)
+            else:
+                comb = safe
+            base.add_(comb)
+            model.copy_(base)                      # (synchronous: nothing was trained since the delta)
         else:
             raise ValueError("unknown sync mode")
         return model
