@@ -23,7 +23,7 @@ The headline runs WITH the loss bookkeeping (--loss 1): the instantiation ./word
 
 Prints ONE JSON line on rank 0 (contract in the task description) with extra objects:
   roofline     -- algorithmic HBM bytes per launch / hipEvent-measured launch duration vs 8 TB/s, min / median / max per
-                  launch, and the HBM bytes of the calibrated rocprofv3 counters (quoted from profiles/r05_pmc_worker.json:
+                  launch, and the HBM bytes of the calibrated rocprofv3 counters (quoted from profiles/r06_pmc_worker.json:
                   traffic_measured_in_this_run = false)
   cpu_baseline -- the reference CPU program (oracle/_ref/word2bits_stock, built from the unmodified reference sources)
                   on all host threads, training phase of a whole epoch over a bounded corpus of the same shape;
@@ -127,7 +127,7 @@ def parse():
 
 def latest_profile(name):
     """profiles/rNN_<name> of the newest round that has it (committed measurements that this script quotes, never re-labels)"""
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         f = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))
         if os.path.exists(f):
             return f

@@ -31,9 +31,9 @@ def small_counts(seed=3, V=3000, n=60000):
     return ids, np.maximum(np.bincount(ids, minlength=V), 1).astype(np.int64)
 
 
-def small_setup(nw, total, offset, seed=3, V=3000, D=64, n=60000, **kw):
+def small_setup(nw, total, offset, seed=3, V=3000, D=64, n=60000, bitlevel=1, **kw):
     ids, counts = small_counts(seed, V, n)
-    t = w2b.Trainer(V, D, 5, 5, 1, num_threads=nw, iter=1, sample=0.0, train_words=int(counts.sum()),
+    t = w2b.Trainer(V, D, 5, 5, bitlevel, num_threads=nw, iter=1, sample=0.0, train_words=int(counts.sum()),
                     compute_loss=True, worker_offset=offset, total_threads=total, **kw)
     t.init_net()
     t.set_vocab_counts(counts, 100000)
@@ -143,17 +143,28 @@ def smooth_factors(counts, words, window, negative, c, tau_u=64.0, tau_v=64.0):
     return np.clip(k, 1.0 / np.maximum(c, 1), 1.0)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, "2 saturation only", "2 hard threshold"])
+def host_cell(x, bitlevel):
+    """the quantization cell of every element (quantize(), ref :73-108), as labels: equal labels <=> equal forward values"""
+    neg = (x < 0).astype(np.int64)
+    if bitlevel == 1:
+        return neg
+    assert bitlevel == 2
+    return neg * 2 + (~(np.abs(x) <= np.float32(0.5))).astype(np.int64)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, "2 two bits", "2 saturation only", "2 hard threshold"])
 def test_phase_api_arithmetic_two_replicas(gpu, mode):
     """W_r += comb - d_r on top of the CURRENT rows, base += comb, against host arithmetic on copies of both replicas.
     comb = a * sum with a = 1 (mode 0) / 1/R (mode 1); mode 2: a per-row factor k on the sum -- exponential saturation
     (exchange_rule 2), or rounds 4-5's 1 / contributors for the saturated rows (exchange_rule 1) -- and, by default (exchange_rule
-    0), per element the whole sum wherever base + sum has the sign of base + k * sum (one bit: the quantization cell)."""
+    0), per element the whole sum wherever base + sum lies in the quantization cell of base + k * sum (one bit: the same sign; two
+    bits: the same sign and the same side of |x| = 0.5)."""
     R, nw = 2, 4
     rule = {"2 saturation only": 2, "2 hard threshold": 1}.get(mode, 0)
+    bitlevel = 2 if mode == "2 two bits" else 1
     if isinstance(mode, str):
         mode = 2
-    ts = [small_setup(nw, R * nw, r * nw, seed=3, **(dict(exchange_rule=rule) if rule else {})) for r in range(R)]
+    ts = [small_setup(nw, R * nw, r * nw, seed=3, bitlevel=bitlevel, **(dict(exchange_rule=rule) if rule else {})) for r in range(R)]
     for t in ts:
         t.exchange_init()
         t.epoch_begin()
@@ -189,7 +200,7 @@ def test_phase_api_arithmetic_two_replicas(gpu, mode):
                 assert (k[~both] == 1).all()
             safe = k.astype(np.float32)[:, None].repeat(D, 1).ravel() * S
             if rule == 0:
-                same = ((base + safe) < 0) == ((base + S) < 0)
+                same = host_cell(base + safe, bitlevel) == host_cell(base + S, bitlevel)
                 assert 0.5 < same.mean() < 1.0 and (~same).sum() > 100              # both branches are exercised
                 total, alt = np.where(same, S, safe), np.where(same, safe, S)
             else:
