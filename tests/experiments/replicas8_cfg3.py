@@ -1,9 +1,11 @@
 """Measurement, not a test: BASELINE configs[3] on ONE GPU through the phase API -- 8 replicas at the configs[1] shape
-(V = 400 K, size 800, negative 24, bitlevel 1), 128 workers each, a full exchange after every launch of ~1 M centre words per
-replica (what the xGMI links carry), against the single replica with the same 1024 workers and against
-8 replicas that meet at the end of the epoch only.  Also timed: the elementwise kernels of one full exchange (k_xchg_delta,
-k_xchg_apply; the collective itself is a device-side sum here) beside one training launch.
-  python tests/experiments/replicas8_cfg3.py CORPUS.txt [--replicas 8] [--positions 8192] [--out file.json]"""
+(V = 400 K, size 800, negative 24, bitlevel 1), 128 workers each, a full exchange after every launch (--positions 0: the interval
+./word2bits -gpus 8 picks, 1 / 32 of a replica's epoch between 32 K and 1 M centre words; 8192: 1 M words, what the xGMI links carry
+beside a full-device launch), against the single replica with the same 1024 workers and the same launches
+and against 8 replicas that meet at the end of the epoch only.  Also timed: the elementwise kernels of one full exchange
+(k_xchg_delta, k_xchg_apply; the collective itself is a device-side sum here) beside one training launch, and printed: the bytes one
+exchange puts on the links with the two link models (ring over one ~153 GB/s link; reduce-scatter + all-gather over all seven).
+  python tests/experiments/replicas8_cfg3.py CORPUS.txt [--replicas 8] [--positions 0] [--out file.json]"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,7 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("corpus")
 ap.add_argument("--replicas", type=int, default=8)
 ap.add_argument("--workers", type=int, default=1024)
-ap.add_argument("--positions", type=int, default=8192)
+ap.add_argument("--positions", type=int, default=0)
 ap.add_argument("--modes", default="2")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
@@ -27,6 +29,9 @@ corpus = w2b.Corpus(a.corpus, 5)
 print("R8 corpus: %d words, vocabulary %d  [%.1f s]" % (corpus.train_words, corpus.vocab_size, time.time() - t0), flush=True)
 tokens = corpus.tokens()
 counts = corpus.counts()
+if a.positions <= 0:                                      # the command line's rule (word2bits_main.cpp): 1 / 32 of a replica's epoch
+    words = min(1048576, max(32768, corpus.train_words // a.replicas // 32))
+    a.positions = max(16, words // (a.workers // a.replicas))
 res = {"corpus_words": int(corpus.train_words), "workers_total": a.workers, "positions": a.positions, "runs": []}
 
 
@@ -134,11 +139,23 @@ for name, se in (("end of the epoch only", 0), ("full exchange after every launc
         # bytes: delta reads w + base and writes d + s = 4 model-sized passes; apply reads w, base, d, s (+ counts) and writes w, base = 6
         rec["xchg_delta_GB"] = 4 * model_gb
         rec["xchg_apply_GB"] = 6 * model_gb
+        # what one exchange puts on the links: a ring all-reduce moves 2 (R - 1) / R of the model over ONE ~153 GB/s xGMI link, a direct
+        # reduce-scatter + all-gather 2 / R of it over each of the R - 1 links at once; beside the launch(es) of one interval -- of a
+        # 128-worker replica here, and of a full device (1024 workers: 27 M words/s) in a real 8-GPU job
+        R = a.replicas
+        rec["link_bytes_per_exchange"] = model_gb * 1e9
+        rec["link_ms_ring_one_link"] = 2 * (R - 1) / R * model_gb / 153 * 1e3
+        rec["link_ms_direct_all_links"] = 2 * model_gb / R / 153 * 1e3
+        rec["interval_ms_this_replica"] = rec["launch_ms"]
+        rec["interval_ms_full_device"] = words_between / 27e6 * 1e3
         res["runs"].append(rec)
         print("R8 %d replicas x %d workers, %-34s mode %d: loss %.0f (%+.2f %% vs 1 replica), %d launches of %.1f ms (%d words/replica), "
-              "exchange kernels %.1f + %.1f ms per exchange = %.0f %% of a launch  [%.0f s]" % (
+              "exchange kernels %.1f + %.1f ms per exchange = %.0f %% of a launch; %.2f GB per exchange on the links: ring over one link %.1f ms, "
+              "direct over all links %.1f ms, beside an interval of %.1f ms (this 128-worker replica) / %.1f ms (a full device)  [%.0f s]" % (
                   a.replicas, a.workers // a.replicas, name, mode, loss, rec["deviation_pct"], launches, rec["launch_ms"], words_between,
-                  rec["xchg_delta_ms_per_exchange"], rec["xchg_apply_ms_per_exchange"], 100 * rec["xchg_elementwise_share_of_a_launch"], time.time() - t0), flush=True)
+                  rec["xchg_delta_ms_per_exchange"], rec["xchg_apply_ms_per_exchange"], 100 * rec["xchg_elementwise_share_of_a_launch"],
+                  model_gb, rec["link_ms_ring_one_link"], rec["link_ms_direct_all_links"], rec["interval_ms_this_replica"],
+                  rec["interval_ms_full_device"], time.time() - t0), flush=True)
 if a.out:
     json.dump(res, open(a.out, "w"), indent=1)
 corpus.close()
