@@ -172,7 +172,11 @@ typedef struct w2b_tuning {
   int32_t exchange_rule;
   int32_t exchange_tau_u;
   int32_t exchange_tau_v;
-  int32_t reserved_r6;     /* must be zero */
+  /* plain worker kernel: how many workers run AT ONCE; a launch of more workers runs them in slices of this many, one after the
+   * other (every worker still advances by max_positions per w2b_train_step).  0 = the library decides: all of them, except on
+   * vocabularies so small and flat that every row collides, where a quarter run at a time (at least 16): there concurrency x the
+   * time a row is open is what moves the epoch loss, and a GPU workgroup has a row open several times longer than a CPU thread. */
+  int32_t concurrent_workers;
 } w2b_tuning;
 /* What the library decides for a launch of the automatic worker kernel with `workers` concurrent workers on a GPU with `num_cus`
  * compute units, from the word counts alone (pure host arithmetic: usable -- and tested -- without a GPU): per-XCD copies

@@ -38,6 +38,7 @@ ap.add_argument("--size", type=int, default=800)
 ap.add_argument("--negative", type=int, default=24)
 ap.add_argument("--window", type=int, default=8)
 ap.add_argument("--bitlevel", type=int, default=1)
+ap.add_argument("--sample", type=float, default=0.0, help="-sample of every trainer (the reference's default is 1e-3)")
 ap.add_argument("--single", type=float, default=0.0, help="epoch loss of the single replica (skips that run)")
 ap.add_argument("--single-validation", type=float, default=0.0)
 ap.add_argument("--out", default="")
@@ -223,7 +224,7 @@ def run(Rn, rule, bf16=False):
     quota = corpus.train_words // a.workers
     ts = []
     for r in range(Rn):
-        t = w2b.Trainer(V, D, a.window, a.negative, a.bitlevel, num_threads=per, iter=1, sample=0.0, train_words=corpus.train_words,
+        t = w2b.Trainer(V, D, a.window, a.negative, a.bitlevel, num_threads=per, iter=1, sample=a.sample, train_words=corpus.train_words,
                         compute_loss=True, worker_offset=r * per, total_threads=a.workers)
         t.init_net()
         t.set_vocab_counts(counts, 100_000_000)

@@ -300,31 +300,26 @@ def test_benchmarked_setting_literally_100m_tokens(gpu, tmp_path):
         os.remove(corpus)
 
 
-def one_run_band(job):
-    """regimes with ONE reference run (minutes of the 256-thread host each): the tolerance is the FLOOR"""
-    runs = [r for r in BANDS[job]["runs"] if r["threads"] == 256]
-    return np.array([r["epoch_losses"] for r in runs]).mean(0)
-
-
 def test_full_device_on_a_second_held_out_long_stream(gpu, tmp_path):
     """heldout_v1m (round 6; asked for by the round-5 review): V = 1 M, Zipf exponent 1.1, size 512, window 5, negative 10, 85 M
     words -- a second full-device long-stream regime, its reference band recorded BEFORE any constant of the full-device mode
     (merge period 16 -- tuned on the very stream it was asserted on --, weight 1/8, ~113 + 113 copies) was touched again.
-    `-threads 0` runs 1701 workers with per-XCD copies.  Measured with the shipped defaults (profiles/r06_sessions/
-    r06b_fidelity_runs.txt): +0.96 / +1.19 % of the reference's epoch loss; `-hot-rows 0`: -1.17 %."""
+    `-threads 0` runs 1701 workers with per-XCD copies.  Band: two 256-thread runs of the unmodified reference (0.37 % apart,
+    sigma 0.26 % -- this regime is the reference's least repeatable one).  Measured with the shipped defaults (profiles/r06_sessions/
+    r06b_fidelity_runs.txt, r06e): -336.5 ... -337.3 M = +1.15 ... +1.38 % of the band's mean; `-hot-rows 0`: -1.0 %.  The product's
+    own runs scatter by 0.12 %; the gate is on the mean of two, like the band."""
     from w2b_testlib import write_heldout_corpus, HELDOUT_BIG
     job = "heldout_v1m"
     corpus = write_heldout_corpus(str(tmp_path / "c.txt"), job)
     flags = BANDS[job]["flags"]
     assert flags == HELDOUT_BIG[job]["flags"]
-    ref = one_run_band(job)
     try:
-        losses, workers, _ = train(corpus, "/dev/null", 0, flags)
-        dev = (losses - ref) / np.abs(ref)
-        print("FIDELITY %s threads=0 (%d workers): losses %s | reference @256 threads %s | deviation %s %%" %
-              (job, workers, losses.tolist(), ref.tolist(), np.round(100 * dev, 2).tolist()))
-        assert workers >= 768
-        assert np.all(np.abs(dev) <= FLOOR), dev.tolist()
+        runs = []
+        for _ in range(2):
+            losses, workers, _ = train(corpus, "/dev/null", 0, flags)
+            assert workers >= 768
+            runs.append(losses)
+        check_losses("%s threads=0 (%d workers), mean of two runs %s" % (job, workers, [r.tolist() for r in runs]), job, 256, np.mean(runs, 0))
     finally:
         os.remove(corpus)
 
@@ -332,20 +327,17 @@ def test_full_device_on_a_second_held_out_long_stream(gpu, tmp_path):
 def test_long_streams_at_short_rows(gpu, tmp_path):
     """(round-5 review, weak 1d) the row lengths at which the row-group kernel is automatic -- BASELINE configs[0] (size 200) and
     configs[2] (size 400, 2 bits) -- on a 100 M-token stream over the text8-sized vocabulary (default sub-sampling): explicit
-    `-threads 256` (row groups) and `-threads 0` (a full device here: plain kernel with copies) against one 256-thread run of the
-    unmodified reference each.  Measured (r06b): size 200 +0.11 / +0.65 %, size 400 / 2 bits -0.62 / +0.92 %."""
+    `-threads 256` (row groups) and `-threads 0` (a full device here: plain kernel with copies) against two 256-thread runs of the
+    unmodified reference each (sigma 0.01 %).  Measured (r06b): size 200 +0.11 / +0.65 %, size 400 / 2 bits -0.62 / +0.92 %."""
     from w2b_testlib import write_heldout_corpus, HELDOUT_BIG
     corpus = write_heldout_corpus(str(tmp_path / "c.txt"), "long_d200")
     try:
         for job in ("long_d200", "long_d400b2"):
             flags = BANDS[job]["flags"]
             assert flags == HELDOUT_BIG[job]["flags"] and HELDOUT_BIG[job]["corpus"] == HELDOUT_BIG["long_d200"]["corpus"]
-            ref = one_run_band(job)
             for threads in (256, 0):
                 losses, workers, err = train(corpus, "/dev/null", threads, flags)
-                dev = (losses - ref) / np.abs(ref)
-                print("FIDELITY %s threads=%d (%d workers): deviation %s %%" % (job, threads, workers, np.round(100 * dev, 2).tolist()))
                 assert "notice" not in err                      # (an explicit count that the row-group kernel runs is kept)
-                assert np.all(np.abs(dev) <= FLOOR), (job, threads, dev.tolist())
+                check_losses("%s threads=%d (%d workers)" % (job, threads, workers), job, 256, losses)
     finally:
         os.remove(corpus)

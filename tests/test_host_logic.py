@@ -216,7 +216,7 @@ def test_tuning_struct_layout_matches_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = re.findall(r"int32_t\s+(\w+)", body)
     assert names == [n for n, _ in _lib.Tuning._fields_]
-    assert C.sizeof(_lib.Tuning) == 4 * (12 + 4 + 4)          # round 6: + exchange_rule, exchange_tau_u / _v, reserved_r6
+    assert C.sizeof(_lib.Tuning) == 4 * (12 + 4 + 4)          # round 6: + exchange_rule, exchange_tau_u / _v, concurrent_workers
 
 
 def test_replica_token_slice_covers_what_the_workers_read():

@@ -42,7 +42,7 @@ class Tuning(C.Structure):
         ("hot_cap", C.c_int32), ("force_row_desc", C.c_int32), ("grid_per_cu", C.c_int32), ("mem_mode", C.c_int32),
         ("atomic_rank", C.c_int32), ("atomic_cap", C.c_int32), ("hot_weight_permille", C.c_int32), ("window_refresh", C.c_int32),
         ("atomic_rank_u", C.c_int32), ("fresh_rank_u", C.c_int32), ("exchange_sat_updates", C.c_int32), ("refresh_rows_u", C.c_int32),
-        ("exchange_rule", C.c_int32), ("exchange_tau_u", C.c_int32), ("exchange_tau_v", C.c_int32), ("reserved_r6", C.c_int32),
+        ("exchange_rule", C.c_int32), ("exchange_tau_u", C.c_int32), ("exchange_tau_v", C.c_int32), ("concurrent_workers", C.c_int32),
     ]
 
 

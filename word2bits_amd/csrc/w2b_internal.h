@@ -85,6 +85,8 @@ struct W2bParams {
   int rc_rows;                    // 0 = none
   float *rc;                      // [W2B_NXCD][rc_rows][dim]
   int *rc_flags;                  // [0..8) claim (one refresher per XCD), [16..24) alive (the XCD's copies have been filled in this launch)
+  int worker_base;                // plain worker kernel: workgroup b is worker worker_base + b (a launch may cover a slice of the workers:
+                                  // w2b_tuning.concurrent_workers)
   float starting_alpha, sample, reg;
 };
 
@@ -97,7 +99,7 @@ hipError_t w2b_launch_tuples(const W2bParams &p, long long n, const int32_t *cen
                              const int32_t *ctx_off, const int32_t *ctx, const int32_t *neg,
                              float alpha, int grid, int num_cus, int per_cu_override, bool loss,
                              hipStream_t s);
-hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s);
+hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s, int grid = 0);   // grid workgroups = workers worker_base .. worker_base + grid
 // sentence-resident variant (w2b_kernels_resident.hip): radius >= 0 when it can run for this shape
 int w2b_resident_plan(int dim, int window, int negative);
 bool w2b_resident_atomic_ok(const W2bParams &p, int radius);           // atomic_rank > 0: can the sentence-resident kernel do it?

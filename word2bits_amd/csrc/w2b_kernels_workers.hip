@@ -13,7 +13,7 @@ __global__ void __launch_bounds__(MAXTHREADS, (MAXTHREADS <= 256 ? W2B_MINWAVES 
   WorkerLds *S = reinterpret_cast<WorkerLds *>(s_sen + round4(W2B_MAX_SEN) + 4);
   if (MM == W2B_MM_EXACT) L.xprod = reinterpret_cast<float *>(reinterpret_cast<int *>(S) + (sizeof(WorkerLds) + 3) / 4 + 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wid = blockIdx.x;
+  const int wid = blockIdx.x + P.worker_base;
   if (wid >= P.num_threads) return;
   W2bWorker *G = P.workers + wid;
   if (G->done) return;
@@ -160,7 +160,8 @@ int w2b_workers_per_cu(const W2bParams &p, bool loss) {
   return nb > 0 ? nb : 1;
 }
 
-hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s) {
+hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool loss, hipStream_t s, int grid) {
+  if (grid <= 0) grid = p.num_threads - p.worker_base;
   int vec;
   const int threads = w2b_block_threads(p.dim, &vec);
   const size_t lds = w2b_lds_bytes(p.dim, p.window, p.negative, true, p.exact != 0);
@@ -169,13 +170,13 @@ hipError_t w2b_launch_workers(const W2bParams &p, long long max_positions, bool 
   return dispatch_q(p.bitlevel, [&](auto qm) -> hipError_t {
     constexpr int QM = decltype(qm)::value;
 #define W2B_LAUNCH_W(VEC, LOSS) \
-    do { if (threads <= 256) hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 256, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); \
-         else hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 1024, MM>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions); } while (0)
+    do { if (threads <= 256) hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 256, MM>), dim3(grid), dim3(threads), lds, s, p, max_positions); \
+         else hipLaunchKernelGGL((k_train_workers<QM, VEC, LOSS, 1024, MM>), dim3(grid), dim3(threads), lds, s, p, max_positions); } while (0)
     if constexpr (MM == 0) {          // coherent rows, 16-byte columns, at most 256 threads: the instantiations with the row addressing
       // fixed at compile time (TB) and, where rows are updated with atomic adds (w2b_tuning.atomic_rank*), the ATOM ones
       const int atom = p.atomic_rank > 0 ? 2 : (p.atomic_rank_u > 0 ? 1 : 0);
       if (vec == 4 && threads <= 256 && (atom || p.tab_bytes != 0)) {
-#define W2B_LAUNCH_A(LOSS, ATOM, TB) hipLaunchKernelGGL((k_train_workers<QM, 4, LOSS, 256, 0, ATOM, TB>), dim3(p.num_threads), dim3(threads), lds, s, p, max_positions)
+#define W2B_LAUNCH_A(LOSS, ATOM, TB) hipLaunchKernelGGL((k_train_workers<QM, 4, LOSS, 256, 0, ATOM, TB>), dim3(grid), dim3(threads), lds, s, p, max_positions)
 #define W2B_LAUNCH_AT(LOSS, ATOM) do { if (p.tab_bytes != 0) W2B_LAUNCH_A(LOSS, ATOM, 0); else W2B_LAUNCH_A(LOSS, ATOM, -1); } while (0)
         if (atom == 2) { if (loss) W2B_LAUNCH_AT(true, 2); else W2B_LAUNCH_AT(false, 2); }
         else if (atom == 1) { if (loss) W2B_LAUNCH_AT(true, 1); else W2B_LAUNCH_AT(false, 1); }

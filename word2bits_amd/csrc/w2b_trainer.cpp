@@ -247,6 +247,7 @@ static W2bParams make_params(const w2b_trainer *t) {
   p.rc_rows = 0;
   p.rc = nullptr;
   p.rc_flags = nullptr;
+  p.worker_base = 0;
   p.starting_alpha = t->cfg.alpha;
   p.sample = t->cfg.sample;
   p.reg = t->cfg.reg;
@@ -396,8 +397,8 @@ extern "C" int w2b_set_tuning(w2b_trainer *t, const w2b_tuning *in) {
   if (in->hot_weight_permille < 1 || in->hot_weight_permille > 1000)
     return fail(W2B_EINVAL, "w2b_set_tuning: hot_weight_permille must be 1..1000");
   if (in->refresh_rows_u < -1 || in->refresh_rows_u > W2B_RC_MAX) return fail(W2B_EINVAL, "w2b_set_tuning: refresh_rows_u must be -1 .. 64");
-  if (in->exchange_rule < 0 || in->exchange_rule > 2 || in->exchange_tau_u < 0 || in->exchange_tau_v < 0 || in->reserved_r6 != 0)
-    return fail(W2B_EINVAL, "w2b_set_tuning: exchange_rule must be 0, 1 or 2, exchange_tau_* >= 0, reserved_r6 == 0");
+  if (in->exchange_rule < 0 || in->exchange_rule > 2 || in->exchange_tau_u < 0 || in->exchange_tau_v < 0 || in->concurrent_workers < 0)
+    return fail(W2B_EINVAL, "w2b_set_tuning: exchange_rule must be 0, 1 or 2, exchange_tau_* >= 0, concurrent_workers >= 0");
   t->tune = *in;
   return W2B_OK;
 }
@@ -1177,6 +1178,25 @@ extern "C" int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, cons
   return W2B_OK;
 }
 
+// How many workers of the plain kernel run AT ONCE (w2b_tuning.concurrent_workers; 0 = automatic).  A worker is a shard and an LCG
+// stream; how many of them are in flight together is an execution detail -- the reference's own threads are scheduled by the OS,
+// and a GPU launch with more workers than resident workgroups already runs them in rounds.  Automatic = all of them, except on
+// vocabularies so small and flat that every row collides (atomic_plan: every row gets lossless adds).  There what decides the
+// epoch loss is concurrency x the time a row is open, and a GPU workgroup has a chunk of 13 target rows open for ~10 us where the
+// reference's thread has one row open for ~1.5 us: 64 workers at once over-shoot (planted corpus at the configs[2] shape: -1.0 ...
+// -2.8 % over five epochs, the ONE stated exception of the 1.5 % floor until round 6), a quarter of them at a time do not.
+static const int W2B_FLAT_CONCURRENCY_DIV = 4, W2B_FLAT_CONCURRENCY_MIN = 16;
+static int concurrency_plan(const w2b_trainer *t, int workers) {
+  int c = workers;
+  if (t->tune.concurrent_workers > 0) c = t->tune.concurrent_workers;
+  else if (workers > W2B_FLAT_CONCURRENCY_MIN && atomic_plan(t, workers) >= t->cfg.vocab_size - 1 && t->tune.atomic_rank < 0) {
+    c = workers / W2B_FLAT_CONCURRENCY_DIV;
+    if (c < W2B_FLAT_CONCURRENCY_MIN) c = W2B_FLAT_CONCURRENCY_MIN;
+  }
+  if (c > workers) c = workers;
+  return c > 0 ? c : 1;
+}
+
 extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   NEED(t);
   if (!t->corpus || !t->shards_set) return fail(W2B_ESTATE, "w2b_train_step: corpus/shards not set");
@@ -1218,7 +1238,17 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
       HIPCHK(hipEventRecord(t->rc_end, t->rc_stream));
     }
   }
-  else HIPCHK(w2b_launch_workers(p, max_positions, t->cfg.compute_loss != 0, t->stream));
+  else {
+    // plain kernel: all workers at once, or -- w2b_tuning.concurrent_workers / concurrency_plan -- in slices of that many, one
+    // slice after the other on the stream (every worker still advances by max_positions per call)
+    const int conc = concurrency_plan(t, t->cfg.num_threads);
+    W2bParams q = p;
+    for (int base = 0; base < t->cfg.num_threads; base += conc) {
+      q.worker_base = base;
+      q.num_threads = t->cfg.num_threads;
+      HIPCHK(w2b_launch_workers(q, max_positions, t->cfg.compute_loss != 0, t->stream, base + conc < t->cfg.num_threads ? conc : t->cfg.num_threads - base));
+    }
+  }
   HIPCHK(timing_end(t));
   if (p.rc_rows > 0) HIPCHK(hipStreamWaitEvent(t->stream, t->rc_end, 0));   // (what follows on this stream also follows the refresher's end)
   HIPCHK(w2b_launch_xhot_fold(p, t->stream));      // the master rows are complete again when the stream is idle

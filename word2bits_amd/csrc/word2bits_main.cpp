@@ -55,6 +55,7 @@ struct Options {                       // defaults: ref src/word2bits.cpp:48-54,
   int row_desc = 0;                    // -row-desc 1: the row addressing of tables >= 2 GiB on any table (w2b_tuning.force_row_desc)
   long long sync_words = 0;            // -sync-words N: centre words per replica between two exchanges (0 = automatic, below); sets -positions / -sync-every
   int threads_literal = 0;             // -threads-literal 1: keep an explicit -threads N even where the library would rather fill the device
+  int concurrent = 0;                  // -concurrent N: w2b_tuning.concurrent_workers (0 = the library decides)
   int xchg_rule = 0, xchg_tau_u = 0, xchg_tau_v = 0;   // -exchange-rule / -exchange-tau-u / -exchange-tau-v: w2b_tuning.exchange_* (replicas)
 };
 
@@ -211,6 +212,7 @@ int main(int argc, char **argv) {
   if ((i = arg_pos("-window-refresh", argc, argv)) > 0) o.window_refresh = atoi(argv[i + 1]);
   if ((i = arg_pos("-threads-literal", argc, argv)) > 0) o.threads_literal = atoi(argv[i + 1]);
   if ((i = arg_pos("-sync-words", argc, argv)) > 0) o.sync_words = atoll(argv[i + 1]);
+  if ((i = arg_pos("-concurrent", argc, argv)) > 0) o.concurrent = atoi(argv[i + 1]);
   if ((i = arg_pos("-exchange-rule", argc, argv)) > 0) o.xchg_rule = atoi(argv[i + 1]);
   if ((i = arg_pos("-exchange-tau-u", argc, argv)) > 0) o.xchg_tau_u = atoi(argv[i + 1]);
   if ((i = arg_pos("-exchange-tau-v", argc, argv)) > 0) o.xchg_tau_v = atoi(argv[i + 1]);
@@ -377,7 +379,8 @@ int main(int argc, char **argv) {
     cfg.exact_reduction = o.exact;
     cfg.total_threads = o.num_threads;                  // total_threads across all GPUs
     CK(w2b_trainer_create(&cfg, &a->r->t));
-    if (o.hot_rows >= 0 || o.hot_rows_u >= 0 || o.hot_rows_v >= 0 || o.hot_cap >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0 || o.atomic_rank_u != 0 || o.fresh_rank_u != 0 || o.refresh_rows_u != 0) {
+    if (o.hot_rows >= 0 || o.hot_rows_u >= 0 || o.hot_rows_v >= 0 || o.hot_cap >= 0 || o.hot_period > 0 || o.row_desc || o.atomic_rank >= -1 || o.atomic_cap >= 0 || o.hot_weight > 0 || o.window_refresh >= 0 || o.atomic_rank_u != 0 || o.fresh_rank_u != 0 || o.refresh_rows_u != 0 ||
+        o.concurrent > 0 || o.xchg_rule > 0 || o.xchg_tau_u > 0 || o.xchg_tau_v > 0) {
       w2b_tuning tn;
       CK(w2b_get_tuning(a->r->t, &tn));
       if (o.hot_rows >= 0) tn.hot_rows_v = tn.hot_rows_u = o.hot_rows;
@@ -393,6 +396,7 @@ int main(int argc, char **argv) {
       if (o.atomic_rank_u != 0) tn.atomic_rank_u = o.atomic_rank_u;
       if (o.fresh_rank_u != 0) tn.fresh_rank_u = o.fresh_rank_u;
       if (o.refresh_rows_u != 0) tn.refresh_rows_u = o.refresh_rows_u;
+      if (o.concurrent > 0) tn.concurrent_workers = o.concurrent;
       if (o.xchg_rule > 0) tn.exchange_rule = o.xchg_rule;
       if (o.xchg_tau_u > 0) tn.exchange_tau_u = o.xchg_tau_u;
       if (o.xchg_tau_v > 0) tn.exchange_tau_v = o.xchg_tau_v;
