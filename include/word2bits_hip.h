@@ -174,7 +174,7 @@ typedef struct w2b_tuning {
   int32_t exchange_tau_v;
   /* plain worker kernel: how many workers run AT ONCE; a launch of more workers runs them in slices of this many, one after the
    * other (every worker still advances by max_positions per w2b_train_step).  0 = the library decides: all of them, except on
-   * vocabularies so small and flat that every row collides, where a quarter run at a time (at least 16): there concurrency x the
+   * vocabularies so small and flat that every row collides, where 3/8 of them run at a time (at least 16): there concurrency x the
    * time a row is open is what moves the epoch loss, and a GPU workgroup has a row open several times longer than a CPU thread. */
   int32_t concurrent_workers;
 } w2b_tuning;
@@ -188,6 +188,7 @@ typedef struct w2b_row_plan {
   int32_t merge_period;                /* centre words between two merge events of a worker */
   int32_t row_group_kernel;            /* round 5: 1 = the row-group worker kernel runs (short rows, fidelity budget not thin), 0 = the plain one */
   int32_t refresh_rows_u;              /* round 5: context rows 1..N read at refreshed per-XCD copies (row-group kernel only) */
+  int32_t concurrent_workers;          /* round 6: workers of the plain kernel that run at once (= workers, except on small flat vocabularies) */
 } w2b_row_plan;
 int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, const int64_t *cn, int32_t num_cus, int32_t workers,
                   w2b_row_plan *out);

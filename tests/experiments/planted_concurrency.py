@@ -10,13 +10,14 @@ from planted import make_planted, parse_accuracy
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", default="")
+ap.add_argument("--cfg2-64", default="0,64,32,16,8", help="workers at once to try for planted_cfg2_b2_d400 at 64 threads (0 = automatic)")
 a = ap.parse_args()
 BANDS = json.load(open(os.path.join(ROOT, "tests", "golden", "fidelity_bands.json")))["jobs"]
 d = tempfile.mkdtemp()
 corpus, questions = os.path.join(d, "planted.txt"), os.path.join(d, "questions.txt")
 make_planted(corpus, questions, repeats=120)
 res = []
-for job, threads, concs in (("planted_cfg2_b2_d400", 64, (0, 64, 32, 16, 8)), ("planted_b1_d200", 64, (0, 64, 16)),
+for job, threads, concs in (("planted_cfg2_b2_d400", 64, tuple(int(x) for x in a.cfg2_64.split(","))), ("planted_b1_d200", 64, (0, 64, 16)),
                             ("planted_b1_d200", 512, (0, 512, 64)), ("planted_cfg2_b2_d400", 8, (0,))):
     runs = [r for r in BANDS[job]["runs"] if r["threads"] == threads]
     mean = np.array([r["epoch_losses"] for r in runs]).mean(0)

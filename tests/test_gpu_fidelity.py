@@ -16,8 +16,8 @@ to what the UNMODIFIED reference program does with the SAME number of truly conc
 
 Every tolerance is  max(3 sigma of the reference's own runs at that thread count, FLOOR)  per epoch.  The reference is
 extremely repeatable (sigma 0.01-0.4 % of an epoch loss), so the floor decides: ONE floor for every regime since round 4,
-1.5 % (round 3 had 1.5 % / 3.5 % per regime, set just above what the product measured), with one exception that is stated
-where it is made (FLOOR_EXCEPTION: the planted corpus at the configs[2] shape with 64 workers).  What the product does to stay
+1.5 % (round 3 had 1.5 % / 3.5 % per regime, set just above what the product measured); rounds 3-5 stated one exception (the
+planted corpus at the configs[2] shape with 64 workers), round 6 retired it (FLOOR_EXCEPTION below is empty).  What the product does to stay
 inside it (profiles/r04_sessions/ has every matrix these numbers were read from):
   * the automatic kernel is the plain one (the sentence-resident kernel keeps context rows private for up to 2 x window + 1
     positions: -13 % on heldout_zipf12 at 256 workers; it is an explicit choice now and held to its own, looser bound below);
@@ -53,15 +53,17 @@ EVAL = os.path.join(ROOT, "compute_accuracy")
 BANDS = json.load(open(os.path.join(GOLDEN, "fidelity_bands.json")))["jobs"]
 
 FLOOR = 0.015            # of the reference's mean epoch loss; every regime, every worker count, the automatic kernel
-# ... with ONE exception, stated rather than hidden: the planted corpus at the configs[2] shape (2 bits, size 400) with 64
-# workers -- 2 129 words without a frequency skew, 8 800 words per worker and epoch, every row hit by several workers per
-# window.  There every row is updated by lossless adds (w2b_tuning.atomic_rank, automatic), and the epoch losses drift from
-# -1.0 % (epoch 1) to -2.8 % (epoch 5) of the reference's (whose own 3 sigma is 1.3 % there); without the adds they are
-# +3 ... +5 % off, with them for the context rows only +3 ... +4 % (profiles/r04_sessions/r04f_planted_arms.txt).  A target row
-# is open for a chunk of 13 rows here where the reference's thread has it open for one row: the gradients that are summed
-# are staler than the reference's.  Its 2-bit accuracy is 2.7-3.9 points ABOVE the reference's band (20.5 against 16.9-17.8).
-FLOOR_EXCEPTION = {("planted_cfg2_b2_d400", 64): 0.035}
-ACC_EXCEPTION = {("planted_cfg2_b2_d400", 64): 5.0}
+# Rounds 3-5 had ONE stated exception: the planted corpus at the configs[2] shape (2 bits, size 400) with 64 workers -- 2 129 words
+# without a frequency skew, every row hit by several workers per window: -1.0 ... -2.8 % over the five epochs (3.5 % allowed) and an
+# accuracy of 19.2-20.5 against the reference's 16.9-17.8 (5 points allowed).  A GPU workgroup has a chunk of 13 target rows open for
+# ~10 us where the reference's thread has one row open for ~1.5 us, so 64 workers AT ONCE collide far more often than 64 threads.
+# Round 6 retired it: on such vocabularies the plain kernel runs 3/8 of the workers at a time (w2b_tuning.concurrent_workers,
+# automatic; every worker still walks its own shard with its own LCG stream): +0.5 ... -0.9 %, accuracy 15.3-16.0
+# (profiles/r06_sessions/r06h_planted_concurrency.txt, r06i).  No exception is left for the automatic kernel.
+FLOOR_EXCEPTION = {}
+ACC_EXCEPTION = {}
+# (the sentence-resident kernel -- explicit only, not sliced -- keeps round 5's bound on that one case: -1.8 ... -2.5 %)
+FLOOR_RESIDENT_EXCEPTION = {("planted_cfg2_b2_d400", 64): 0.035}
 # The sentence-resident kernel (explicit: -window-cache 1) where it was measured (profiles/r03_sessions, r04_sessions):
 # planted corpus and text8-sized corpus within 2.5 %; NOT asserted on the held-out regimes (-13 % on heldout_zipf12).
 FLOOR_RESIDENT = 0.025
@@ -139,7 +141,8 @@ def test_planted_matches_reference_at_equal_thread_count(gpu, planted, job, thre
     _, _, acc_ref = band(job, threads)
     margin = max(ACC_EXCEPTION.get((job, threads), ACC_POINTS), 3 * float(acc_ref.std(ddof=1)))
     floor_auto = FLOOR_EXCEPTION.get((job, threads), FLOOR)
-    for kernel, extra, floor in (("auto", [], floor_auto), ("resident", ["-window-cache", "1"], max(floor_auto, FLOOR_RESIDENT))):
+    floor_res = max(floor_auto, FLOOR_RESIDENT_EXCEPTION.get((job, threads), FLOOR_RESIDENT))
+    for kernel, extra, floor in (("auto", [], floor_auto), ("resident", ["-window-cache", "1"], floor_res)):
         out = str(d / ("%s_%s_%d.bin" % (job, kernel, threads)))
         losses, _, _ = train(corpus, out, threads, flags, extra)
         acc = score(out, questions)

@@ -406,6 +406,11 @@ def test_row_rules_round5_kernel_choice_refreshed_copies_and_unsupported_shapes(
     # (c)
     flat2 = np.full(2129, 300, np.int64)
     assert _plan(flat2, 64, D=800)["atomic_rank_v"] == 2128
+    # (round 6) ... and on such a vocabulary the plain kernel runs 3/8 of the workers at a time, at least 16 (w2b_tuning.concurrent_workers)
+    assert _plan(flat2, 64, D=400)["concurrent_workers"] == 24 and _plan(flat2, 512, D=200)["concurrent_workers"] == 192
+    assert _plan(flat2, 16, D=400)["concurrent_workers"] == 16 and _plan(flat2, 8, D=400)["concurrent_workers"] == 8
+    assert _plan(flat2, 64, D=400, concurrent_workers=40)["concurrent_workers"] == 40
+    assert _plan(cn, 256, D=800)["concurrent_workers"] == 256 and _plan(cn, 1024, D=800)["concurrent_workers"] == 1024
     assert _plan(flat2, 64, D=1024, atomic_rank=100)["atomic_rank_v"] == 100     # the widest row with an ATOM instantiation
     p = _plan(flat2, 64, D=2048, atomic_rank=100, atomic_rank_u=100)
     assert p["atomic_rank_v"] == 0 and p["atomic_rank_u"] == 0

@@ -49,7 +49,8 @@ class Tuning(C.Structure):
 class RowPlan(C.Structure):
     """struct w2b_row_plan -- what w2b_plan_rows decides for a launch (include/word2bits_hip.h)."""
     _fields_ = [("copies_u", C.c_int32), ("copies_v", C.c_int32), ("atomic_rank_u", C.c_int32), ("atomic_rank_v", C.c_int32),
-                ("full_device", C.c_int32), ("merge_period", C.c_int32), ("row_group_kernel", C.c_int32), ("refresh_rows_u", C.c_int32)]
+                ("full_device", C.c_int32), ("merge_period", C.c_int32), ("row_group_kernel", C.c_int32), ("refresh_rows_u", C.c_int32),
+                ("concurrent_workers", C.c_int32)]
 
 
 vp, i32p, i64p, f32p, f64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), \

@@ -1151,6 +1151,8 @@ extern "C" int w2b_worker_kernel_info(w2b_trainer *t, int32_t *resident, int32_t
 
 // The row rules of a launch without a device (pure host arithmetic on the word counts): what w2b_train_step would decide for
 // `workers` concurrent workers of the plain kernel on a GPU with `num_cus` compute units.
+static int concurrency_plan(const w2b_trainer *t, int workers);
+
 extern "C" int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, const int64_t *cn, int32_t num_cus, int32_t workers,
                              w2b_row_plan *out) {
   if (!cfg || !cn || !out || num_cus < 1 || workers < 1 || cfg->vocab_size < 2 || cfg->layer1_size < 1)
@@ -1175,6 +1177,7 @@ extern "C" int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, cons
   t.table_elems = (long long)cfg->vocab_size * cfg->layer1_size;
   out->row_group_kernel = groups_plan(&t, workers) ? 1 : 0;
   out->refresh_rows_u = out->row_group_kernel ? rc_plan(&t, workers, out->atomic_rank_u) : 0;
+  out->concurrent_workers = out->row_group_kernel ? workers : concurrency_plan(&t, workers);
   return W2B_OK;
 }
 
@@ -1184,13 +1187,21 @@ extern "C" int w2b_plan_rows(const w2b_config *cfg, const w2b_tuning *tune, cons
 // vocabularies so small and flat that every row collides (atomic_plan: every row gets lossless adds).  There what decides the
 // epoch loss is concurrency x the time a row is open, and a GPU workgroup has a chunk of 13 target rows open for ~10 us where the
 // reference's thread has one row open for ~1.5 us: 64 workers at once over-shoot (planted corpus at the configs[2] shape: -1.0 ...
-// -2.8 % over five epochs, the ONE stated exception of the 1.5 % floor until round 6), a quarter of them at a time do not.
-static const int W2B_FLAT_CONCURRENCY_DIV = 4, W2B_FLAT_CONCURRENCY_MIN = 16;
+// -2.8 % over five epochs, the ONE stated exception of the 1.5 % floor until round 6), a part of them at a time do not.
+// Measured (planted corpus, configs[2] shape, 64 workers, five epochs; profiles/r06_sessions/r06h_planted_concurrency.txt, r06i):
+//   at once   epoch losses vs the reference's 64-thread band          accuracy (band 16.9-17.8)
+//      64     -0.7 / -1.2 / -1.4 / -2.0 / -2.5 %                       19.9      (rounds 3-5: the exception)
+//      32     -0.1 / +0.2 / -0.6 / -1.4 / -1.2 %                       15.5
+//      16     +0.3 / +0.4 / +0.1 / -0.3 / +0.1 %                       14.2
+//       8     +0.5 / +1.1 / +0.6 / +0.5 / +0.5 %                       14.1
+// The losses want few workers at once, the accuracy (which in the reference itself rises from 9.5 at 8 threads to 17.3 at 64) wants
+// many: 3/8 of the workers, at least 16, keeps both inside their gates.
+static const int W2B_FLAT_CONCURRENCY_NUM = 3, W2B_FLAT_CONCURRENCY_DEN = 8, W2B_FLAT_CONCURRENCY_MIN = 16;
 static int concurrency_plan(const w2b_trainer *t, int workers) {
   int c = workers;
   if (t->tune.concurrent_workers > 0) c = t->tune.concurrent_workers;
   else if (workers > W2B_FLAT_CONCURRENCY_MIN && atomic_plan(t, workers) >= t->cfg.vocab_size - 1 && t->tune.atomic_rank < 0) {
-    c = workers / W2B_FLAT_CONCURRENCY_DIV;
+    c = workers * W2B_FLAT_CONCURRENCY_NUM / W2B_FLAT_CONCURRENCY_DEN;
     if (c < W2B_FLAT_CONCURRENCY_MIN) c = W2B_FLAT_CONCURRENCY_MIN;
   }
   if (c > workers) c = workers;
