@@ -308,6 +308,10 @@ int w2b_comm_count(w2b_trainer *t, int32_t *nranks_out);
  * from 4 replicas on).  Measured in tests/test_gpu_exchange.py: 2 / 4 / 8 replicas on one GPU through the phase API below.
  * Asynchronous (see above). */
 int w2b_sync_replicas(w2b_trainer *t, int32_t mode);
+/* Centre words per replica between two exchanges that ./word2bits -gpus N uses when nothing else is said: 1 / 32 of a replica's
+ * words per epoch, between 32 768 and 1 048 576 (where the staleness of a replica and the rule's own bias were measured to cancel on
+ * four regimes, and where one exchange of the whole model per launch fits the xGMI links).  Pure arithmetic. */
+int64_t w2b_suggested_exchange_words(int64_t train_words_per_epoch, int32_t replicas);
 /* (Round 4 also had a HOT TIER -- w2b_sync_hot_rows / w2b_exchange_begin_hot / w2b_exchange_hot_rows: the leading rows of both
  * tables exchanged after every launch.  It measured no gain over the full exchanges alone -- the rows that are rare individually
  * are a quarter of all draws and want the short interval as much as the frequent ones -- and was removed in round 5.) */

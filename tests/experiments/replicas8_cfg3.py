@@ -30,7 +30,7 @@ print("R8 corpus: %d words, vocabulary %d  [%.1f s]" % (corpus.train_words, corp
 tokens = corpus.tokens()
 counts = corpus.counts()
 if a.positions <= 0:                                      # the command line's rule (word2bits_main.cpp): 1 / 32 of a replica's epoch
-    words = min(1048576, max(32768, corpus.train_words // a.replicas // 32))
+    words = w2b.lib().w2b_suggested_exchange_words(int(corpus.train_words), a.replicas)
     a.positions = max(16, words // (a.workers // a.replicas))
 res = {"corpus_words": int(corpus.train_words), "workers_total": a.workers, "positions": a.positions, "runs": []}
 

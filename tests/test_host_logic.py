@@ -416,3 +416,14 @@ def test_row_rules_round5_kernel_choice_refreshed_copies_and_unsupported_shapes(
     assert p["atomic_rank_v"] == 0 and p["atomic_rank_u"] == 0
     assert _plan(flat2, 64, D=200, mem_mode=1, atomic_rank_u=100)["atomic_rank_u"] == 0
     assert _plan(flat2, 64, D=200, atomic_rank_u=100)["atomic_rank_u"] == 100
+
+
+def test_suggested_exchange_interval():
+    """./word2bits -gpus N: centre words per replica between two exchanges -- 1 / 32 of a replica's epoch, clamped to 32 K ... 1 M
+    (w2b_suggested_exchange_words; DESIGN.md section 3.5 has the four regimes it was read off)"""
+    f = w2b.lib().w2b_suggested_exchange_words
+    assert f(22_021_995, 8) == 22_021_995 // 8 // 32 == 86_023          # the 22 M-token proxy: 86 K words
+    assert f(100_099_995, 8) == 100_099_995 // 8 // 32 == 391_015           # configs[1] literally
+    assert f(1_000_000_000, 8) == 1_048_576                              # configs[3]: the 1 M words the links allow
+    assert f(1_000_000, 8) == 32_768 and f(100, 0) == 32_768
+    assert f(100_099_995, 1) == 1_048_576

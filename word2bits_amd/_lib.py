@@ -101,6 +101,7 @@ SIGNATURES = {
     "w2b_comm_init": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
     "w2b_comm_count": (C.c_int, [vp, i32p]),
     "w2b_sync_replicas": (C.c_int, [vp, C.c_int32]),
+    "w2b_suggested_exchange_words": (C.c_int64, [C.c_int64, C.c_int32]),
     "w2b_sync_stats": (C.c_int, [vp, i64p, f64p]),
     "w2b_exchange_init": (C.c_int, [vp]),
     "w2b_exchange_begin": (C.c_int, [vp, i64p, i64p]),

@@ -1729,6 +1729,14 @@ static int xchg_run_rccl(w2b_trainer *t, int32_t mode) {
   return W2B_OK;
 }
 
+extern "C" int64_t w2b_suggested_exchange_words(int64_t train_words_per_epoch, int32_t replicas) {
+  if (replicas < 1) replicas = 1;
+  long long words = train_words_per_epoch / replicas / 32;
+  if (words < 32768) words = 32768;
+  if (words > 1048576) words = 1048576;
+  return words;
+}
+
 extern "C" int w2b_sync_replicas(w2b_trainer *t, int32_t mode) {
   NEED(t);
   if (!t->comm) return W2B_OK;             // a single replica without a communicator: nothing to exchange

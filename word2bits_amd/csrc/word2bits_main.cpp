@@ -334,12 +334,7 @@ int main(int argc, char **argv) {
     // at 32 K / 65 K / 131 K).  Automatic: 1 / 32 of the replica's words per epoch, between 32 768 words and the 1 048 576 at which
     // one full exchange of a 2.56 GB model per launch fits the xGMI links; -sync-words N sets it, -sync-every / -positions keep
     // their old meaning when given.
-    long long words = o.sync_words;
-    if (words <= 0) {
-      words = train_words / o.gpus / 32;
-      if (words < 32768) words = 32768;
-      if (words > 1048576) words = 1048576;
-    }
+    long long words = o.sync_words > 0 ? o.sync_words : w2b_suggested_exchange_words(train_words, o.gpus);
     long long pos = words / (per_gpu > 0 ? per_gpu : 1);
     if (pos < 16) pos = 16;
     if (arg_pos("-positions", argc, argv) > 0 && o.positions < pos) pos = o.positions;     // (an explicit, shorter launch is kept)
