@@ -168,7 +168,8 @@ typedef struct w2b_tuning {
    *     safe step (the same sign at -bitlevel 1): the forward values of the safe rule, the fp32 masters' inertia of one shared
    *     model (-bitlevel 0 has no cells: rule 2);
    *   exchange_rule 1 = the hard threshold of rounds 4-5 (mean for rows with n >= exchange_sat_updates, sum otherwise).
-   * What was measured, including a rule that looked optimal and diverged: DESIGN.md section 3.5. */
+   * The expected update counts come from w2b_set_vocab_counts; without word counts every row keeps the plain sum.
+ * What was measured, including a rule that looked optimal and diverged: DESIGN.md section 3.5. */
   int32_t exchange_rule;
   int32_t exchange_tau_u;
   int32_t exchange_tau_v;
