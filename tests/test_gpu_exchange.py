@@ -369,7 +369,7 @@ def test_eight_replicas_literal_stream(gpu, tmp_path):
     launch of 1 M words is 38 ms on a full device; ring over one link 29 ms, reduce-scatter + all-gather over all seven 4 ms).
     Measured in round 6: +5.0 / +2.0 / +0.2 / -2.1 % of the single replica's epoch loss at 131 K / 262 K / 524 K / 1 M words (round
     5's rule at 1 M words: -12.6 %, worse than not exchanging at all).  Gate: 3 % each.  (The single replica is run with the same launches: its own epoch loss moves by 1.6 %
-    between launches of 1024 and 8192 positions -- the per-XCD copies are folded at every launch boundary.)"""
+    between launches of 1024 and 8192 positions -- a launch boundary is a device-wide barrier.)"""
     from w2b_testlib import write_headline_corpus
     path = write_headline_corpus(str(tmp_path / "c.txt"), n_zipf=98_000_000)
     corpus = w2b.Corpus(path, 5)
