@@ -65,9 +65,6 @@ struct w2b_trainer {
   hipEvent_t rc_go = nullptr, rc_end = nullptr;
   int xhot_nu = -1, xhot_nv = -1;       // layout the buffer currently has (-1: none)
   bool xhot_master_changed = true;      // the master rows may differ from what the copies were folded into
-  bool xhot_dirty = false;              // the per-XCD copies hold progress that has not been folded into the master rows yet
-  W2bParams xhot_last{};                // parameters of the launch that left them so (what the fold needs)
-  long long xhot_positions = 0;         // sentence positions per worker trained since the last fold
   bool debug = false;           // W2B_DEBUG was set when the trainer was created (diagnostics on stderr)
   const int32_t *corpus = nullptr;
   int32_t *corpus_owned = nullptr;
@@ -335,9 +332,7 @@ extern "C" int w2b_trainer_create(const w2b_config *cfg, w2b_trainer **out) {
   return W2B_OK;
 }
 
-static int xhot_flush(w2b_trainer *t);      // the per-XCD copies meet their master rows now, if they hold unfolded progress (below)
-static int xhot_after_launch(w2b_trainer *t, const W2bParams &p, long long positions, bool now);
-static int xchg_fence(w2b_trainer *t);      // the training stream waits for a replica exchange in flight (below); flushes the copies first
+static int xchg_fence(w2b_trainer *t);      // the training stream waits for a replica exchange in flight (below)
 static void xchg_teardown(w2b_trainer *t);  // streams, events and buffers of the replica exchange
 
 extern "C" void w2b_trainer_destroy(w2b_trainer *t) {
@@ -1041,8 +1036,6 @@ static int wide_prepare(w2b_trainer *t, W2bParams &p, long long workgroups) {
 static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool with_u) {
   int nu = 0, nv = 0;
   xhot_plan(t, workers, with_u, &nu, &nv, false);
-  if (t->xhot_dirty && (nu != t->xhot_nu || nv != t->xhot_nv))       // another layout (or none): the old copies' progress first
-    if (int rc = xhot_flush(t)) return rc;
   p.xhot = nullptr;
   p.xhot_u = nu;
   p.xhot_v = nv;
@@ -1090,10 +1083,7 @@ static int xhot_prepare(w2b_trainer *t, W2bParams &p, long long workers, bool wi
     t->xhot_nv = nv;
     t->xhot_master_changed = true;
   }
-  if (t->xhot_master_changed) {       // (dirty copies AND changed masters meet by the same consensus rule)
-    HIPCHK(w2b_launch_xhot_fold(p, t->stream));
-    t->xhot_dirty = false;
-  }
+  if (t->xhot_master_changed) HIPCHK(w2b_launch_xhot_fold(p, t->stream));
   t->xhot_master_changed = false;
   return W2B_OK;
 }
@@ -1272,7 +1262,7 @@ extern "C" int w2b_train_step(w2b_trainer *t, int64_t max_positions) {
   }
   HIPCHK(timing_end(t));
   if (p.rc_rows > 0) HIPCHK(hipStreamWaitEvent(t->stream, t->rc_end, 0));   // (what follows on this stream also follows the refresher's end)
-  if (int rc = xhot_after_launch(t, p, max_positions, false)) return rc;   // fold on the word schedule (see xhot_flush)
+  HIPCHK(w2b_launch_xhot_fold(p, t->stream));      // the master rows are complete again when the stream is idle
   {   // progress snapshot of this launch for w2b_epoch_poll (asynchronous; pinned host memory)
     if (!t->poll_host) {
       HIPCHK(hipHostMalloc((void **)&t->poll_host, sizeof(W2bShared) * w2b_trainer::kPoll, hipHostMallocDefault));
@@ -1356,7 +1346,7 @@ extern "C" int w2b_train_tuples_device(w2b_trainer *t, int64_t n, const void *ce
                            (const int32_t *)neg, alpha, grid > 0 ? grid : 0, t->num_cus, t->tune.grid_per_cu,
                            t->cfg.compute_loss != 0, t->stream));
   HIPCHK(timing_end(t));
-  if (int rc = xhot_after_launch(t, p, 0, true)) return rc;    // (form ii: the master rows are complete after every call)
+  HIPCHK(w2b_launch_xhot_fold(p, t->stream));
   return W2B_OK;
 }
 
@@ -1510,33 +1500,7 @@ static int xchg_setup(w2b_trainer *t) {
 }
 
 // The training stream (and with it every reader of the model) waits for the exchange in flight.
-// Round 6: the copies are folded into the master rows on a WORD schedule, not at every launch boundary.  The fold is one more
-// consensus merge of all eight copies, so folding after every launch made the epoch loss depend on the launch length (configs[1]
-// literally, one replica: +0.3 % of the reference with launches of 8192 positions, -0.5 % with the command line's 4096, -1.3 % with
-// bench.py's 1024).  Now a fold happens once W2B_FOLD_POSITIONS positions per worker have been trained since the last one -- the
-// command line's launches behave exactly as before, shorter launches (bench.py, tests) like the command line's -- and whenever
-// somebody reads or writes the model (every such entry point passes through xchg_fence), starts a replica exchange, or the
-// layout of the copies changes.
-static const long long W2B_FOLD_POSITIONS = 4096;
-static int xhot_flush(w2b_trainer *t) {
-  if (!t->xhot_dirty) return W2B_OK;
-  HIPCHK(w2b_launch_xhot_fold(t->xhot_last, t->stream));
-  t->xhot_dirty = false;
-  t->xhot_positions = 0;
-  return W2B_OK;
-}
-// a training launch with copies has been issued: fold now or later
-static int xhot_after_launch(w2b_trainer *t, const W2bParams &p, long long positions, bool now) {
-  if (!p.xhot || p.xhot_u + p.xhot_v <= 0) return W2B_OK;
-  t->xhot_last = p;
-  t->xhot_dirty = true;
-  t->xhot_positions += positions;
-  if (now || t->xhot_positions >= W2B_FOLD_POSITIONS) return xhot_flush(t);
-  return W2B_OK;
-}
-
 static int xchg_fence(w2b_trainer *t) {
-  if (int rc = xhot_flush(t)) return rc;
   if (!t->x_pending) return W2B_OK;
   for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->stream, t->x_done[k], 0));
   t->x_pending = false;
@@ -1636,9 +1600,7 @@ static int xchg_begin(w2b_trainer *t) {
     (void)hipEventDestroy(t->x_ev[1]);
     t->x_ev.erase(t->x_ev.begin(), t->x_ev.begin() + 2);
   }
-  // the exchange sees every launch issued so far (and nothing forces the launches issued later to wait for a FULL exchange);
-  // it reads the master rows: the copies' progress goes in first
-  if (int rc = xhot_flush(t)) return rc;
+  // the exchange sees every launch issued so far (and nothing forces the launches issued later to wait for a FULL exchange)
   HIPCHK(hipEventRecord(t->x_train, t->stream));
   for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent(t->xs[k], t->x_train, 0));
   // ... and follows the PREVIOUS exchange on both of its streams: the collective stream's first operations of this exchange
