@@ -164,9 +164,9 @@ typedef struct w2b_tuning {
    *     n = expected updates of the row per replica since the last exchange (from the word counts): the sum for rarely updated
    *     rows, the mean for rows every replica has saturated, everything in between; exchange_tau_u / exchange_tau_v = tau for rows
    *     of u / v in updates (0 = the library's default, 64);
-   *   exchange_rule 0 (default) = the same, and per ELEMENT the whole sum wherever it lands in the same quantization cell as that
-   *     safe step (the same sign at -bitlevel 1): the forward values of the safe rule, the fp32 masters' inertia of one shared
-   *     model (-bitlevel 0 has no cells: rule 2);
+   *   exchange_rule 0 (default) = the same, and at -bitlevel 1 per ELEMENT the whole sum wherever it keeps the sign the safe step
+   *     gives (the quantization cell of one bit): the forward values of the safe rule, the fp32 masters' inertia of one shared
+   *     model.  Every other bitlevel: rule 2 (with more bits a master's magnitude is part of the forward value; measured);
    *   exchange_rule 1 = the hard threshold of rounds 4-5 (mean for rows with n >= exchange_sat_updates, sum otherwise).
    * The expected update counts come from w2b_set_vocab_counts; without word counts every row keeps the plain sum.
  * What was measured, including a rule that looked optimal and diverged: DESIGN.md section 3.5. */
@@ -304,7 +304,7 @@ int w2b_comm_count(w2b_trainer *t, int32_t *nranks_out);
 /* mode 0: delta-sum (a = 1);  mode 1: average of the deltas (a = 1/R);  mode 2 (what ./word2bits -gpus N uses; round 6): a
  * per-row factor on the summed delta from the row's expected number of updates per replica since the last exchange -- the sum
  * for rarely updated rows, towards the mean of the c replicas that changed it for rows every replica has saturated -- decides
- * every element's QUANTIZED value, and the whole sum is taken wherever it lands in the same quantization cell (w2b_tuning.
+ * every element's QUANTIZED value, and at -bitlevel 1 the whole sum is taken wherever it keeps that sign (w2b_tuning.
  * exchange_rule; a row that only one replica saw keeps that replica's whole update, which mode 1 divides by R; mode 0 diverges
  * from 4 replicas on).  Measured in tests/test_gpu_exchange.py: 2 / 4 / 8 replicas on one GPU through the phase API below.
  * Asynchronous (see above). */

@@ -157,8 +157,8 @@ def test_phase_api_arithmetic_two_replicas(gpu, mode):
     """W_r += comb - d_r on top of the CURRENT rows, base += comb, against host arithmetic on copies of both replicas.
     comb = a * sum with a = 1 (mode 0) / 1/R (mode 1); mode 2: a per-row factor k on the sum -- exponential saturation
     (exchange_rule 2), or rounds 4-5's 1 / contributors for the saturated rows (exchange_rule 1) -- and, by default (exchange_rule
-    0), per element the whole sum wherever base + sum lies in the quantization cell of base + k * sum (one bit: the same sign; two
-    bits: the same sign and the same side of |x| = 0.5)."""
+    0) at ONE bit, per element the whole sum wherever base + sum has the sign of base + k * sum (its quantization cell); at two bits
+    exchange_rule 0 is the saturation factor alone (the cells were measured to do harm there: -9.4 % against -1.9 %)."""
     R, nw = 2, 4
     rule = {"2 saturation only": 2, "2 hard threshold": 1}.get(mode, 0)
     bitlevel = 2 if mode == "2 two bits" else 1
@@ -199,7 +199,7 @@ def test_phase_api_arithmetic_two_replicas(gpu, mode):
                 assert ((k[both] > 0.6) & (k[both] < 0.9)).any()
                 assert (k[~both] == 1).all()
             safe = k.astype(np.float32)[:, None].repeat(D, 1).ravel() * S
-            if rule == 0:
+            if rule == 0 and bitlevel == 1:
                 same = host_cell(base + safe, bitlevel) == host_cell(base + S, bitlevel)
                 assert 0.5 < same.mean() < 1.0 and (~same).sum() > 100              # both branches are exercised
                 total, alt = np.where(same, S, safe), np.where(same, safe, S)

@@ -1644,7 +1644,10 @@ static int xchg_delta(w2b_trainer *t, long long c) {
 //   * rule 0, the default: exponential saturation decides every element's QUANTIZED value, and where the whole sum lands in the
 //     same quantization cell it is taken instead (k_xchg_apply) -- the forward values of the stable rule, the masters' inertia of a
 //     shared model: -2.9 % at 131 K words per replica on the 22 M-token proxy (-0.3 % with doubling intervals), -0.5 % on the
-//     literal configs[1] stream at 1 M words.
+//     literal configs[1] stream at 1 M words.  ONE BIT ONLY: there a forward value is a sign and a master's magnitude is pure inertia.
+//     With more bits the magnitude is part of the forward value and the cells do harm -- two bits, same proxy at 86 K words: cells
+//     -9.4 %, saturation alone -1.9 %, the sign alone as the criterion diverges (four bits: cells -6.3 %; profiles/r06_sessions/r06o,
+//     r06p) -- so every other bitlevel runs the saturation factor alone.
 // contributor counts in xcnt -> factors on the summed delta (k_xchg_factor), once per exchange, on stream q
 static const double W2B_XCHG_TAU_U = 64.0, W2B_XCHG_TAU_V = 64.0;   // updates that move a row most of the way
 static int xchg_factor(w2b_trainer *t, hipStream_t q) {
@@ -1662,7 +1665,7 @@ static int xchg_apply(w2b_trainer *t, long long c, float scale) {
   const int k = (int)(c & 1);
   if (t->x_use_cnt) if (int rc = xchg_factor(t, t->xs[0])) return rc;
   HIPCHK(w2b_launch_xchg_apply(t->uv + r.off, t->base + r.off, t->xd[k], t->xsum[k], scale, r.len, t->x_use_cnt ? t->xcnt : nullptr,
-                               r.off, t->cfg.layer1_size, t->cfg.bitlevel, t->tune.exchange_rule == 0 ? 1 : 0, t->xs[0]));
+                               r.off, t->cfg.layer1_size, t->cfg.bitlevel, (t->tune.exchange_rule == 0 && t->cfg.bitlevel == 1) ? 1 : 0, t->xs[0]));
   return W2B_OK;
 }
 // per row of [u || v]: has this replica changed it since the last exchange?

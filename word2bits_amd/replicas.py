@@ -96,7 +96,7 @@ class TorchReplicaSync:
     `model` is the flat [u || v] tensor of this rank, `base` the snapshot taken at the previous exchange.
       mode 0: delta-sum;  mode 1: average;
       mode 2: the library's default rule -- per row the saturation factor on the summed delta decides every
-              element's quantized value, and the whole sum is taken wherever it lands in the same quantization cell.  Needs
+              element's quantized value, and at bitlevel 1 the whole sum is taken wherever it keeps that sign.  Needs
               `rate` ([2 V] expected updates per centre word), `dim`, `bitlevel`, and per call `words` (centre words per replica
               since the last exchange).
     With world size 1 every mode leaves `model` bit-identical (no arithmetic is done)."""
@@ -127,7 +127,7 @@ class TorchReplicaSync:
             self.dist.all_reduce(d)                                        # S
             k = saturation_factors(self.rate, words, touched, *self.tau)
             safe = d * k.repeat_interleave(self.dim)
-            if self.cells and self.bitlevel != 0:
+            if self.cells and self.bitlevel == 1:          # (one bit only: with more bits the cells do harm)
                 same = quantization_cell(base + safe, self.bitlevel) == quantization_cell(base + d, self.bitlevel)
                 comb = torch.where(same, d, safe)
             else:
